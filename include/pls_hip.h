@@ -1,0 +1,180 @@
+/*
+ * pls_hip.h -- C-ABI of the MI355X (gfx950) PLS fit / predict hot path.
+ *
+ * This is the drop-in boundary for the body of PLS::Model::plsr and the products
+ * behind Model::scores / coefficients / fitted_values of tjhladish/PLS:
+ *
+ *   reference interface                                   replaced by
+ *   ----------------------------------------------------  --------------------------
+ *   void Model::plsr(const Mat2D&, const Mat2D&, METHOD)   pls_hip_fit
+ *     include/PLS/pls.h:199, src/pls.cpp:390-437
+ *   const Mat2Dc Model::coefficients(size_t)               pls_hip_coefficients
+ *     include/PLS/pls.h:214, src/pls.cpp:444-447
+ *   const Mat2D  Model::fitted_values(const Mat2D&,size_t) pls_hip_xb  (X_new * B)
+ *     include/PLS/pls.h:218, src/pls.cpp:449-451
+ *   const Mat2Dc Model::scores(const Mat2D&, size_t)       pls_hip_xb  (X_new * R[:, :c])
+ *     include/PLS/pls.h:203, src/pls.cpp:439-442
+ *
+ * The reference has no FFI of its own (it is a C++ library on Eigen); the binding a
+ * maintainer adds is the body of Model::plsr in src/pls.cpp -- shown in INTEGRATION.md and
+ * shipped in pls_amd/host/pls.cpp.
+ *
+ * Conventions (the reference's, include/PLS/pls.h:22-27): every matrix is COLUMN-MAJOR
+ * with an explicit leading dimension in elements (ld >= rows); dimensions are 64-bit.
+ * X is N x K (samples x predictors), Y is N x M, A components.  W,P,R are K x A, Q is
+ * M x A, B is K x M, T is N x A.  W,P,Q,R,B and every vector are always fp64; X, Y and T
+ * use the storage dtype of the call (fp64, or fp32 storage with fp64 accumulation).
+ * All results are real: the reference's std::complex containers (include/PLS/pls.h:26-27)
+ * always hold zero imaginary parts and are rebuilt at the C++ boundary.
+ *
+ * No torch types, no C++ types, no exceptions cross this boundary; every entry point
+ * returns a pls_hip_status and never calls exit().  There is NO CPU fallback: without a
+ * gfx950 device every compute entry point fails with PLS_HIP_ERR_DEVICE.
+ */
+#ifndef PLS_HIP_H
+#define PLS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLS_HIP_ABI_VERSION 1
+
+#if defined(PLS_HIP_BUILDING)
+#define PLS_HIP_API __attribute__((visibility("default")))
+#else
+#define PLS_HIP_API
+#endif
+
+typedef struct pls_hip_context *pls_hip_handle;
+
+typedef enum {
+    PLS_HIP_OK = 0,
+    PLS_HIP_ERR_INVALID = 1,     /* bad shape / pointer / enum (the reference only assert()s: src/pls.cpp:345-347) */
+    PLS_HIP_ERR_DEVICE = 2,      /* HIP runtime error or no usable gfx950 device */
+    PLS_HIP_ERR_ALLOC = 3,       /* device allocation failed */
+    PLS_HIP_ERR_UNSUPPORTED = 4, /* valid request this build does not implement */
+    PLS_HIP_ERR_REDUCER = 5      /* the injected all-reduce returned non-zero */
+} pls_hip_status;
+
+/* PLS::METHOD, include/PLS/pls.h:131 */
+typedef enum { PLS_HIP_KERNEL_TYPE1 = 0, PLS_HIP_KERNEL_TYPE2 = 1 } pls_hip_method;
+
+typedef enum { PLS_HIP_F64 = 0, PLS_HIP_F32 = 1 } pls_hip_dtype;
+
+/* where the caller's X/Y/outputs live */
+typedef enum { PLS_HIP_MEM_HOST = 0, PLS_HIP_MEM_DEVICE = 1 } pls_hip_mem;
+
+/* How the score/loading passes treat X (identical W,P,Q,R,T,B up to rounding):
+ *  KERNEL : the reference's operation sequence -- X is read-only, only the K x M matrix
+ *           XY is deflated (src/pls.cpp:419-429).
+ *  NIPALS : the north-star sequence -- t = X_a w, p = X_a^T t, then the rank-1 deflation
+ *           X_{a+1} = X_a - t p^T on a library-owned working copy. */
+typedef enum { PLS_HIP_ALGO_KERNEL = 0, PLS_HIP_ALGO_NIPALS = 1 } pls_hip_algo;
+
+typedef enum {
+    PLS_HIP_OPT_ALGO = 1,       /* pls_hip_algo; default PLS_HIP_ALGO_KERNEL */
+    PLS_HIP_OPT_FUSE = 2,       /* 0: one kernel per product (Xv, X^T t, deflate); 1 (default): row-tile-resident fused pass when the shape allows */
+    PLS_HIP_OPT_PROFILE = 3,    /* 1: bracket every kernel family with HIP events on the launch stream */
+    PLS_HIP_OPT_POWER_ITERS = 4 /* squarings of the S^T S power iteration (m > 1); default 48 */
+} pls_hip_option;
+
+/*
+ * In-place sum over ranks of `count` fp64 values at DEVICE address `buf`, ordered on
+ * `stream` (a hipStream_t).  Must leave bit-identical results on every rank.  Called
+ * 1 + A times per fit: once with count = K*M (the X^T Y partial), then once per
+ * component with count = K+1 (packed [X^T t, t^T t]).  Return 0 on success.
+ */
+typedef int (*pls_hip_allreduce_fn)(void *user, void *buf, int64_t count, void *stream);
+
+/* Per-family device time of the most recent fit (filled only with PLS_HIP_OPT_PROFILE=1;
+ * ms from hipEventElapsedTime on the launch stream) and launch counts. */
+enum {
+    PLS_HIP_FAM_XTY = 0,     /* X^T Y  and  X^T t   (column reductions)           */
+    PLS_HIP_FAM_XB = 1,      /* t = X v, X B        (row products)                */
+    PLS_HIP_FAM_DEFLATE = 2, /* X -= t p^T                                        */
+    PLS_HIP_FAM_FUSED = 3,   /* tile-resident fused pass ([deflate +] score + loading) */
+    PLS_HIP_FAM_SMALL = 4,   /* partial reduction + per-component K-sized bookkeeping */
+    PLS_HIP_FAM_COUNT = 5
+};
+typedef struct {
+    double fit_ms;                       /* whole fit, first launch to last            */
+    double fam_ms[PLS_HIP_FAM_COUNT];    /* summed over launches of the family        */
+    int64_t fam_launches[PLS_HIP_FAM_COUNT];
+    int64_t fam_bytes[PLS_HIP_FAM_COUNT]; /* ALGORITHMIC bytes summed over those launches */
+} pls_hip_timing;
+
+/* ---- lifetime ------------------------------------------------------------------- */
+
+PLS_HIP_API int pls_hip_abi_version(void);
+
+/* device: HIP ordinal.  stream: the hipStream_t every kernel, copy and event of this handle is
+ * issued on; NULL = the device's default (null) stream.  Fails with PLS_HIP_ERR_DEVICE if the
+ * device is not gfx950. */
+PLS_HIP_API int pls_hip_create(pls_hip_handle *out, int device, void *stream);
+PLS_HIP_API int pls_hip_destroy(pls_hip_handle h);
+PLS_HIP_API int pls_hip_set_stream(pls_hip_handle h, void *stream);
+PLS_HIP_API int pls_hip_set_option(pls_hip_handle h, int option, int64_t value);
+PLS_HIP_API int pls_hip_get_option(pls_hip_handle h, int option, int64_t *value);
+/* Row-sharded fit over `nranks` processes (one per GPU): every rank passes its own row
+ * block and the same K, M, A; fn sums the small partial products.  fn == NULL: single rank. */
+PLS_HIP_API int pls_hip_set_reducer(pls_hip_handle h, pls_hip_allreduce_fn fn, void *user, int rank, int nranks);
+/* Optional caller-owned DEVICE staging buffer for the reducer (>= max(K*M, K+1) fp64), so a
+ * host runtime can hand its collective a buffer it allocated itself. */
+PLS_HIP_API int pls_hip_set_reduce_buffer(pls_hip_handle h, void *buf, int64_t count);
+PLS_HIP_API int pls_hip_synchronize(pls_hip_handle h);
+PLS_HIP_API const char *pls_hip_last_error(pls_hip_handle h);
+PLS_HIP_API int pls_hip_get_timing(pls_hip_handle h, pls_hip_timing *out);
+
+/* ---- the hot path --------------------------------------------------------------- */
+
+/*
+ * Fit A components: the body of Model::plsr (src/pls.cpp:390-437).
+ * X, Y are never written.  T may be NULL for PLS_HIP_KERNEL_TYPE2 only.  B (K x M, ld K)
+ * may be NULL; otherwise it receives coefficients(A) = R Q^T (src/pls.cpp:444-447).
+ * mem == DEVICE: all pointers are device pointers, the call only enqueues work on the
+ * stream (pls_hip_synchronize or the caller's own stream sync completes it).
+ * mem == HOST: pointers are host memory; the call copies in, fits, copies out and returns
+ * with the results in place.
+ * Shapes follow the reference's asserts (src/pls.cpp:345-347): 1 <= A <= K, N >= 1
+ * (N may be 0 on a rank of a sharded fit), M >= 1 (M <= 32 when M > 1).
+ * A > rank(X) yields inf/NaN in the surplus columns, as in the reference (:427-428).
+ */
+PLS_HIP_API int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy,
+                int64_t N, int64_t K, int64_t M, int64_t A, int method, int dtype, int mem,
+                double *W, double *P, double *Q, double *R, void *T, int64_t ldt, double *B);
+
+/* B(K x M) = R[:, :c] Q[:, :c]^T.  Model::coefficients, src/pls.cpp:444-447. */
+PLS_HIP_API int pls_hip_coefficients(pls_hip_handle h, const double *R, const double *Q, int64_t K,
+                         int64_t M, int64_t A, int64_t c, int mem, double *B);
+
+/* out(N x C) = X(N x K) * Bm(K x C); Bm fp64, X/out in `dtype`.
+ * Model::fitted_values (Bm = B, src/pls.cpp:449-451), Model::scores (Bm = R[:, :c], :439-442). */
+PLS_HIP_API int pls_hip_xb(pls_hip_handle h, const void *X, int64_t ldx, int64_t N, int64_t K,
+               const double *Bm, int64_t ldb, int64_t C, int dtype, int mem, void *out,
+               int64_t ldo);
+
+/* ---- single steps of the path on DEVICE pointers (parity tests, bench, profiling) -- */
+
+/* XY(K x M, ld K, fp64) = X^T Y   (src/pls.cpp:396; with Y = t, M = 1: src/pls.cpp:421) */
+PLS_HIP_API int pls_hip_xty(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy,
+                int64_t N, int64_t K, int64_t M, int dtype, double *XY);
+/* dst = src - t p^T  (N x K; dst may equal src).  The north-star rank-1 deflation. */
+PLS_HIP_API int pls_hip_deflate(pls_hip_handle h, const void *src, int64_t lds, void *dst, int64_t ldd,
+                    int64_t N, int64_t K, const void *t, const double *p, int dtype);
+
+/* ---- synthetic inputs, generated on the device (DESIGN.md "Synthetic inputs") ------ */
+
+/* rows [row0, row0+nrows) of the global matrix -> X (nrows x K, ld ldx) / Y (nrows x M) */
+PLS_HIP_API int pls_hip_synth_x(pls_hip_handle h, void *X, int64_t ldx, int64_t row0, int64_t nrows,
+                    int64_t K, uint64_t seed, int dtype);
+PLS_HIP_API int pls_hip_synth_y(pls_hip_handle h, void *Y, int64_t ldy, int64_t row0, int64_t nrows,
+                    int64_t M, uint64_t seed, int dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLS_HIP_H */

@@ -1,0 +1,59 @@
+// Shared device helpers for the gfx950 PLS kernels.  Wave = 64 lanes, workgroup = 256 threads
+// unless a kernel says otherwise.  All reductions are fixed-order (no float atomics) so a
+// fit is bit-reproducible run to run and bit-identical across the ranks of a sharded fit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plsk {
+
+typedef int64_t i64;
+
+constexpr int WAVE = 64;
+constexpr int WG = 256;
+
+// VEC consecutive rows of one column = one 16-byte (or narrower) global access per lane.
+template <typename T, int V>
+struct alignas(sizeof(T) * V) Pack {
+    T v[V];
+};
+
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> ld_pack(const T *p) {
+    return *reinterpret_cast<const Pack<T, V> *>(p);
+}
+template <typename T, int V>
+__device__ __forceinline__ void st_pack(T *p, const Pack<T, V> &x) {
+    *reinterpret_cast<Pack<T, V> *>(p) = x;
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double x, int mask) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __shfl_xor(lo, mask, WAVE);
+    hi = __shfl_xor(hi, mask, WAVE);
+    return __hiloint2double(hi, lo);
+}
+
+// butterfly sum over the 64 lanes of a wave: every lane ends with the same bits
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += shfl_xor_f64(x, m);
+    return x;
+}
+
+// Sum over a workgroup of NW waves (blockDim.x = 64*NW); result valid in every thread.
+// smem: >= NW doubles.  Fixed order: butterfly inside the wave, then waves 0..NW-1.
+template <int NW>
+__device__ __forceinline__ double block_sum(double x, double *smem) {
+    x = wave_sum(x);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) smem[w] = x;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += smem[i];
+    return s;
+}
+
+}  // namespace plsk

@@ -1,0 +1,777 @@
+// pls_hip.hip -- the C-ABI of include/pls_hip.h over the gfx950 kernels in this directory.
+// Host side of the library: argument checks, workspace, launch geometry, the A-loop of
+// Model::plsr (src/pls.cpp:390-437) enqueued on one HIP stream with no host round trip,
+// the injected all-reduce for row-sharded fits, HIP-event profiling.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pls_hip.h"
+#include "fused_kernels.hpp"
+#include "small_kernels.hpp"
+#include "stream_kernels.hpp"
+#include "synth_kernels.hpp"
+
+using plsk::i64;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Launch {
+    int fam;
+    i64 bytes;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct pls_hip_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    pls_hip_allreduce_fn reducer = nullptr;
+    void *reducer_user = nullptr;
+    int rank = 0, nranks = 1;
+    double *user_red = nullptr;
+    i64 user_red_count = 0;
+    i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
+    DevBuf part, sspart, red, xy, v, tab, work, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
+    std::string err;
+    // profiling
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<Launch> launches;
+    hipEvent_t fit0 = nullptr, fit1 = nullptr;
+    bool fit_timed = false;
+    int num_cu = 256;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);               \
+            return PLS_HIP_ERR_DEVICE;                                                     \
+        }                                                                                  \
+    } while (0)
+
+#define CHK(expr)                      \
+    do {                               \
+        int rc__ = (expr);             \
+        if (rc__ != PLS_HIP_OK) return rc__; \
+    } while (0)
+
+int fail(pls_hip_context *c, int code, const std::string &msg) {
+    c->err = msg;
+    return code;
+}
+
+int ensure(pls_hip_context *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.bytes && b.p) return PLS_HIP_OK;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // earlier launches may still read it
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    bytes = std::max<size_t>(bytes, 256);
+    if (hipMalloc(&b.p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        b.p = nullptr;
+        return fail(c, PLS_HIP_ERR_ALLOC, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
+    }
+    b.bytes = bytes;
+    return PLS_HIP_OK;
+}
+
+size_t esize(int dtype) { return dtype == PLS_HIP_F64 ? 8 : 4; }
+
+// ---- profiling ------------------------------------------------------------------------
+hipEvent_t take_event(pls_hip_context *c) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+struct Scope {  // brackets one launch with events when profiling is on
+    pls_hip_context *c;
+    Launch l{};
+    bool on;
+    Scope(pls_hip_context *ctx, int fam, i64 bytes) : c(ctx), on(ctx->opt_profile != 0) {
+        if (!on) return;
+        l.fam = fam;
+        l.bytes = bytes;
+        l.e0 = take_event(c);
+        l.e1 = take_event(c);
+        if (!l.e0 || !l.e1) { on = false; return; }
+        (void)hipEventRecord(l.e0, c->stream);
+    }
+    ~Scope() {
+        if (!on) return;
+        (void)hipEventRecord(l.e1, c->stream);
+        c->launches.push_back(l);
+    }
+};
+
+#define LAUNCH_CHECK(ctx)                                                           \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            (ctx)->err = std::string("kernel launch: ") + hipGetErrorString(e__);   \
+            return PLS_HIP_ERR_DEVICE;                                              \
+        }                                                                           \
+    } while (0)
+
+template <typename T>
+bool vec_ok(const void *p, i64 ld, int vec) {
+    return ((uintptr_t)p % (sizeof(T) * vec) == 0) && (ld % vec == 0);
+}
+
+// ---- geometry -------------------------------------------------------------------------
+constexpr int XTY_KCMT = 32;  // accumulators per lane in xty_kernel
+constexpr int DEFL_KC = 32;
+
+struct XtyGeom {
+    int G;    // row groups = number of partial rows (same for every m-tile of one product)
+    int nkg;  // column groups of this m-tile
+};
+// G is derived from the widest column group (KC = 32) so that all m-tiles of one X^T Y write
+// the same number of partial rows; narrower tiles simply launch more workgroups.
+XtyGeom xty_geom(i64 N, int K, int KC, int vec, int target_wgs) {
+    XtyGeom g;
+    g.nkg = (K + KC - 1) / KC;
+    const int nkg32 = (K + XTY_KCMT - 1) / XTY_KCMT;
+    const i64 nch = (N + (i64)plsk::WG * vec - 1) / ((i64)plsk::WG * vec);
+    i64 G = std::max<i64>(1, target_wgs / nkg32);
+    G = std::min<i64>(G, std::max<i64>(nch, 1));
+    g.G = (int)G;
+    return g;
+}
+// upper bound of partial rows any product of this fit can write
+i64 max_partial_rows(pls_hip_context *c, i64 N, int K) {
+    const int nkg32 = (K + XTY_KCMT - 1) / XTY_KCMT;
+    const i64 nch = (N + plsk::WG - 1) / plsk::WG;  // vec = 1 is the worst case
+    const i64 G = std::min<i64>(std::max<i64>(1, (8 * c->num_cu) / nkg32), std::max<i64>(nch, 1));
+    return std::max<i64>(G, 4 * (i64)c->num_cu);
+}
+
+// ---- typed launchers --------------------------------------------------------------------
+template <typename T, int VEC, int MT>
+void launch_xb_t(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const double *Bm, i64 ldb,
+                 T *out, i64 ldo, double *sspart, int *nss) {
+    const i64 per = (i64)plsk::WG * VEC;
+    const int nblk = (int)((N + per - 1) / per);
+    if (sspart) {
+        hipLaunchKernelGGL((plsk::xb_kernel<T, VEC, MT, true>), dim3(nblk), dim3(plsk::WG), 0,
+                           c->stream, X, ldx, N, K, Bm, ldb, out, ldo, sspart);
+        *nss = nblk;
+    } else {
+        hipLaunchKernelGGL((plsk::xb_kernel<T, VEC, MT, false>), dim3(nblk), dim3(plsk::WG), 0,
+                           c->stream, X, ldx, N, K, Bm, ldb, out, ldo, (double *)nullptr);
+    }
+}
+
+// out(N x C) = X * Bm ; optionally sum of squares partials of column 0 (C must be 1 then)
+template <typename T>
+int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const double *Bm, i64 ldb,
+              int C, T *out, i64 ldo, double *sspart, int *nss) {
+    constexpr int FV = 16 / sizeof(T);
+    bool wide = vec_ok<T>(X, ldx, FV) && vec_ok<T>(out, ldo, FV);
+    // keep >= ~4 workgroups per CU in flight: narrow the per-lane access on short matrices
+    if (wide && N / ((i64)FV * plsk::WG) < 4 * (i64)c->num_cu) wide = false;
+    int c0 = 0;
+    while (c0 < C) {
+        const int mt = (C - c0 >= 4) ? 4 : (C - c0 >= 2 ? 2 : 1);
+        const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * mt * sizeof(T) + (i64)K * mt * 8;
+        Scope s(c, PLS_HIP_FAM_XB, bytes);
+        const double *b = Bm + (i64)c0 * ldb;
+        T *o = out + (i64)c0 * ldo;
+#define XB_CASE(V, M_)                                                                  \
+    launch_xb_t<T, V, M_>(c, X, ldx, N, K, b, ldb, o, ldo, sspart, nss)
+        if (wide) {
+            if (mt == 4) XB_CASE(FV, 4); else if (mt == 2) XB_CASE(FV, 2); else XB_CASE(FV, 1);
+        } else {
+            if (mt == 4) XB_CASE(1, 4); else if (mt == 2) XB_CASE(1, 2); else XB_CASE(1, 1);
+        }
+#undef XB_CASE
+        LAUNCH_CHECK(c);
+        c0 += mt;
+    }
+    return PLS_HIP_OK;
+}
+
+template <typename T, int VEC, int KC, int MT>
+void launch_xty_t(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64 N, int K, int M,
+                  int m0, double *part, const XtyGeom &g) {
+    hipLaunchKernelGGL((plsk::xty_kernel<T, VEC, KC, MT>), dim3(g.G, g.nkg), dim3(plsk::WG), 0,
+                       c->stream, X, ldx, Y, ldy, N, K, M, m0, part);
+}
+
+// part[G][K*M] = per-row-group partials of X^T Y; returns G through *nb
+template <typename T>
+int launch_xty(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64 N, int K, int M,
+               double *part, int *nb) {
+    constexpr int FV = 16 / sizeof(T);
+    const bool wide = vec_ok<T>(X, ldx, FV) && vec_ok<T>(Y, ldy, FV);
+    const int target = 8 * c->num_cu;
+    int m0 = 0;
+    while (m0 < M) {
+        const int mt = (M - m0 >= 8) ? 8 : (M - m0 >= 4 ? 4 : (M - m0 >= 2 ? 2 : 1));
+        const int kc = XTY_KCMT / mt;
+        const XtyGeom g = xty_geom(N, K, kc, wide ? FV : 1, target);
+        *nb = g.G;
+        const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * mt * sizeof(T) + (i64)K * mt * 8;
+        Scope s(c, PLS_HIP_FAM_XTY, bytes);
+#define XTY_CASE(V, KC_, M_) launch_xty_t<T, V, KC_, M_>(c, X, ldx, Y, ldy, N, K, M, m0, part, g)
+        if (wide) {
+            if (mt == 8) XTY_CASE(FV, 4, 8); else if (mt == 4) XTY_CASE(FV, 8, 4);
+            else if (mt == 2) XTY_CASE(FV, 16, 2); else XTY_CASE(FV, 32, 1);
+        } else {
+            if (mt == 8) XTY_CASE(1, 4, 8); else if (mt == 4) XTY_CASE(1, 8, 4);
+            else if (mt == 2) XTY_CASE(1, 16, 2); else XTY_CASE(1, 32, 1);
+        }
+#undef XTY_CASE
+        LAUNCH_CHECK(c);
+        m0 += mt;
+    }
+    return PLS_HIP_OK;
+}
+
+template <typename T>
+int launch_deflate(pls_hip_context *c, const T *src, i64 lds, T *dst, i64 ldd, i64 N, int K,
+                   const T *t, const double *p) {
+    constexpr int FV = 16 / sizeof(T);
+    const bool wide = vec_ok<T>(src, lds, FV) && vec_ok<T>(dst, ldd, FV) && vec_ok<T>(t, FV, FV);
+    const int nkg = (K + DEFL_KC - 1) / DEFL_KC;
+    const int vec = wide ? FV : 1;
+    const i64 nch = (N + (i64)plsk::WG * vec - 1) / ((i64)plsk::WG * vec);
+    const i64 G = std::min<i64>(std::max<i64>(nch, 1), std::max<i64>(1, (16 * c->num_cu) / nkg));
+    const i64 bytes = 2 * (i64)N * K * sizeof(T) + (i64)N * sizeof(T) + (i64)K * 8;
+    Scope s(c, PLS_HIP_FAM_DEFLATE, bytes);
+    if (wide)
+        hipLaunchKernelGGL((plsk::deflate_kernel<T, FV, DEFL_KC>), dim3((unsigned)G, nkg),
+                           dim3(plsk::WG), 0, c->stream, src, lds, dst, ldd, N, K, t, p);
+    else
+        hipLaunchKernelGGL((plsk::deflate_kernel<T, 1, DEFL_KC>), dim3((unsigned)G, nkg),
+                           dim3(plsk::WG), 0, c->stream, src, lds, dst, ldd, N, K, t, p);
+    LAUNCH_CHECK(c);
+    return PLS_HIP_OK;
+}
+
+int launch_reduce(pls_hip_context *c, const double *part, int nb, int L, const double *sspart,
+                  int nss, double *red) {
+    Scope s(c, PLS_HIP_FAM_SMALL, ((i64)nb * L + nss + L) * 8);
+    const int nblk = (L + 63) / 64 + (nss > 0 ? 1 : 0);
+    hipLaunchKernelGGL(plsk::reduce_partials_kernel, dim3(nblk), dim3(plsk::WG), 0, c->stream, part,
+                       nb, L, sspart, nss, red);
+    LAUNCH_CHECK(c);
+    return PLS_HIP_OK;
+}
+
+int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, double *P,
+                  double *Q, double *R, double *v, int K, int M, int A, int a) {
+    Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * M * 3 + (i64)K * (2 * (a + 2)) + K) * 8);
+    hipLaunchKernelGGL(plsk::component_update_kernel, dim3(1), dim3(plsk::UPD_THREADS),
+                       (size_t)A * sizeof(double), c->stream, red, XY, W, P, Q, R, v, K, M, A, a,
+                       (int)(c->opt_algo == PLS_HIP_ALGO_NIPALS), (int)c->opt_power_iters);
+    LAUNCH_CHECK(c);
+    return PLS_HIP_OK;
+}
+
+int do_allreduce(pls_hip_context *c, double *buf, i64 count) {
+    if (!c->reducer || c->nranks <= 1) return PLS_HIP_OK;
+    const int rc = c->reducer(c->reducer_user, buf, count, (void *)c->stream);
+    if (rc != 0) return fail(c, PLS_HIP_ERR_REDUCER, "all-reduce callback returned " + std::to_string(rc));
+    return PLS_HIP_OK;
+}
+
+// ---- the fit on device pointers -----------------------------------------------------------
+template <typename T>
+int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64 N, int K, int M,
+               int A, double *W, double *P, double *Q, double *R, T *Tm, i64 ldt, double *B) {
+    const bool nipals = (c->opt_algo == PLS_HIP_ALGO_NIPALS);
+    const i64 L0 = (i64)K * M;
+    const i64 redn = std::max<i64>(L0, K + 1);
+    const i64 prow = max_partial_rows(c, N, K);
+    CHK(ensure(c, c->part, (size_t)prow * (size_t)std::max<i64>(L0, K) * 8));
+    const i64 ssmax = std::max<i64>((N + plsk::WG - 1) / plsk::WG, 1);
+    CHK(ensure(c, c->sspart, (size_t)ssmax * 8));
+    CHK(ensure(c, c->xy, (size_t)L0 * 8));
+    CHK(ensure(c, c->v, (size_t)K * 8));
+    double *red;
+    if (c->user_red) {
+        if (c->user_red_count < redn) return fail(c, PLS_HIP_ERR_INVALID, "reduce buffer too small");
+        red = c->user_red;
+    } else {
+        CHK(ensure(c, c->red, (size_t)redn * 8));
+        red = (double *)c->red.p;
+    }
+    if (nipals && A > 1 && N > 0) CHK(ensure(c, c->work, (size_t)N * K * sizeof(T)));
+    double *part = (double *)c->part.p, *sspart = (double *)c->sspart.p;
+    double *XY = (double *)c->xy.p, *v = (double *)c->v.p;
+    T *work = (T *)c->work.p;
+
+    // prologue: XY = X^T Y (src/pls.cpp:396), summed over ranks
+    if (N > 0) {
+        int nb = 0;
+        CHK(launch_xty<T>(c, X, ldx, Y, ldy, N, K, M, part, &nb));
+        CHK(launch_reduce(c, part, nb, (int)L0, nullptr, 0, red));
+    } else {
+        HIPCHK(c, hipMemsetAsync(red, 0, (size_t)L0 * 8, c->stream));
+    }
+    CHK(do_allreduce(c, red, L0));
+    CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, -1));
+
+    const T *Xc = X;
+    i64 ldc = ldx;
+    for (int a = 0; a < A; ++a) {
+        if (N > 0) {
+            bool done = false;
+            if (c->opt_fuse) {
+                // tile-resident pass: [deflate with (t_{a-1}, p_{a-1}) +] t_a = X v, X^T t_a partials
+                int nb = 0, nss = 0;
+                const T *tprev = (nipals && a > 0) ? Tm + (i64)(a - 1) * ldt : nullptr;
+                const double *pprev = (nipals && a > 0) ? P + (i64)(a - 1) * K : nullptr;
+                int rc;
+                {
+                    const i64 bytes = (tprev ? 2 : 1) * (i64)N * K * sizeof(T) +
+                                      (tprev ? 2 : 1) * (i64)N * sizeof(T) + (tprev ? 3 : 2) * (i64)K * 8;
+                    Scope s(c, PLS_HIP_FAM_FUSED, bytes);
+                    rc = plsk::launch_fused_pass<T>(c->stream, c->num_cu, Xc, ldc, tprev ? work : nullptr,
+                                                    N, N, K, v, tprev, pprev, Tm + (i64)a * ldt, part,
+                                                    (int)prow, sspart, &nb, &nss);
+                    if (rc != 0) s.on = false;  // nothing was launched: drop the event pair
+                }
+                if (rc == 0) {
+                    LAUNCH_CHECK(c);
+                    done = true;
+                    if (tprev) { Xc = work; ldc = N; }
+                    CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
+                } else if (rc < 0) {
+                    return fail(c, PLS_HIP_ERR_DEVICE, "fused pass launch failed");
+                }
+            }
+            if (!done) {
+                if (nipals && a > 0) {  // X_a = X_{a-1} - t_{a-1} p_{a-1}^T (first one out of place)
+                    CHK(launch_deflate<T>(c, Xc, ldc, work, N, N, K, Tm + (i64)(a - 1) * ldt,
+                                          P + (i64)(a - 1) * K));
+                    Xc = work;
+                    ldc = N;
+                }
+                int nss = 0, nb = 0;
+                CHK(launch_xb<T>(c, Xc, ldc, N, K, v, K, 1, Tm + (i64)a * ldt, ldt, sspart, &nss));  // :419-420
+                CHK(launch_xty<T>(c, Xc, ldc, Tm + (i64)a * ldt, ldt, N, K, 1, part, &nb));           // :421
+                CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
+            }
+        } else {
+            HIPCHK(c, hipMemsetAsync(red, 0, (size_t)(K + 1) * 8, c->stream));
+        }
+        CHK(do_allreduce(c, red, K + 1));
+        CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a));  // :427-433 and :403-416 of a+1
+    }
+    if (B) {
+        Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * A + (i64)M * A + (i64)K * M) * 8);
+        const int nblk = (int)((L0 + plsk::WG - 1) / plsk::WG);
+        hipLaunchKernelGGL(plsk::coefficients_kernel, dim3(nblk), dim3(plsk::WG), 0, c->stream, R, Q,
+                           K, M, A, B);
+        LAUNCH_CHECK(c);
+    }
+    return PLS_HIP_OK;
+}
+
+int check_handle(pls_hip_handle h) { return h ? PLS_HIP_OK : PLS_HIP_ERR_INVALID; }
+
+int set_device(pls_hip_context *c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    return PLS_HIP_OK;
+}
+
+void begin_fit_timing(pls_hip_context *c) {
+    c->launches.clear();
+    c->ev_used = 0;
+    c->fit_timed = false;
+    if (!c->opt_profile) return;
+    if (!c->fit0) (void)hipEventCreate(&c->fit0);
+    if (!c->fit1) (void)hipEventCreate(&c->fit1);
+    if (c->fit0 && c->fit1) {
+        (void)hipEventRecord(c->fit0, c->stream);
+        c->fit_timed = true;
+    }
+}
+void end_fit_timing(pls_hip_context *c) {
+    if (c->fit_timed) (void)hipEventRecord(c->fit1, c->stream);
+}
+
+// host <-> device staging of a column-major matrix with leading dimension
+int h2d(pls_hip_context *c, void *dst, i64 ldd, const void *src, i64 lds, i64 rows, i64 cols, size_t es) {
+    if (rows == 0 || cols == 0) return PLS_HIP_OK;
+    HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)ldd * es, src, (size_t)lds * es, (size_t)rows * es,
+                               (size_t)cols, hipMemcpyHostToDevice, c->stream));
+    return PLS_HIP_OK;
+}
+int d2h(pls_hip_context *c, void *dst, i64 ldd, const void *src, i64 lds, i64 rows, i64 cols, size_t es) {
+    if (rows == 0 || cols == 0) return PLS_HIP_OK;
+    HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)ldd * es, src, (size_t)lds * es, (size_t)rows * es,
+                               (size_t)cols, hipMemcpyDeviceToHost, c->stream));
+    return PLS_HIP_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+int pls_hip_abi_version(void) { return PLS_HIP_ABI_VERSION; }
+
+int pls_hip_create(pls_hip_handle *out, int device, void *stream) {
+    if (!out) return PLS_HIP_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        (void)hipGetLastError();
+        return PLS_HIP_ERR_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PLS_HIP_ERR_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PLS_HIP_ERR_DEVICE;  // no other target
+    pls_hip_context *c = new (std::nothrow) pls_hip_context();
+    if (!c) return PLS_HIP_ERR_ALLOC;
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return PLS_HIP_ERR_DEVICE; }
+    c->stream = (hipStream_t)stream;  // NULL = the device's default (null) stream
+    *out = c;
+    return PLS_HIP_OK;
+}
+
+int pls_hip_destroy(pls_hip_handle h) {
+    if (!h) return PLS_HIP_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf *bufs[] = {&h->part, &h->sspart, &h->red, &h->xy, &h->v, &h->tab, &h->work, &h->hX, &h->hY,
+                      &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->fit0) (void)hipEventDestroy(h->fit0);
+    if (h->fit1) (void)hipEventDestroy(h->fit1);
+    delete h;
+    return PLS_HIP_OK;
+}
+
+int pls_hip_set_stream(pls_hip_handle h, void *stream) {
+    CHK(check_handle(h));
+    CHK(set_device(h));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = (hipStream_t)stream;
+    return PLS_HIP_OK;
+}
+
+int pls_hip_set_option(pls_hip_handle h, int option, int64_t value) {
+    CHK(check_handle(h));
+    switch (option) {
+        case PLS_HIP_OPT_ALGO:
+            if (value != PLS_HIP_ALGO_KERNEL && value != PLS_HIP_ALGO_NIPALS)
+                return fail(h, PLS_HIP_ERR_INVALID, "unknown algo");
+            h->opt_algo = value;
+            return PLS_HIP_OK;
+        case PLS_HIP_OPT_FUSE: h->opt_fuse = value ? 1 : 0; return PLS_HIP_OK;
+        case PLS_HIP_OPT_PROFILE: h->opt_profile = value ? 1 : 0; return PLS_HIP_OK;
+        case PLS_HIP_OPT_POWER_ITERS:
+            if (value < 1 || value > 4096) return fail(h, PLS_HIP_ERR_INVALID, "power iters out of range");
+            h->opt_power_iters = value;
+            return PLS_HIP_OK;
+        default: return fail(h, PLS_HIP_ERR_INVALID, "unknown option");
+    }
+}
+
+int pls_hip_get_option(pls_hip_handle h, int option, int64_t *value) {
+    CHK(check_handle(h));
+    if (!value) return PLS_HIP_ERR_INVALID;
+    switch (option) {
+        case PLS_HIP_OPT_ALGO: *value = h->opt_algo; return PLS_HIP_OK;
+        case PLS_HIP_OPT_FUSE: *value = h->opt_fuse; return PLS_HIP_OK;
+        case PLS_HIP_OPT_PROFILE: *value = h->opt_profile; return PLS_HIP_OK;
+        case PLS_HIP_OPT_POWER_ITERS: *value = h->opt_power_iters; return PLS_HIP_OK;
+        default: return fail(h, PLS_HIP_ERR_INVALID, "unknown option");
+    }
+}
+
+int pls_hip_set_reducer(pls_hip_handle h, pls_hip_allreduce_fn fn, void *user, int rank, int nranks) {
+    CHK(check_handle(h));
+    if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn))
+        return fail(h, PLS_HIP_ERR_INVALID, "bad reducer arguments");
+    h->reducer = fn;
+    h->reducer_user = user;
+    h->rank = rank;
+    h->nranks = nranks;
+    return PLS_HIP_OK;
+}
+
+int pls_hip_set_reduce_buffer(pls_hip_handle h, void *buf, int64_t count) {
+    CHK(check_handle(h));
+    if ((buf && count <= 0) || (!buf && count != 0)) return fail(h, PLS_HIP_ERR_INVALID, "bad reduce buffer");
+    h->user_red = (double *)buf;
+    h->user_red_count = count;
+    return PLS_HIP_OK;
+}
+
+int pls_hip_synchronize(pls_hip_handle h) {
+    CHK(check_handle(h));
+    CHK(set_device(h));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PLS_HIP_OK;
+}
+
+const char *pls_hip_last_error(pls_hip_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int pls_hip_get_timing(pls_hip_handle h, pls_hip_timing *out) {
+    CHK(check_handle(h));
+    if (!out) return PLS_HIP_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    CHK(set_device(h));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->fit_timed) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->fit0, h->fit1));
+        out->fit_ms = ms;
+    }
+    for (const Launch &l : h->launches) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, l.e0, l.e1));
+        out->fam_ms[l.fam] += ms;
+        out->fam_launches[l.fam] += 1;
+        out->fam_bytes[l.fam] += l.bytes;
+    }
+    return PLS_HIP_OK;
+}
+
+int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy, int64_t N,
+                int64_t K, int64_t M, int64_t A, int method, int dtype, int mem, double *W, double *P,
+                double *Q, double *R, void *T, int64_t ldt, double *B) {
+    CHK(check_handle(h));
+    if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
+    if (mem != PLS_HIP_MEM_HOST && mem != PLS_HIP_MEM_DEVICE) return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
+    if (method != PLS_HIP_KERNEL_TYPE1 && method != PLS_HIP_KERNEL_TYPE2)
+        return fail(h, PLS_HIP_ERR_INVALID, "bad method");
+    if (method == PLS_HIP_KERNEL_TYPE2)
+        return fail(h, PLS_HIP_ERR_UNSUPPORTED, "KERNEL_TYPE2 (X^T X form) is not implemented on the device yet");
+    const bool sharded = h->nranks > 1;
+    if (N < 0 || (N == 0 && !sharded) || K < 1 || M < 1 || A < 1 || A > K)
+        return fail(h, PLS_HIP_ERR_INVALID, "bad shape: need N>=1, K>=1, M>=1, 1<=A<=K");
+    if (K > (1 << 30) || M > (1 << 20) || (M > 1 && M > plsk::MMAX))
+        return fail(h, PLS_HIP_ERR_UNSUPPORTED, "M > 32 responses (or K > 2^30) not supported on the device");
+    if (N > 0 && (!X || !Y || !T)) return fail(h, PLS_HIP_ERR_INVALID, "null X/Y/T");
+    if (!W || !P || !Q || !R) return fail(h, PLS_HIP_ERR_INVALID, "null W/P/Q/R");
+    if (ldx < std::max<i64>(N, 1) || ldy < std::max<i64>(N, 1) || ldt < std::max<i64>(N, 1))
+        return fail(h, PLS_HIP_ERR_INVALID, "leading dimension smaller than N");
+    CHK(set_device(h));
+    const size_t es = esize(dtype);
+    const int Ki = (int)K, Mi = (int)M, Ai = (int)A;
+
+    const void *dX = X, *dY = Y;
+    void *dT = T;
+    double *dW = W, *dP = P, *dQ = Q, *dR = R, *dB = B;
+    i64 dldx = ldx, dldy = ldy, dldt = ldt;
+    if (mem == PLS_HIP_MEM_HOST) {
+        const i64 ldn = std::max<i64>(N, 1) + (std::max<i64>(N, 1) & 1);  // even ld keeps 16-B columns
+        CHK(ensure(h, h->hX, (size_t)ldn * K * es));
+        CHK(ensure(h, h->hY, (size_t)ldn * M * es));
+        CHK(ensure(h, h->hT, (size_t)ldn * A * es));
+        CHK(ensure(h, h->hW, (size_t)K * A * 8));
+        CHK(ensure(h, h->hP, (size_t)K * A * 8));
+        CHK(ensure(h, h->hR, (size_t)K * A * 8));
+        CHK(ensure(h, h->hQ, (size_t)M * A * 8));
+        CHK(ensure(h, h->hB, (size_t)K * M * 8));
+        CHK(h2d(h, h->hX.p, ldn, X, ldx, N, K, es));
+        CHK(h2d(h, h->hY.p, ldn, Y, ldy, N, M, es));
+        dX = h->hX.p; dY = h->hY.p; dT = h->hT.p;
+        dW = (double *)h->hW.p; dP = (double *)h->hP.p; dQ = (double *)h->hQ.p; dR = (double *)h->hR.p;
+        dB = B ? (double *)h->hB.p : nullptr;
+        dldx = dldy = dldt = ldn;
+    }
+    begin_fit_timing(h);
+    int rc;
+    if (dtype == PLS_HIP_F64)
+        rc = fit_device<double>(h, (const double *)dX, dldx, (const double *)dY, dldy, N, Ki, Mi, Ai, dW,
+                                dP, dQ, dR, (double *)dT, dldt, dB);
+    else
+        rc = fit_device<float>(h, (const float *)dX, dldx, (const float *)dY, dldy, N, Ki, Mi, Ai, dW, dP,
+                               dQ, dR, (float *)dT, dldt, dB);
+    end_fit_timing(h);
+    if (rc != PLS_HIP_OK) return rc;
+    if (mem == PLS_HIP_MEM_HOST) {
+        CHK(d2h(h, W, K, dW, K, K, A, 8));
+        CHK(d2h(h, P, K, dP, K, K, A, 8));
+        CHK(d2h(h, R, K, dR, K, K, A, 8));
+        CHK(d2h(h, Q, M, dQ, M, M, A, 8));
+        if (B) CHK(d2h(h, B, K, dB, K, K, M, 8));
+        CHK(d2h(h, T, ldt, dT, dldt, N, A, es));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return PLS_HIP_OK;
+}
+
+int pls_hip_coefficients(pls_hip_handle h, const double *R, const double *Q, int64_t K, int64_t M,
+                         int64_t A, int64_t cc, int mem, double *B) {
+    CHK(check_handle(h));
+    if (!R || !Q || !B || K < 1 || M < 1 || A < 1 || cc < 0 || cc > A || K > (1 << 30))
+        return fail(h, PLS_HIP_ERR_INVALID, "bad coefficients arguments");  // comp <= A: src/pls.cpp:445
+    CHK(set_device(h));
+    const double *dR = R, *dQ = Q;
+    double *dB = B;
+    if (mem == PLS_HIP_MEM_HOST) {
+        CHK(ensure(h, h->hR, (size_t)K * A * 8));
+        CHK(ensure(h, h->hQ, (size_t)M * A * 8));
+        CHK(ensure(h, h->hB, (size_t)K * M * 8));
+        CHK(h2d(h, h->hR.p, K, R, K, K, A, 8));
+        CHK(h2d(h, h->hQ.p, M, Q, M, M, A, 8));
+        dR = (double *)h->hR.p; dQ = (double *)h->hQ.p; dB = (double *)h->hB.p;
+    } else if (mem != PLS_HIP_MEM_DEVICE) {
+        return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
+    }
+    const int nblk = (int)((K * M + plsk::WG - 1) / plsk::WG);
+    hipLaunchKernelGGL(plsk::coefficients_kernel, dim3(nblk), dim3(plsk::WG), 0, h->stream, dR, dQ,
+                       (int)K, (int)M, (int)cc, dB);
+    LAUNCH_CHECK(h);
+    if (mem == PLS_HIP_MEM_HOST) {
+        CHK(d2h(h, B, K, dB, K, K, M, 8));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return PLS_HIP_OK;
+}
+
+int pls_hip_xb(pls_hip_handle h, const void *X, int64_t ldx, int64_t N, int64_t K, const double *Bm,
+               int64_t ldb, int64_t C, int dtype, int mem, void *out, int64_t ldo) {
+    CHK(check_handle(h));
+    if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
+    if (N < 0 || K < 1 || C < 1 || K > (1 << 30) || C > (1 << 20) || ldb < K ||
+        ldx < std::max<i64>(N, 1) || ldo < std::max<i64>(N, 1) || !Bm || (N > 0 && (!X || !out)))
+        return fail(h, PLS_HIP_ERR_INVALID, "bad xb arguments");
+    if (N == 0) return PLS_HIP_OK;
+    CHK(set_device(h));
+    const size_t es = esize(dtype);
+    const void *dX = X;
+    const double *dBm = Bm;
+    void *dO = out;
+    i64 dldx = ldx, dldo = ldo, dldb = ldb;
+    if (mem == PLS_HIP_MEM_HOST) {
+        const i64 ldn = N + (N & 1);
+        CHK(ensure(h, h->hIn, (size_t)ldn * K * es));
+        CHK(ensure(h, h->hOut, (size_t)ldn * C * es));
+        CHK(ensure(h, h->hB, (size_t)K * C * 8));
+        CHK(h2d(h, h->hIn.p, ldn, X, ldx, N, K, es));
+        CHK(h2d(h, h->hB.p, K, Bm, ldb, K, C, 8));
+        dX = h->hIn.p; dO = h->hOut.p; dBm = (const double *)h->hB.p;
+        dldx = dldo = ldn; dldb = K;
+    } else if (mem != PLS_HIP_MEM_DEVICE) {
+        return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
+    }
+    int nss = 0;
+    if (dtype == PLS_HIP_F64)
+        CHK(launch_xb<double>(h, (const double *)dX, dldx, N, (int)K, dBm, dldb, (int)C, (double *)dO, dldo, nullptr, &nss));
+    else
+        CHK(launch_xb<float>(h, (const float *)dX, dldx, N, (int)K, dBm, dldb, (int)C, (float *)dO, dldo, nullptr, &nss));
+    if (mem == PLS_HIP_MEM_HOST) {
+        CHK(d2h(h, out, ldo, dO, dldo, N, C, es));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return PLS_HIP_OK;
+}
+
+int pls_hip_xty(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy, int64_t N,
+                int64_t K, int64_t M, int dtype, double *XY) {
+    CHK(check_handle(h));
+    if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
+    if (N < 1 || K < 1 || M < 1 || K > (1 << 30) || M > (1 << 20) || !X || !Y || !XY || ldx < N || ldy < N)
+        return fail(h, PLS_HIP_ERR_INVALID, "bad xty arguments");
+    CHK(set_device(h));
+    CHK(ensure(h, h->part, (size_t)max_partial_rows(h, N, (int)K) * (size_t)(K * M) * 8));
+    int nb = 0;
+    if (dtype == PLS_HIP_F64)
+        CHK(launch_xty<double>(h, (const double *)X, ldx, (const double *)Y, ldy, N, (int)K, (int)M, (double *)h->part.p, &nb));
+    else
+        CHK(launch_xty<float>(h, (const float *)X, ldx, (const float *)Y, ldy, N, (int)K, (int)M, (double *)h->part.p, &nb));
+    return launch_reduce(h, (const double *)h->part.p, nb, (int)(K * M), nullptr, 0, XY);
+}
+
+int pls_hip_deflate(pls_hip_handle h, const void *src, int64_t lds, void *dst, int64_t ldd, int64_t N,
+                    int64_t K, const void *t, const double *p, int dtype) {
+    CHK(check_handle(h));
+    if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
+    if (N < 1 || K < 1 || K > (1 << 30) || !src || !dst || !t || !p || lds < N || ldd < N)
+        return fail(h, PLS_HIP_ERR_INVALID, "bad deflate arguments");
+    CHK(set_device(h));
+    if (dtype == PLS_HIP_F64)
+        return launch_deflate<double>(h, (const double *)src, lds, (double *)dst, ldd, N, (int)K, (const double *)t, p);
+    return launch_deflate<float>(h, (const float *)src, lds, (float *)dst, ldd, N, (int)K, (const float *)t, p);
+}
+
+int pls_hip_synth_x(pls_hip_handle h, void *X, int64_t ldx, int64_t row0, int64_t nrows, int64_t K,
+                    uint64_t seed, int dtype) {
+    CHK(check_handle(h));
+    if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
+    if (nrows < 0 || row0 < 0 || K < 1 || K > (1 << 28) || (nrows > 0 && !X) || ldx < std::max<i64>(nrows, 1))
+        return fail(h, PLS_HIP_ERR_INVALID, "bad synth_x arguments");
+    if (nrows == 0) return PLS_HIP_OK;
+    CHK(set_device(h));
+    CHK(ensure(h, h->tab, (size_t)K * plsk::SYN_F * 8));
+    const uint64_t sE = plsk::mix64(seed), sZ = plsk::mix64(seed + 1), sL = plsk::mix64(seed + 2);
+    const int ntab = (int)((K * plsk::SYN_F + plsk::WG - 1) / plsk::WG);
+    hipLaunchKernelGGL(plsk::synth_table_kernel, dim3(ntab), dim3(plsk::WG), 0, h->stream,
+                       (double *)h->tab.p, (int)K, sL, 0);
+    LAUNCH_CHECK(h);
+    constexpr int KC = 64;
+    const dim3 grid((unsigned)((nrows + plsk::WG - 1) / plsk::WG), (unsigned)((K + KC - 1) / KC));
+    if (dtype == PLS_HIP_F64)
+        hipLaunchKernelGGL((plsk::synth_x_kernel<double, KC>), grid, dim3(plsk::WG), 0, h->stream,
+                           (double *)X, ldx, row0, nrows, (int)K, sE, sZ, (const double *)h->tab.p);
+    else
+        hipLaunchKernelGGL((plsk::synth_x_kernel<float, KC>), grid, dim3(plsk::WG), 0, h->stream,
+                           (float *)X, ldx, row0, nrows, (int)K, sE, sZ, (const double *)h->tab.p);
+    LAUNCH_CHECK(h);
+    return PLS_HIP_OK;
+}
+
+int pls_hip_synth_y(pls_hip_handle h, void *Y, int64_t ldy, int64_t row0, int64_t nrows, int64_t M,
+                    uint64_t seed, int dtype) {
+    CHK(check_handle(h));
+    if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
+    if (nrows < 0 || row0 < 0 || M < 1 || M > (1 << 20) || (nrows > 0 && !Y) || ldy < std::max<i64>(nrows, 1))
+        return fail(h, PLS_HIP_ERR_INVALID, "bad synth_y arguments");
+    if (nrows == 0) return PLS_HIP_OK;
+    CHK(set_device(h));
+    // the Y table shares the workspace with the X table: generate Y before or after X, both
+    // are stream-ordered
+    CHK(ensure(h, h->tab, (size_t)std::max<i64>(M, 1) * plsk::SYN_F * 8));
+    const uint64_t sZ = plsk::mix64(seed + 1), sC = plsk::mix64(seed + 3), sN = plsk::mix64(seed + 4);
+    const int ntab = (int)((M * plsk::SYN_F + plsk::WG - 1) / plsk::WG);
+    hipLaunchKernelGGL(plsk::synth_table_kernel, dim3(ntab), dim3(plsk::WG), 0, h->stream,
+                       (double *)h->tab.p, (int)M, sC, 1);
+    LAUNCH_CHECK(h);
+    const dim3 grid((unsigned)((nrows + plsk::WG - 1) / plsk::WG));
+    if (dtype == PLS_HIP_F64)
+        hipLaunchKernelGGL((plsk::synth_y_kernel<double>), grid, dim3(plsk::WG), 0, h->stream,
+                           (double *)Y, ldy, row0, nrows, (int)M, sZ, sN, (const double *)h->tab.p);
+    else
+        hipLaunchKernelGGL((plsk::synth_y_kernel<float>), grid, dim3(plsk::WG), 0, h->stream, (float *)Y,
+                           ldy, row0, nrows, (int)M, sZ, sN, (const double *)h->tab.p);
+    LAUNCH_CHECK(h);
+    return PLS_HIP_OK;
+}
+
+}  // extern "C"

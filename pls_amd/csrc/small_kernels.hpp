@@ -1,0 +1,175 @@
+// The K-sized bookkeeping of one component, kept on the device so the A-loop never returns
+// to the host (src/pls.cpp:403-416 and :427-433), plus coefficients (:444-447).
+// One workgroup of 1024 threads; every rank of a sharded fit runs it on bit-identical
+// inputs (the all-reduced partials) and therefore derives bit-identical w, r, p, q.
+#pragma once
+#include "common.hpp"
+
+namespace plsk {
+
+constexpr int UPD_THREADS = 1024;
+constexpr int UPD_WAVES = UPD_THREADS / WAVE;
+constexpr int MMAX = 32;  // responses supported by the on-device direction solve (m > 1)
+
+// Dominant eigenvector of G = S^T S (M x M, symmetric PSD) by power iteration carried out as
+// repeated squaring: B_0 = G/tr G, B_{j+1} = B_j^2 / tr(B_j^2) -> v1 v1^T with the error
+// contracting as (lambda2/lambda1)^(2^j); then two plain power steps q <- G q / |G q| on the
+// original G polish the vector to working precision.  This replaces the reference's general
+// EigenSolver + find_dominant_ev (src/pls.cpp:406-408, :113-141).  Sign (left open by the
+// reference): largest-|.| entry positive, lowest index on ties.
+// Called by all threads of the workgroup; G, Bm, Cm: M*M doubles of LDS; qv: M doubles.
+__device__ inline void dominant_eigvec_lds(double *G, double *Bm, double *Cm, double *qv, int M,
+                                           int iters) {
+    const int tid = threadIdx.x;
+    const int a = tid % MMAX, b = tid / MMAX;  // (row, col) when a < M && b < M
+    const bool act = (a < M) && (b < M);
+    double tr = 0.0;
+    for (int c = 0; c < M; ++c) tr += G[c + c * M];
+    if (act) Bm[a + b * M] = G[a + b * M] / tr;
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        if (act) {
+            double s = 0.0;
+            for (int c = 0; c < M; ++c) s = fma(Bm[a + c * M], Bm[c + b * M], s);
+            Cm[a + b * M] = s;
+        }
+        __syncthreads();
+        double t2 = 0.0;
+        for (int c = 0; c < M; ++c) t2 += Cm[c + c * M];
+        if (act) Bm[a + b * M] = Cm[a + b * M] / t2;
+        __syncthreads();
+    }
+    // column with the largest diagonal entry spans the dominant direction
+    int best = 0;
+    double bd = Bm[0];
+    for (int c = 1; c < M; ++c)
+        if (Bm[c + c * M] > bd) { bd = Bm[c + c * M]; best = c; }
+    if (tid < M) qv[tid] = Bm[tid + best * M];
+    __syncthreads();
+    for (int pol = 0; pol < 2; ++pol) {
+        double s = 0.0;
+        if (tid < M)
+            for (int c = 0; c < M; ++c) s = fma(G[tid + c * M], qv[c], s);
+        __syncthreads();
+        if (tid < M) qv[tid] = s;
+        __syncthreads();
+        double n2 = 0.0;
+        for (int c = 0; c < M; ++c) n2 = fma(qv[c], qv[c], n2);
+        const double inv = 1.0 / sqrt(n2);
+        __syncthreads();
+        if (tid < M) qv[tid] = s * inv;
+        __syncthreads();
+    }
+    int big = 0;
+    for (int c = 1; c < M; ++c)
+        if (fabs(qv[c]) > fabs(qv[big])) big = c;
+    const double sgn = (qv[big] < 0.0) ? -1.0 : 1.0;
+    __syncthreads();
+    if (tid < M) qv[tid] *= sgn;
+    __syncthreads();
+}
+
+// a = index of the component whose pass just finished (-1: prologue, red holds X^T Y).
+//   a >= 0 : red = [X^T t (K), t^T t];  p = red/tt (:427) -> P[:,a];  q = XY^T r_a / tt (:428)
+//            -> Q[:,a];  XY -= (p q^T) tt (:429).
+//   then, when a+1 < A: w from XY (:403-411) -> W[:,a+1];  r (:412-416) -> R[:,a+1];
+//   vnext = r (KERNEL algo: next pass is X r) or w (NIPALS algo: next pass is X_a w).
+// Dynamic LDS: A doubles (the p_j^T w inner products).
+__global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
+    const double *__restrict__ red, double *__restrict__ XY, double *__restrict__ W,
+    double *__restrict__ P, double *__restrict__ Q, double *__restrict__ R,
+    double *__restrict__ vnext, int K, int M, int A, int a, int nipals, int power_iters) {
+    extern __shared__ double cs[];  // [A]
+    __shared__ double sred[UPD_WAVES];
+    __shared__ double qs[MMAX];
+    __shared__ double Gs[MMAX * MMAX], Bs[MMAX * MMAX], Cs[MMAX * MMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    if (a < 0) {
+        for (int j = tid; j < K * M; j += UPD_THREADS) XY[j] = red[j];
+    } else {
+        const double tt = red[K];
+        const double *ra = R + (i64)a * K;
+        for (int m = wv; m < M; m += UPD_WAVES) {  // q_m = (r^T XY[:,m]) / tt
+            double s = 0.0;
+            for (int k = lane; k < K; k += WAVE) s = fma(ra[k], XY[k + (i64)m * K], s);
+            s = wave_sum(s);
+            if (lane == 0) {
+                qs[m] = s / tt;
+                Q[m + (i64)a * M] = s / tt;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < K; k += UPD_THREADS) {
+            const double p = red[k] / tt;
+            P[k + (i64)a * K] = p;
+            for (int m = 0; m < M; ++m) XY[k + (i64)m * K] -= (p * qs[m]) * tt;
+        }
+    }
+    const int n = a + 1;
+    if (n >= A) return;
+    __syncthreads();  // XY complete (same workgroup: its own global stores are visible)
+
+    double *wn = W + (i64)n * K;
+    if (M == 1) {
+        double ss = 0.0;
+        for (int k = tid; k < K; k += UPD_THREADS) ss = fma(XY[k], XY[k], ss);
+        ss = block_sum<UPD_WAVES>(ss, sred);
+        const double nrm = sqrt(ss);
+        for (int k = tid; k < K; k += UPD_THREADS) wn[k] = XY[k] / nrm;
+    } else {
+        const int npairs = M * (M + 1) / 2;
+        for (int pr = wv; pr < npairs; pr += UPD_WAVES) {  // G = XY^T XY, one wave per (i<=j)
+            int i = 0, rem = pr;
+            while (rem >= M - i) { rem -= M - i; ++i; }
+            const int j = i + rem;
+            double s = 0.0;
+            for (int k = lane; k < K; k += WAVE) s = fma(XY[k + (i64)i * K], XY[k + (i64)j * K], s);
+            s = wave_sum(s);
+            if (lane == 0) { Gs[i + j * M] = s; Gs[j + i * M] = s; }
+        }
+        __syncthreads();
+        dominant_eigvec_lds(Gs, Bs, Cs, qs, M, power_iters);
+        double ss = 0.0;
+        for (int k = tid; k < K; k += UPD_THREADS) {  // w = XY q (:408)
+            double s = 0.0;
+            for (int m = 0; m < M; ++m) s = fma(XY[k + (i64)m * K], qs[m], s);
+            wn[k] = s;
+            ss = fma(s, s, ss);
+        }
+        ss = block_sum<UPD_WAVES>(ss, sred);
+        const double nrm = sqrt(ss);
+        for (int k = tid; k < K; k += UPD_THREADS) wn[k] = wn[k] / nrm;  // own element: no hazard
+    }
+    __syncthreads();
+    for (int j = wv; j < n; j += UPD_WAVES) {  // c_j = P[:,j]^T w  (against the ORIGINAL w, :415)
+        const double *pj = P + (i64)j * K;
+        double s = 0.0;
+        for (int k = lane; k < K; k += WAVE) s = fma(pj[k], wn[k], s);
+        s = wave_sum(s);
+        if (lane == 0) cs[j] = s;
+    }
+    __syncthreads();
+    double *rn = R + (i64)n * K;
+    for (int k = tid; k < K; k += UPD_THREADS) {
+        const double w = wn[k];
+        double r = w;
+        for (int j = 0; j < n; ++j) r -= cs[j] * R[k + (i64)j * K];
+        rn[k] = r;
+        vnext[k] = nipals ? w : r;
+    }
+}
+
+// B[k + m*K] = sum_{j<c} R[k + j*K] * Q[m + j*M]     Model::coefficients, src/pls.cpp:444-447
+__global__ __launch_bounds__(WG) void coefficients_kernel(const double *__restrict__ R,
+                                                          const double *__restrict__ Q, int K,
+                                                          int M, int c, double *__restrict__ B) {
+    const i64 idx = (i64)blockIdx.x * WG + threadIdx.x;
+    if (idx >= (i64)K * M) return;
+    const int k = (int)(idx % K), m = (int)(idx / K);
+    double s = 0.0;
+    for (int j = 0; j < c; ++j) s = fma(R[k + (i64)j * K], Q[m + (i64)j * M], s);
+    B[idx] = s;
+}
+
+}  // namespace plsk

@@ -1,0 +1,80 @@
+"""Row (sample) sharding of a fit across the GPUs of one node: SURVEY.md section 8(e).
+
+One process per GPU.  Rank r owns a contiguous block of rows of X and Y; every O(N*K) product
+is a sum over rows, so the only exchange is an all-reduce of the K x M partial of X^T Y (once)
+and of the packed (K+1)-vector [X^T t, t^T t] (once per component).  Those messages are a few KB:
+latency-bound, so they go through torch.distributed's all_reduce (RCCL over xGMI with the "nccl"
+backend) on a buffer this module allocates and hands to the library, stream-ordered with the
+library's kernels -- no host synchronisation inside the A-loop on the nccl path.
+"""
+from __future__ import annotations
+
+import ctypes
+
+from . import _lib as L
+
+
+def row_partition(n_rows: int, world_size: int, rank: int) -> tuple[int, int]:
+    """(row0, nrows) of rank's contiguous block; the first n_rows % world_size ranks get one
+    extra row.  Blocks are disjoint, ordered by rank and cover [0, n_rows)."""
+    if world_size < 1 or not (0 <= rank < world_size) or n_rows < 0:
+        raise ValueError("bad partition arguments")
+    base, extra = divmod(n_rows, world_size)
+    row0 = rank * base + min(rank, extra)
+    return row0, base + (1 if rank < extra else 0)
+
+
+def attach_reducer(handle, K: int, M: int, group=None):
+    """Give `handle` an all-reduce over torch.distributed's default (or the given) group.
+
+    nccl backend: dist.all_reduce on the CUDA staging tensor, enqueued behind the library's
+    kernels on the current stream.  gloo backend (CPU rehearsal of N>1, or several ranks sharing
+    one GPU in tests): the staging tensor is bounced through host memory.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    count = max(K * M, K + 1)
+    dev = torch.device("cuda", handle.device)
+    stage = torch.zeros(count, dtype=torch.float64, device=dev)
+    backend = dist.get_backend(group)
+    host = torch.zeros(count, dtype=torch.float64).pin_memory() if backend != "nccl" else None
+    base = stage.data_ptr()
+
+    def _cb(_user, buf, n, _stream):
+        try:
+            off = (int(buf) - base) // 8
+            view = stage[off:off + n]
+            if backend == "nccl":
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+            else:
+                torch.cuda.current_stream(dev).synchronize()
+                host[:n].copy_(view)
+                dist.all_reduce(host[:n], op=dist.ReduceOp.SUM, group=group)
+                view.copy_(host[:n], non_blocking=False)
+            return 0
+        except Exception:  # an exception must not unwind through the C frame
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    cb = L.ALLREDUCE_FN(_cb)
+    handle._keep += [cb, stage, host]
+    L.check(handle._lib.pls_hip_set_reduce_buffer(handle.h, ctypes.c_void_p(base), count), handle.h)
+    L.check(handle._lib.pls_hip_set_reducer(handle.h, cb, None, rank, world), handle.h)
+    return stage
+
+
+def make_host_allreduce(group=None):
+    """all-reduce of a float64 numpy view through torch.distributed (gloo): the same reduction the
+    device path performs, for CPU rehearsals of the sharded algorithm."""
+    import torch
+    import torch.distributed as dist
+
+    def _allreduce(view):
+        t = torch.from_numpy(view)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+    return _allreduce

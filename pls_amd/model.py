@@ -1,0 +1,334 @@
+"""Python host mirror of the reference's `PLS::Model` fit / predict surface.
+
+Same names, argument meaning and defaults as /root/reference/include/PLS/pls.h:184-266, over
+the C-ABI of include/pls_hip.h.  Differences, all at the type level only:
+  * matrices are torch CUDA tensors (device path, zero copy) or numpy arrays (host path,
+    copied in and out by the library) instead of Eigen matrices;
+  * results are real (the reference's Mat2Dc always has zero imaginary parts);
+  * shape errors raise PlsHipError(INVALID) where the reference only assert()s
+    (src/pls.cpp:345-347, :440, :445).
+torch is used for device memory and streams only; all arithmetic on the N-sized data is done
+by the HIP kernels behind the C-ABI.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+try:  # torch is plumbing (device memory, streams); the host path works without it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+KERNEL_TYPE1 = L.KERNEL_TYPE1
+KERNEL_TYPE2 = L.KERNEL_TYPE2
+
+
+def _is_torch(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+# ---------------------------------------------------------------------------------------------
+# column-major device matrices as torch views
+# ---------------------------------------------------------------------------------------------
+
+def colmajor_empty(rows: int, cols: int, dtype, device, ld: int | None = None):
+    """(rows, cols) view with strides (1, ld): the reference's Eigen column-major layout
+    (include/PLS/pls.h:22-23).  ld defaults to rows rounded up to a 16-byte multiple."""
+    es = torch.empty((), dtype=dtype).element_size()
+    v = 16 // es
+    if ld is None:
+        ld = max(rows, 1)
+        ld += (-ld) % v
+    buf = torch.empty((cols, ld), dtype=dtype, device=device)
+    return buf[:, :rows].t()
+
+
+def as_colmajor(x, dtype=None):
+    """Zero-copy if x already has strides (1, ld>=rows) and the dtype matches, else a copy."""
+    if dtype is None:
+        dtype = x.dtype
+    if x.dim() == 1:
+        x = x[:, None]
+    n, k = x.shape
+    ok = x.dtype == dtype and (n <= 1 or x.stride(0) == 1) and (k <= 1 or x.stride(1) >= max(n, 1))
+    if ok:
+        return x
+    out = colmajor_empty(n, k, dtype, x.device)
+    out.copy_(x)
+    return out
+
+
+def _ld(x) -> int:
+    """leading dimension of a column-major view (a single column may report any stride)"""
+    n, k = x.shape
+    return max(int(x.stride(1)) if k > 1 else 0, int(n), 1)
+
+
+def _np_f(x, dtype):
+    a = np.asarray(x)
+    if a.ndim == 1:
+        a = a[:, None]
+    return np.asfortranarray(a, dtype=dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# handle
+# ---------------------------------------------------------------------------------------------
+
+class Handle:
+    """One pls_hip context: a device, a stream, its workspace and (optionally) a reducer."""
+
+    def __init__(self, device: int | None = None, stream: int | None = None):
+        self._lib = L.lib()
+        if device is None:
+            device = torch.cuda.current_device() if (torch is not None and torch.cuda.is_available()) else 0
+        if stream is None and torch is not None and torch.cuda.is_available():
+            stream = torch.cuda.current_stream(device).cuda_stream
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        L.check(self._lib.pls_hip_create(ctypes.byref(h), self.device, ctypes.c_void_p(stream or 0)))
+        self.h = h
+        self._keep = []  # objects the C side points at (callbacks, reduce buffers)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.pls_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, opt: int, value: int):
+        L.check(self._lib.pls_hip_set_option(self.h, opt, int(value)), self.h)
+
+    def get_option(self, opt: int) -> int:
+        v = ctypes.c_int64()
+        L.check(self._lib.pls_hip_get_option(self.h, opt, ctypes.byref(v)), self.h)
+        return int(v.value)
+
+    def set_stream(self, stream: int | None):
+        L.check(self._lib.pls_hip_set_stream(self.h, ctypes.c_void_p(stream or 0)), self.h)
+
+    def synchronize(self):
+        L.check(self._lib.pls_hip_synchronize(self.h), self.h)
+
+    def timing(self) -> dict:
+        t = L.Timing()
+        L.check(self._lib.pls_hip_get_timing(self.h, ctypes.byref(t)), self.h)
+        return {"fit_ms": t.fit_ms,
+                "ms": {n: t.fam_ms[i] for i, n in enumerate(L.FAM_NAMES)},
+                "launches": {n: int(t.fam_launches[i]) for i, n in enumerate(L.FAM_NAMES)},
+                "bytes": {n: int(t.fam_bytes[i]) for i, n in enumerate(L.FAM_NAMES)}}
+
+    # ---- raw steps on device tensors (tests, bench) -----------------------------------------
+    def _dt(self, x):
+        return L.F64 if x.dtype == torch.float64 else L.F32
+
+    def fit_device(self, X, Y, A: int, method: int = KERNEL_TYPE1, want_B: bool = True):
+        """X (N,K), Y (N,M) column-major CUDA tensors of one dtype.  Enqueues the fit and
+        returns dict(W,P,Q,R,T,B) of device tensors (column-major views)."""
+        X = as_colmajor(X)
+        Y = as_colmajor(Y, X.dtype)
+        N, K = X.shape
+        M = Y.shape[1]
+        dev = X.device
+        f64 = torch.float64
+        W = colmajor_empty(K, A, f64, dev, ld=K); P = colmajor_empty(K, A, f64, dev, ld=K)
+        R = colmajor_empty(K, A, f64, dev, ld=K); Q = colmajor_empty(M, A, f64, dev, ld=M)
+        T = colmajor_empty(N, A, X.dtype, dev)
+        B = colmajor_empty(K, M, f64, dev, ld=K) if want_B else None
+        rc = self._lib.pls_hip_fit(self.h, X.data_ptr(), _ld(X), Y.data_ptr(), _ld(Y), N, K, M, A,
+                                   method, self._dt(X), L.MEM_DEVICE, W.data_ptr(), P.data_ptr(),
+                                   Q.data_ptr(), R.data_ptr(), T.data_ptr(), _ld(T),
+                                   B.data_ptr() if want_B else None)
+        L.check(rc, self.h)
+        self._last_inputs = (X, Y)  # keep alive until the stream has consumed them
+        return dict(W=W, P=P, Q=Q, R=R, T=T, B=B)
+
+    def fit_host(self, X, Y, A: int, method: int = KERNEL_TYPE1, dtype=np.float64):
+        X = _np_f(X, dtype); Y = _np_f(Y, dtype)
+        N, K = X.shape
+        M = Y.shape[1]
+        W = np.zeros((K, A), order="F"); P = np.zeros((K, A), order="F")
+        R = np.zeros((K, A), order="F"); Q = np.zeros((M, A), order="F")
+        B = np.zeros((K, M), order="F")
+        T = np.zeros((N, A), dtype=dtype, order="F")
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = self._lib.pls_hip_fit(self.h, p(X), max(N, 1), p(Y), max(N, 1), N, K, M, A, method,
+                                   L.F64 if dtype == np.float64 else L.F32, L.MEM_HOST,
+                                   p(W), p(P), p(Q), p(R), p(T), max(N, 1), p(B))
+        L.check(rc, self.h)
+        return dict(W=W, P=P, Q=Q, R=R, T=T, B=B)
+
+    def xb(self, X, Bm):
+        """X (N,K) @ Bm (K,C): fitted_values / scores product."""
+        if _is_torch(X):
+            X = as_colmajor(X)
+            Bm = as_colmajor(Bm.to(torch.float64))
+            N, K = X.shape
+            C = Bm.shape[1]
+            out = colmajor_empty(N, C, X.dtype, X.device)
+            rc = self._lib.pls_hip_xb(self.h, X.data_ptr(), _ld(X), N, K, Bm.data_ptr(), _ld(Bm), C,
+                                      self._dt(X), L.MEM_DEVICE, out.data_ptr(), _ld(out))
+            L.check(rc, self.h)
+            self._last_inputs = (X, Bm)
+            return out
+        dtype = np.float32 if np.asarray(X).dtype == np.float32 else np.float64
+        X = _np_f(X, dtype); Bm = _np_f(Bm, np.float64)
+        N, K = X.shape
+        C = Bm.shape[1]
+        out = np.zeros((N, C), dtype=dtype, order="F")
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = self._lib.pls_hip_xb(self.h, p(X), max(N, 1), N, K, p(Bm), K, C,
+                                  L.F64 if dtype == np.float64 else L.F32, L.MEM_HOST, p(out), max(N, 1))
+        L.check(rc, self.h)
+        return out
+
+    def coefficients(self, R, Q, c: int):
+        if _is_torch(R):
+            R = as_colmajor(R); Q = as_colmajor(Q)
+            K, A = R.shape
+            M = Q.shape[0]
+            if _ld(R) != K or _ld(Q) != M:
+                R = colmajor_empty(K, A, torch.float64, R.device, ld=K).copy_(R)
+                Q = colmajor_empty(M, A, torch.float64, Q.device, ld=M).copy_(Q)
+            B = colmajor_empty(K, M, torch.float64, R.device, ld=K)
+            rc = self._lib.pls_hip_coefficients(self.h, R.data_ptr(), Q.data_ptr(), K, M, A, c,
+                                                L.MEM_DEVICE, B.data_ptr())
+            L.check(rc, self.h)
+            self._last_inputs = (R, Q)
+            return B
+        R = _np_f(R, np.float64); Q = _np_f(Q, np.float64)
+        K, A = R.shape
+        M = Q.shape[0]
+        B = np.zeros((K, M), order="F")
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        L.check(self._lib.pls_hip_coefficients(self.h, p(R), p(Q), K, M, A, c, L.MEM_HOST, p(B)), self.h)
+        return B
+
+    def xty(self, X, Y):
+        X = as_colmajor(X); Y = as_colmajor(Y, X.dtype)
+        N, K = X.shape
+        M = Y.shape[1]
+        out = colmajor_empty(K, M, torch.float64, X.device, ld=K)
+        L.check(self._lib.pls_hip_xty(self.h, X.data_ptr(), _ld(X), Y.data_ptr(), _ld(Y), N, K, M,
+                                      self._dt(X), out.data_ptr()), self.h)
+        self._last_inputs = (X, Y)
+        return out
+
+    def deflate(self, src, t, p, dst=None):
+        src = as_colmajor(src)
+        N, K = src.shape
+        if dst is None:
+            dst = colmajor_empty(N, K, src.dtype, src.device)
+        t = t.to(src.dtype).contiguous()
+        p = p.to(torch.float64).contiguous()
+        L.check(self._lib.pls_hip_deflate(self.h, src.data_ptr(), _ld(src), dst.data_ptr(), _ld(dst),
+                                          N, K, t.data_ptr(), p.data_ptr(), self._dt(src)), self.h)
+        self._last_inputs = (src, t, p)
+        return dst
+
+    def synth_x(self, row0: int, nrows: int, K: int, seed: int, dtype=None, device=None):
+        dtype = dtype or torch.float64
+        X = colmajor_empty(nrows, K, dtype, device or f"cuda:{self.device}")
+        L.check(self._lib.pls_hip_synth_x(self.h, X.data_ptr(), _ld(X), row0, nrows, K, seed,
+                                          L.F64 if dtype == torch.float64 else L.F32), self.h)
+        return X
+
+    def synth_y(self, row0: int, nrows: int, M: int, seed: int, dtype=None, device=None):
+        dtype = dtype or torch.float64
+        Y = colmajor_empty(nrows, M, dtype, device or f"cuda:{self.device}")
+        L.check(self._lib.pls_hip_synth_y(self.h, Y.data_ptr(), _ld(Y), row0, nrows, M, seed,
+                                          L.F64 if dtype == torch.float64 else L.F32), self.h)
+        return Y
+
+
+# ---------------------------------------------------------------------------------------------
+# PLS::Model
+# ---------------------------------------------------------------------------------------------
+
+class Model:
+    """Mirror of `PLS::Model` (reference include/PLS/pls.h:184-266).
+
+    Model(X, Y, algorithm=KERNEL_TYPE1, max_components=None) fits immediately, like the
+    reference's data-taking constructors (src/pls.cpp:340-359): max_components defaults to
+    X.cols().  X: N x K, Y: N x M.  torch CUDA tensors stay on the device; numpy arrays go
+    through the library's host path.
+    """
+
+    def __init__(self, X, Y, algorithm: int = KERNEL_TYPE1, max_components: int | None = None, *,
+                 handle: Handle | None = None):
+        self.handle = handle or Handle()
+        self._on_device = _is_torch(X)
+        K = X.shape[1]
+        self.A = int(K if max_components is None else max_components)  # src/pls.cpp:356-359
+        self.method = algorithm
+        self.W = self.P = self.R = self.Q = self.T = None
+        self.plsr(X, Y, algorithm)
+
+    # void plsr(const Mat2D&, const Mat2D&, const METHOD&)  include/PLS/pls.h:199
+    def plsr(self, X, Y, algorithm: int = KERNEL_TYPE1):
+        self.method = algorithm
+        if _is_torch(X):
+            out = self.handle.fit_device(X, Y, self.A, algorithm, want_B=False)
+        else:
+            dt = np.float32 if np.asarray(X).dtype == np.float32 else np.float64
+            out = self.handle.fit_host(X, Y, self.A, algorithm, dtype=dt)
+        self.W, self.P, self.Q, self.R, self.T = (out[k] for k in "WPQRT")
+
+    def _comp(self, comp):
+        comp = self.A if comp is None else int(comp)
+        if not (0 <= comp <= self.A):  # assert (A >= comp): src/pls.cpp:440, :445
+            raise L.PlsHipError(L.ERR_INVALID, f"comp={comp} exceeds the fitted A={self.A}")
+        return comp
+
+    # const Mat2Dc scores(const Mat2D& X_new, size_t comp)   src/pls.cpp:439-442
+    def scores(self, X_new, comp: int | None = None):
+        c = self._comp(comp)
+        return self.handle.xb(X_new, self.R[:, :c])
+
+    # declared but never defined by the reference (include/PLS/pls.h:207-211); the natural
+    # definitions, SURVEY.md section 8(b)
+    def loadingsX(self, comp: int | None = None):
+        return self.P[:, :self._comp(comp)]
+
+    def loadingsY(self, comp: int | None = None):
+        return self.Q[:, :self._comp(comp)]
+
+    # const Mat2Dc coefficients(size_t comp)   src/pls.cpp:444-447
+    def coefficients(self, comp: int | None = None):
+        return self.handle.coefficients(self.R, self.Q, self._comp(comp))
+
+    # const Mat2D fitted_values(const Mat2D& X, size_t comp)   src/pls.cpp:449-451
+    def fitted_values(self, X, comp: int | None = None):
+        return self.handle.xb(X, self.coefficients(comp))
+
+    # residuals / SSE / explained_variance: src/pls.cpp:453-467 (thin host arithmetic on N x M)
+    def residuals(self, X, Y, comp: int | None = None):
+        fv = self.fitted_values(X, comp)
+        if _is_torch(Y):
+            Y2 = Y if Y.dim() == 2 else Y[:, None]
+            return Y2.to(fv.dtype) - fv
+        return _np_f(Y, fv.dtype) - fv
+
+    def SSE(self, X, Y, comp: int | None = None):
+        r = self.residuals(X, Y, comp)
+        return (r * r).sum(0)
+
+    def explained_variance(self, X, Y, comp: int | None = None):
+        sse = self.SSE(X, Y, comp)
+        Y2 = Y if Y.ndim == 2 else Y[:, None]
+        if _is_torch(Y2):
+            Yd = Y2.to(torch.float64)
+            sst = ((Yd - Yd.mean(0, keepdim=True)) ** 2).sum(0) if Yd.shape[0] >= 2 else torch.zeros_like(sse)
+            return 1.0 - sse.to(torch.float64) / sst
+        Yd = np.asarray(Y2, dtype=np.float64)
+        sst = ((Yd - Yd.mean(0)) ** 2).sum(0) if Yd.shape[0] >= 2 else np.zeros(Yd.shape[1])  # SST: :69-73
+        return 1.0 - np.asarray(sse, dtype=np.float64) / sst

@@ -1,0 +1,298 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the oracle and the golden fixtures.
+
+Tolerances (fp64): coefficients B within 1e-10 relative Frobenius error of the oracle (the north
+star's bar); W,P,Q,R,T compared per component modulo sign (the reference leaves the eigenvector
+sign open) within 1e-9.  Integer/bit-exact checks: the synthetic generator.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL_B = 1e-10
+TOL_COL = 1e-9
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def to_dev(a, dtype=None):
+    torch = _torch()
+    import pls_amd
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return pls_amd.as_colmajor(t if dtype is None else t.to(dtype))
+
+
+def check_against(po, out, ref, Bref, Tref=None, tol_b=TOL_B, tol_col=TOL_COL, col_err=None, tol_inv=1e-8):
+    """B: relative Frobenius error <= tol_b (sign-invariant, well conditioned).
+    W,P,R,Q,T: per component, modulo sign, <= max(tol_col, 20 x col_err[a]) where col_err is the
+    disagreement between independent fp64 CPU implementations on that component (noise
+    components are ill-conditioned in direction, not in B; see tests/golden/make_golden.py)."""
+    got = {k: out[k].cpu().numpy().astype(np.float64) for k in "WPQRB"}
+    assert np.isfinite(got["B"]).all()
+    assert po.rel_fro(got["B"], Bref) < tol_b
+    refd = {k: np.asarray(ref[k]) for k in "WPQR"}
+    refd["T"] = None if Tref is None else np.asarray(Tref)
+    got["T"] = None if Tref is None else out["T"].cpu().numpy().astype(np.float64)
+    err = po.column_errors(refd, got)
+    A = got["W"].shape[1]
+    lim = np.full(A, tol_col) if col_err is None else np.maximum(tol_col, 20.0 * np.asarray(col_err))
+    assert (err <= lim).all(), f"column errors {err} exceed {lim}"
+    # invariants of the algorithm: unit-norm w, P^T R = I
+    assert np.allclose((got["W"] ** 2).sum(0), 1.0, atol=1e-12)
+    assert np.allclose(got["P"].T @ got["R"], np.eye(A), atol=tol_inv)
+
+
+def oracle_ref(oracle, po, Xh, Yh, A):
+    """oracle fit + coefficient matrix + per-component conditioning estimate (kernel form vs the
+    independently written NIPALS-deflation form of the oracle)."""
+    ref = oracle.plsr(Xh, Yh, A)
+    alt = oracle.plsr(Xh, Yh, A, nipals=True)
+    return ref, oracle.coefficients(ref["R"], ref["Q"]), po.column_errors(ref, alt)
+
+
+def golden_cases():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "s_*.npz")))
+
+
+@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1)], ids=["kernel-unfused", "kernel-fused", "nipals-unfused", "nipals-fused"])
+def mode(request, handle):
+    import pls_amd
+    algo, fuse = request.param
+    handle.set_option(pls_amd.OPT_ALGO, algo)
+    handle.set_option(pls_amd.OPT_FUSE, fuse)
+    yield request.param
+    handle.set_option(pls_amd.OPT_ALGO, 0)
+    handle.set_option(pls_amd.OPT_FUSE, 1)
+
+
+# ------------------------------------------------------------------------------------------
+# reference example data (BASELINE configs 1 and 2)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,fx,fy", [("toy_A2", "toyX.csv", "toyY.csv"), ("nir_A10", "nir.csv", "octane.csv")])
+def test_reference_csv_golden(handle, oracle, po, mode, name, fx, fy):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    A = int(g["A"])
+    X = oracle.z_scores(po.read_csv(os.path.join(DATA, fx)))
+    Y = oracle.z_scores(po.read_csv(os.path.join(DATA, fy)))
+    out = handle.fit_device(to_dev(X), to_dev(Y), A)
+    handle.synchronize()
+    check_against(po, out, g, g["B"], g["T"], col_err=g["col_err"])
+    assert np.allclose((out["T"].cpu().numpy() ** 2).sum(0), g["tt"], rtol=1e-9)
+
+
+def test_reference_csv_model_api(handle, oracle, po):
+    """the Python mirror of PLS::Model on the README smoke test (toy, A=2): fit, coefficients,
+    fitted_values, scores, explained variance / SSE (src/pls.cpp:439-467)."""
+    import pls_amd
+    g = np.load(os.path.join(GOLDEN, "toy_A2.npz"))
+    X = oracle.z_scores(po.read_csv(os.path.join(DATA, "toyX.csv")))
+    Y = oracle.z_scores(po.read_csv(os.path.join(DATA, "toyY.csv")))
+    Xd, Yd = to_dev(X), to_dev(Y)
+    m = pls_amd.Model(Xd, Yd, pls_amd.KERNEL_TYPE1, 2, handle=handle)
+    assert po.rel_fro(m.coefficients().cpu().numpy(), g["B"]) < TOL_B
+    for c in (1, 2):
+        ev = m.explained_variance(Xd, Yd, c).cpu().numpy()
+        sse = m.SSE(Xd, Yd, c).cpu().numpy()
+        assert np.allclose(ev, g["explained_variance"][c - 1], rtol=1e-9, atol=1e-12)
+        assert np.allclose(sse, g["SSE"][c - 1], rtol=1e-9)
+    s = po.sign_align(g["W"], m.W.cpu().numpy())
+    assert po.rel_fro(m.scores(Xd).cpu().numpy() * s, g["T"]) < TOL_COL
+    assert po.rel_fro(m.fitted_values(Xd).cpu().numpy(), X @ g["B"]) < TOL_B
+    with pytest.raises(pls_amd.PlsHipError):
+        m.coefficients(3)  # comp > A: the reference asserts (src/pls.cpp:445)
+    # host-memory path (numpy in, numpy out): what the C++ Model uses
+    mh = pls_amd.Model(X, Y, pls_amd.KERNEL_TYPE1, 2, handle=handle)
+    assert po.rel_fro(mh.coefficients(), g["B"]) < TOL_B
+    assert po.rel_fro(mh.fitted_values(X), X @ g["B"]) < TOL_B
+
+
+# ------------------------------------------------------------------------------------------
+# seeded synthetic shapes: ragged N and K, m in {1,2,4,8}
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_cases())
+def test_synthetic_golden(handle, po, oracle, mode, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    N, K, M, A, seed = (int(g[k]) for k in ("N", "K", "M", "A", "seed"))
+    X = handle.synth_x(0, N, K, seed)
+    Y = handle.synth_y(0, N, M, seed)
+    # the device generator is bit-identical to the host one (integer/dyadic arithmetic)
+    assert float(np.abs(X.cpu().numpy()).sum()) == float(g["x_checksum"])
+    assert float(np.abs(Y.cpu().numpy()).sum()) == float(g["y_checksum"])
+    out = handle.fit_device(X, Y, A)
+    handle.synchronize()
+    check_against(po, out, g, g["B"], g["T"] if "T" in g.files else None, col_err=g["col_err"])
+    assert np.allclose((out["T"].cpu().numpy() ** 2).sum(0), g["tt"], rtol=1e-9)
+
+
+def test_synth_bit_exact(handle, oracle, po):
+    for (r0, n, K, M) in ((0, 9, 7, 2), (12345, 1000, 33, 8), (1 << 20, 513, 64, 1)):
+        X = handle.synth_x(r0, n, K, 0x504C5301).cpu().numpy()
+        Y = handle.synth_y(r0, n, M, 0x504C5301).cpu().numpy()
+        assert np.array_equal(X, oracle.synth_x(r0, n, K))
+        assert np.array_equal(Y, oracle.synth_y(r0, n, M))
+        assert np.array_equal(X, po.synth_x(r0, n, K))
+    # fp32 storage = the fp64 value rounded once
+    torch = _torch()
+    X32 = handle.synth_x(7, 300, 20, 0x504C5301, dtype=torch.float32).cpu().numpy()
+    assert np.array_equal(X32, oracle.synth_x(7, 300, 20).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------
+# single steps of the path
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,K,M", [(9, 7, 2), (1000, 64, 4), (4097, 513, 8), (2048, 512, 1), (777, 33, 3)])
+def test_steps_xty_xb_deflate(handle, oracle, po, N, K, M):
+    torch = _torch()
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    X, Y = to_dev(Xh), to_dev(Yh)
+    XY = handle.xty(X, Y); handle.synchronize()
+    assert po.rel_fro(XY.cpu().numpy(), oracle.xty(Xh, Yh)) < 1e-13
+    Bm = np.asfortranarray(np.random.default_rng(1).standard_normal((K, M)))
+    out = handle.xb(X, to_dev(Bm)); handle.synchronize()
+    assert po.rel_fro(out.cpu().numpy(), oracle.xb(Xh, Bm)) < 1e-13
+    t = Yh[:, 0].copy(); p = Bm[:, 0].copy()
+    D = handle.deflate(X, torch.from_numpy(t).cuda(), torch.from_numpy(p).cuda()); handle.synchronize()
+    assert po.rel_fro(D.cpu().numpy(), Xh - np.outer(t, p)) < 1e-15
+    # unaligned leading dimension / odd base pointer take the narrow (8-byte) path
+    big = torch.empty((K, N + 3), dtype=torch.float64, device="cuda")
+    Xo = big[:, 1:N + 1].t()
+    Xo.copy_(X)
+    assert po.rel_fro(handle.xty(Xo, Y).cpu().numpy(), oracle.xty(Xh, Yh)) < 1e-13
+    assert po.rel_fro(handle.xb(Xo, to_dev(Bm)).cpu().numpy(), oracle.xb(Xh, Bm)) < 1e-13
+
+
+def test_unaligned_fit(handle, oracle, po, mode):
+    torch = _torch()
+    N, K, M, A = 1001, 37, 2, 6
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    big = torch.empty((K, N + 3), dtype=torch.float64, device="cuda")
+    X = big[:, 1:N + 1].t()
+    X.copy_(torch.from_numpy(Xh).cuda())
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    out = handle.fit_device(X, to_dev(Yh), A); handle.synchronize()
+    check_against(po, out, ref, Bref, ref["T"], col_err=cerr)
+
+
+def test_x_not_modified_and_deterministic(handle, oracle, po, mode):
+    N, K, M, A = 3000, 96, 3, 7
+    X = handle.synth_x(0, N, K, 1234); Y = handle.synth_y(0, N, M, 1234)
+    X0 = X.clone()
+    a = handle.fit_device(X, Y, A); handle.synchronize()
+    b = handle.fit_device(X, Y, A); handle.synchronize()
+    assert _torch().equal(X, X0), "the caller's X must never be written (const at the API, pls.h:188)"
+    for k in "WPQRTB":  # fixed-order reductions: bit-identical run to run
+        assert _torch().equal(a[k], b[k]), k
+
+
+def test_t_orthogonal_full_rank_components(handle, po):
+    """A = K components on a small matrix: scores mutually orthogonal, P^T R = I, and the
+    regression reproduces least squares (B_A=K == lstsq) -- a size-independent property."""
+    N, K, M = 500, 12, 2
+    X = handle.synth_x(0, N, K, 99); Y = handle.synth_y(0, N, M, 99)
+    out = handle.fit_device(X, Y, K); handle.synchronize()
+    T = out["T"].cpu().numpy()
+    G = T.T @ T
+    off = G - np.diag(np.diag(G))
+    assert np.abs(off).max() < 1e-9 * np.diag(G).max()
+    Bls = np.linalg.lstsq(X.cpu().numpy(), Y.cpu().numpy(), rcond=None)[0]
+    assert po.rel_fro(out["B"].cpu().numpy(), Bls) < 1e-8
+
+
+def test_power_iteration_close_eigenvalues(handle, oracle, po):
+    """m > 1 direction: two response columns of nearly equal weight (eigenvalues of S^T S close)."""
+    N, K, A = 2000, 24, 5
+    Xh = oracle.synth_x(0, N, K)
+    Yh = oracle.synth_y(0, N, 4)
+    Yh[:, 1] = Yh[:, 1] * 2.0   # undo the 2^-j scaling so that columns 0 and 1 compete
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    out = handle.fit_device(to_dev(Xh), to_dev(Yh), A); handle.synchronize()
+    check_against(po, out, ref, Bref, ref["T"], col_err=cerr)
+
+
+def test_fp32_storage(handle, oracle, po, mode):
+    """BASELINE config 4 is fp32 (no reference counterpart: float_type is double, pls.h:22).
+    fp32 storage of X, Y, T with fp64 accumulation, checked against the fp64 oracle run on the
+    same fp32-rounded inputs.  Tolerance 2e-5 on B (T is rounded to fp32 between the passes)."""
+    torch = _torch()
+    N, K, M, A = 4096, 200, 8, 10
+    X = handle.synth_x(0, N, K, 7, dtype=torch.float32); Y = handle.synth_y(0, N, M, 7, dtype=torch.float32)
+    Xh = X.cpu().numpy().astype(np.float64); Yh = Y.cpu().numpy().astype(np.float64)
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    out = handle.fit_device(X, Y, A); handle.synchronize()
+    check_against(po, out, ref, Bref, ref["T"], tol_b=2e-5, tol_col=2e-5, col_err=cerr, tol_inv=1e-4)
+
+
+# ------------------------------------------------------------------------------------------
+# error behaviour at the boundary (reference: asserts only, src/pls.cpp:345-347)
+# ------------------------------------------------------------------------------------------
+def test_bad_arguments(handle):
+    import pls_amd
+    torch = _torch()
+    X = handle.synth_x(0, 50, 5, 1); Y = handle.synth_y(0, 50, 1, 1)
+    with pytest.raises(pls_amd.PlsHipError) as e:
+        handle.fit_device(X, Y, 6)  # A > K
+    assert e.value.code == 1
+    with pytest.raises(pls_amd.PlsHipError) as e:
+        handle.fit_device(X, Y, 2, method=pls_amd.KERNEL_TYPE2)
+    assert e.value.code == 4
+    with pytest.raises(pls_amd.PlsHipError):
+        handle.fit_device(X, handle.synth_y(0, 50, 40, 1), 2)  # m > 32
+    # the handle stays usable after an error
+    out = handle.fit_device(X, Y, 2); handle.synchronize()
+    assert torch.isfinite(out["B"]).all()
+
+
+def test_rank_deficient_leading_components(handle, oracle, po):
+    """A > rank(X): the surplus columns are inf/NaN/garbage in the reference too (division by
+    tt ~ 0, src/pls.cpp:427-428); the leading rank(X) components are unaffected."""
+    N, K, A = 5, 9, 7
+    Xh = oracle.synth_x(0, N, K); Yh = oracle.synth_y(0, N, 1)
+    ref = oracle.plsr(Xh, Yh, A)
+    out = handle.fit_device(to_dev(Xh), to_dev(Yh), A); handle.synchronize()
+    W = out["W"].cpu().numpy()
+    s = po.sign_align(ref["W"][:, :4], W[:, :4])
+    assert po.rel_fro(W[:, :4] * s, ref["W"][:, :4]) < 1e-8
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE full size (config 3: 1,048,576 x 512, m = 1) through size-independent properties
+# ------------------------------------------------------------------------------------------
+def test_full_size_properties(handle, po):
+    import pls_amd
+    torch = _torch()
+    N, K, M, A = 1 << 20, 512, 1, 4
+    X = handle.synth_x(0, N, K, pls_amd.SEED_DEFAULT); Y = handle.synth_y(0, N, M, pls_amd.SEED_DEFAULT)
+    outs = {}
+    for algo in (0, 1):
+        for fuse in (0, 1):
+            handle.set_option(pls_amd.OPT_ALGO, algo); handle.set_option(pls_amd.OPT_FUSE, fuse)
+            outs[(algo, fuse)] = handle.fit_device(X, Y, A)
+            handle.synchronize()
+    handle.set_option(pls_amd.OPT_ALGO, 0); handle.set_option(pls_amd.OPT_FUSE, 1)
+    base = outs[(0, 0)]
+    Bb = base["B"].cpu().numpy()
+    for key, o in outs.items():  # the four execution plans agree
+        assert po.rel_fro(o["B"].cpu().numpy(), Bb) < TOL_B, key
+    W = base["W"].cpu().numpy(); P = base["P"].cpu().numpy(); R = base["R"].cpu().numpy()
+    assert np.allclose((W * W).sum(0), 1.0, atol=1e-12)
+    assert np.allclose(P.T @ R, np.eye(A), atol=1e-9)
+    T = base["T"]
+    G = (T.t() @ T).cpu().numpy()
+    assert np.abs(G - np.diag(np.diag(G))).max() < 1e-9 * np.diag(G).max()  # orthogonal scores
+    # deflation: X - t p^T is orthogonal to t (X^T t = p tt)
+    t0 = T[:, 0].contiguous(); p0 = torch.from_numpy(P[:, 0].copy()).cuda()
+    D = handle.deflate(X, t0, p0)
+    resid = handle.xty(D, t0[:, None]); handle.synchronize()
+    assert float(resid.abs().max()) < 1e-9 * float(G[0, 0])
+    # row block of the full-size product against the oracle on the same rows
+    rows = slice(123456, 123456 + 2048)
+    Xs = X[rows].cpu().numpy()
+    assert po.rel_fro(T[rows, 0].cpu().numpy(), Xs @ R[:, 0]) < 1e-12
