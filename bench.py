@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- the PLS fit hot path on MI355X: NIPALS components/sec + achieved HBM GB/s.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one complete fit (A components) of BASELINE.json config 3 -- synthetic tall
+n = 1,048,576 x p = 512, m = 1, A = 20, fp64 -- with X, Y resident in HBM before the timed
+region.  With N > 1 the SAME matrix is row-sharded over the ranks (strong scaling: the metric
+is quoted at n = 1M for 1/2/4/8 GPUs), one process per GPU, the K x M / (K+1)-length partial
+products all-reduced with torch.distributed (RCCL over xGMI).  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      dominant kernel family of the timed fits: algorithmic bytes per launch / average
+                launch duration (HIP events on the launch stream, recorded by the library while
+                the timed steps run) against the 8.0 TB/s HBM3E peak.
+  cpu_baseline  the oracle's C restatement of the reference algorithm (Eigen is unavailable,
+                so this is "kind": "port"), one host core, on a bounded row sample.
+  alt           the other execution plans on the same data (not the headline value).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
+WORKLOADS = {
+    # name: (N, K, M, A, dtype)
+    "C3": (1 << 20, 512, 1, 20, "f64"),
+    "C4": (131072, 4096, 8, 50, "f32"),
+    "C5rank": (2097152, 1024, 4, 20, "f64"),  # one rank's shard of config 5
+    "tiny": (4096, 64, 1, 5, "f64"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--algo", default="nipals", choices=["nipals", "kernel"],
+                    help="nipals: north-star sequence with the rank-1 deflation of X (headline); "
+                         "kernel: the reference's own sequence, X read-only")
+    ap.add_argument("--fuse", type=int, default=1)
+    ap.add_argument("--no-alt", action="store_true", help="skip the alternative execution plans")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-rows", type=int, default=1 << 20, help="rows of the CPU baseline sample (default: the whole workload, ~10 s on one core)")
+    return ap.parse_args()
+
+
+def timed_fits(h, torch, dist, world, X, Y, A, steps, warmup, out):
+    for _ in range(warmup):
+        h.fit_device(X, Y, A, out=out)
+    torch.cuda.synchronize()
+    h.timing()  # drop warm-up events
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h.fit_device(X, Y, A, out=out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el, h.timing()
+
+
+def roofline_of(tm):
+    fams = [f for f in ("fused", "deflate", "xb", "xty") if tm["launches"][f] > 0]
+    if not fams:
+        return None
+    dom = max(fams, key=lambda f: tm["ms"][f])
+    n = tm["launches"][dom]
+    avg_ms = tm["ms"][dom] / n
+    bytes_per = tm["bytes"][dom] / n
+    ach = bytes_per / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "launches": n, "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(bytes_per),
+            "families_ms_per_fit": {f: round(tm["ms"][f] / max(tm["fits"], 1), 4) for f in tm["ms"]}}
+
+
+def cpu_baseline(N, K, M, A, rows):
+    """oracle C restatement (reference operation sequence: 1 + 2A passes over X), 1 core, -O3."""
+    from oracle import pls_oracle as po
+    rows = min(rows, N)
+    gen = po.OracleLib(omp=True)
+    Xh = gen.synth_x(0, rows, K)
+    Yh = gen.synth_y(0, rows, M)
+    one = po.OracleLib(omp=False)
+    t0 = time.perf_counter()
+    one.plsr(Xh, Yh, A)
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    gen.plsr(Xh, Yh, A)
+    tn = time.perf_counter() - t0
+    scale = rows / N  # cost is linear in N: components/s at the full N = sample rate x rows/N
+    base = {"value": round(A / t1 * scale, 4), "unit": "components/s", "cores": 1, "kind": "port",
+            "sample": f"first {rows} of {N} rows x {K} cols, A={A}, fp64, one fit = {t1:.2f} s; "
+                      f"rate scaled by {rows}/{N} (cost linear in rows); restatement of the reference "
+                      f"algorithm, Eigen unavailable"}
+    omp = {"value": round(A / tn * scale, 4), "unit": "components/s", "cores": gen.num_threads(), "kind": "port",
+           "sample": f"same sample, -O3 -march=x86-64-v3 -fopenmp, one fit = {tn:.2f} s"}
+    return base, omp
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    import pls_amd
+    from pls_amd.distributed import attach_reducer, row_partition
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    N, K, M, A, dt = WORKLOADS[a.workload]
+    tdt = torch.float64 if dt == "f64" else torch.float32
+    row0, nrows = row_partition(N, world, rank)
+    h = pls_amd.Handle()
+    X = h.synth_x(row0, nrows, K, pls_amd.SEED_DEFAULT, dtype=tdt)
+    Y = h.synth_y(row0, nrows, M, pls_amd.SEED_DEFAULT, dtype=tdt)
+    if world > 1:
+        attach_reducer(h, K, M)
+    algo = pls_amd.ALGO_NIPALS if a.algo == "nipals" else pls_amd.ALGO_KERNEL
+    h.set_option(pls_amd.OPT_ALGO, algo)
+    h.set_option(pls_amd.OPT_FUSE, a.fuse)
+    h.set_option(pls_amd.OPT_PROFILE, 1)
+    out = h.fit_device(X, Y, A)  # allocates outputs + workspace once
+    torch.cuda.synchronize()
+
+    el, tm = timed_fits(h, torch, dist, world, X, Y, A, a.steps, a.warmup, out)
+    value = A * a.steps / el
+    es = 8 if dt == "f64" else 4
+    line = {
+        "metric": "NIPALS components/sec", "value": round(value, 2), "unit": "components/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dt, "data": "synthetic",
+        "config": {"workload": f"{a.workload}: synthetic tall n={N} x p={K}, m={M}, A={A}, {dt}, resident in HBM",
+                   "algo": a.algo, "fuse": a.fuse, "rows_per_gpu": nrows,
+                   "parallelism": f"row-shard x{world}" if world > 1 else "single GPU"},
+        "roofline": roofline_of(tm),
+        # end-to-end effective stream rate: (2A) N K s / t_fit, the fused lower bound
+        "effective_gbs": round(2 * A * N * K * es / (el / a.steps) / 1e9, 1),
+    }
+
+    if rank == 0 or world > 1:
+        alt = {}
+        if not a.no_alt and world == 1:
+            for name, (al, fu) in {"kernel_fused": (0, 1), "kernel_unfused": (0, 0), "nipals_fused": (1, 1),
+                                   "nipals_unfused": (1, 0)}.items():
+                if (al, fu) == (algo, a.fuse):
+                    continue
+                h.set_option(pls_amd.OPT_ALGO, al)
+                h.set_option(pls_amd.OPT_FUSE, fu)
+                e2, t2 = timed_fits(h, torch, dist, 1, X, Y, A, max(2, a.steps // 2), 1, out)
+                st = max(2, a.steps // 2)
+                alt[name] = {"components_per_s": round(A * st / e2, 2), "ms_per_fit": round(e2 / st * 1e3, 3),
+                             "roofline": roofline_of(t2)}
+            # the stand-alone rank-1 deflation (the north star's "deflation step"), X -= t p^T in place
+            h.set_option(pls_amd.OPT_ALGO, algo)
+            h.set_option(pls_amd.OPT_FUSE, a.fuse)
+            t = out["T"][:, 0].contiguous()
+            p = out["P"][:, 0].contiguous()
+            W = pls_amd.colmajor_empty(nrows, K, tdt, X.device)
+            W.copy_(X)
+            for _ in range(2):
+                h.deflate(W, t, p, dst=W)
+            torch.cuda.synchronize()
+            h.timing()
+            for _ in range(10):
+                h.deflate(W, t, p, dst=W)
+            td = h.timing()
+            alt["deflate_kernel"] = roofline_of(td)
+            del W
+        line["alt"] = alt
+
+    if rank == 0:
+        if not a.no_cpu:
+            try:
+                base, omp = cpu_baseline(N, K, M, A, a.cpu_rows)
+                line["cpu_baseline"] = base
+                line["cpu_baseline_allcore"] = omp
+            except Exception as e:  # the oracle is test infrastructure: report, do not hide
+                line["cpu_baseline"] = {"value": None, "unit": "components/s", "cores": 1, "kind": "port",
+                                        "sample": f"failed: {e!r}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

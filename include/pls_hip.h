@@ -90,8 +90,9 @@ typedef enum {
  */
 typedef int (*pls_hip_allreduce_fn)(void *user, void *buf, int64_t count, void *stream);
 
-/* Per-family device time of the most recent fit (filled only with PLS_HIP_OPT_PROFILE=1;
- * ms from hipEventElapsedTime on the launch stream) and launch counts. */
+/* Per-family device time of every launch since the previous pls_hip_get_timing call (recorded
+ * only while PLS_HIP_OPT_PROFILE=1; ms from hipEventElapsedTime on the launch stream), launch
+ * counts and algorithmic bytes.  pls_hip_get_timing synchronises the stream and resets. */
 enum {
     PLS_HIP_FAM_XTY = 0,     /* X^T Y  and  X^T t   (column reductions)           */
     PLS_HIP_FAM_XB = 1,      /* t = X v, X B        (row products)                */
@@ -101,7 +102,8 @@ enum {
     PLS_HIP_FAM_COUNT = 5
 };
 typedef struct {
-    double fit_ms;                       /* whole fit, first launch to last            */
+    double fit_ms;                       /* summed over fits: first launch to last     */
+    int64_t fits;                        /* number of pls_hip_fit calls covered        */
     double fam_ms[PLS_HIP_FAM_COUNT];    /* summed over launches of the family        */
     int64_t fam_launches[PLS_HIP_FAM_COUNT];
     int64_t fam_bytes[PLS_HIP_FAM_COUNT]; /* ALGORITHMIC bytes summed over those launches */

@@ -33,6 +33,7 @@ ALLREDUCE_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _i64, _vp)
 
 class Timing(ctypes.Structure):
     _fields_ = [("fit_ms", ctypes.c_double),
+                ("fits", _i64),
                 ("fam_ms", ctypes.c_double * FAM_COUNT),
                 ("fam_launches", _i64 * FAM_COUNT),
                 ("fam_bytes", _i64 * FAM_COUNT)]

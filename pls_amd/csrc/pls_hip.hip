@@ -46,10 +46,11 @@ struct pls_hip_context {
     DevBuf part, sspart, red, xy, v, tab, work, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
-    std::vector<hipEvent_t> ev_pool;
+    std::vector<hipEvent_t> ev_pool;  // grows until pls_hip_get_timing harvests and recycles it
     size_t ev_used = 0;
-    std::vector<Launch> launches;
-    hipEvent_t fit0 = nullptr, fit1 = nullptr;
+    std::vector<Launch> launches;     // every bracketed launch since the last harvest
+    std::vector<Launch> fits;         // one bracket per pls_hip_fit since the last harvest
+    Launch cur_fit{};
     bool fit_timed = false;
     int num_cu = 256;
 };
@@ -399,19 +400,20 @@ int set_device(pls_hip_context *c) {
 }
 
 void begin_fit_timing(pls_hip_context *c) {
-    c->launches.clear();
-    c->ev_used = 0;
     c->fit_timed = false;
     if (!c->opt_profile) return;
-    if (!c->fit0) (void)hipEventCreate(&c->fit0);
-    if (!c->fit1) (void)hipEventCreate(&c->fit1);
-    if (c->fit0 && c->fit1) {
-        (void)hipEventRecord(c->fit0, c->stream);
+    c->cur_fit.e0 = take_event(c);
+    c->cur_fit.e1 = take_event(c);
+    if (c->cur_fit.e0 && c->cur_fit.e1) {
+        (void)hipEventRecord(c->cur_fit.e0, c->stream);
         c->fit_timed = true;
     }
 }
 void end_fit_timing(pls_hip_context *c) {
-    if (c->fit_timed) (void)hipEventRecord(c->fit1, c->stream);
+    if (!c->fit_timed) return;
+    (void)hipEventRecord(c->cur_fit.e1, c->stream);
+    c->fits.push_back(c->cur_fit);
+    c->fit_timed = false;
 }
 
 // host <-> device staging of a column-major matrix with leading dimension
@@ -467,8 +469,6 @@ int pls_hip_destroy(pls_hip_handle h) {
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    if (h->fit0) (void)hipEventDestroy(h->fit0);
-    if (h->fit1) (void)hipEventDestroy(h->fit1);
     delete h;
     return PLS_HIP_OK;
 }
@@ -545,10 +545,11 @@ int pls_hip_get_timing(pls_hip_handle h, pls_hip_timing *out) {
     std::memset(out, 0, sizeof(*out));
     CHK(set_device(h));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->fit_timed) {
+    for (const Launch &l : h->fits) {
         float ms = 0.f;
-        HIPCHK(h, hipEventElapsedTime(&ms, h->fit0, h->fit1));
-        out->fit_ms = ms;
+        HIPCHK(h, hipEventElapsedTime(&ms, l.e0, l.e1));
+        out->fit_ms += ms;
+        out->fits += 1;
     }
     for (const Launch &l : h->launches) {
         float ms = 0.f;
@@ -557,6 +558,9 @@ int pls_hip_get_timing(pls_hip_handle h, pls_hip_timing *out) {
         out->fam_launches[l.fam] += 1;
         out->fam_bytes[l.fam] += l.bytes;
     }
+    h->launches.clear();  // harvested: recycle the event pool
+    h->fits.clear();
+    h->ev_used = 0;
     return PLS_HIP_OK;
 }
 

@@ -122,7 +122,7 @@ class Handle:
     def timing(self) -> dict:
         t = L.Timing()
         L.check(self._lib.pls_hip_get_timing(self.h, ctypes.byref(t)), self.h)
-        return {"fit_ms": t.fit_ms,
+        return {"fit_ms": t.fit_ms, "fits": int(t.fits),
                 "ms": {n: t.fam_ms[i] for i, n in enumerate(L.FAM_NAMES)},
                 "launches": {n: int(t.fam_launches[i]) for i, n in enumerate(L.FAM_NAMES)},
                 "bytes": {n: int(t.fam_bytes[i]) for i, n in enumerate(L.FAM_NAMES)}}
@@ -131,19 +131,24 @@ class Handle:
     def _dt(self, x):
         return L.F64 if x.dtype == torch.float64 else L.F32
 
-    def fit_device(self, X, Y, A: int, method: int = KERNEL_TYPE1, want_B: bool = True):
+    def fit_device(self, X, Y, A: int, method: int = KERNEL_TYPE1, want_B: bool = True, out=None):
         """X (N,K), Y (N,M) column-major CUDA tensors of one dtype.  Enqueues the fit and
-        returns dict(W,P,Q,R,T,B) of device tensors (column-major views)."""
+        returns dict(W,P,Q,R,T,B) of device tensors (column-major views).  `out`: a dict
+        returned by an earlier call with the same shapes, to be overwritten in place."""
         X = as_colmajor(X)
         Y = as_colmajor(Y, X.dtype)
         N, K = X.shape
         M = Y.shape[1]
         dev = X.device
         f64 = torch.float64
-        W = colmajor_empty(K, A, f64, dev, ld=K); P = colmajor_empty(K, A, f64, dev, ld=K)
-        R = colmajor_empty(K, A, f64, dev, ld=K); Q = colmajor_empty(M, A, f64, dev, ld=M)
-        T = colmajor_empty(N, A, X.dtype, dev)
-        B = colmajor_empty(K, M, f64, dev, ld=K) if want_B else None
+        if out is not None:
+            W, P, Q, R, T, B = (out[k] for k in "WPQRTB")
+            want_B = B is not None
+        else:
+            W = colmajor_empty(K, A, f64, dev, ld=K); P = colmajor_empty(K, A, f64, dev, ld=K)
+            R = colmajor_empty(K, A, f64, dev, ld=K); Q = colmajor_empty(M, A, f64, dev, ld=M)
+            T = colmajor_empty(N, A, X.dtype, dev)
+            B = colmajor_empty(K, M, f64, dev, ld=K) if want_B else None
         rc = self._lib.pls_hip_fit(self.h, X.data_ptr(), _ld(X), Y.data_ptr(), _ld(Y), N, K, M, A,
                                    method, self._dt(X), L.MEM_DEVICE, W.data_ptr(), P.data_ptr(),
                                    Q.data_ptr(), R.data_ptr(), T.data_ptr(), _ld(T),
