@@ -79,15 +79,18 @@ typedef enum {
     PLS_HIP_OPT_ALGO = 1,       /* pls_hip_algo; default PLS_HIP_ALGO_KERNEL */
     PLS_HIP_OPT_FUSE = 2,       /* 0: one kernel per product (Xv, X^T t, deflate); 1 (default): row-tile-resident fused pass when the shape allows */
     PLS_HIP_OPT_PROFILE = 3,    /* 1: bracket every kernel family with HIP events on the launch stream */
-    PLS_HIP_OPT_POWER_ITERS = 4 /* squarings of the S^T S power iteration (m > 1); default 48 */
+    PLS_HIP_OPT_POWER_ITERS = 4, /* squarings of the S^T S power iteration (m > 1); default 48 */
+    PLS_HIP_OPT_FUSED_GRID = 5   /* workgroups of the fused pass; 0 (default) = 8 per CU */
 } pls_hip_option;
 
 /*
  * In-place sum over ranks of `count` fp64 values at DEVICE address `buf`, ordered on
  * `stream` (a hipStream_t).  Must leave bit-identical results on every rank.  Called
- * 1 + A times per fit: once with count = K*M (the X^T Y partial), then once per
- * component with count = K+1 (packed [X^T t, t^T t]).  Return 0 on success.
+ * 1 + A times per fit: once with count = 8*K*M (the X^T Y partial, in PLS_HIP_REDUCE_SLICES
+ * fixed-order slices), then once per component with count = 8*(K+1) (slices of the packed
+ * [X^T t, t^T t]).  Return 0 on success.
  */
+#define PLS_HIP_REDUCE_SLICES 8
 typedef int (*pls_hip_allreduce_fn)(void *user, void *buf, int64_t count, void *stream);
 
 /* Per-family device time of every launch since the previous pls_hip_get_timing call (recorded
@@ -124,7 +127,8 @@ PLS_HIP_API int pls_hip_get_option(pls_hip_handle h, int option, int64_t *value)
 /* Row-sharded fit over `nranks` processes (one per GPU): every rank passes its own row
  * block and the same K, M, A; fn sums the small partial products.  fn == NULL: single rank. */
 PLS_HIP_API int pls_hip_set_reducer(pls_hip_handle h, pls_hip_allreduce_fn fn, void *user, int rank, int nranks);
-/* Optional caller-owned DEVICE staging buffer for the reducer (>= max(K*M, K+1) fp64), so a
+/* Optional caller-owned DEVICE staging buffer for the reducer
+ * (>= PLS_HIP_REDUCE_SLICES * max(K*M, K+1) fp64), so a
  * host runtime can hand its collective a buffer it allocated itself. */
 PLS_HIP_API int pls_hip_set_reduce_buffer(pls_hip_handle h, void *buf, int64_t count);
 PLS_HIP_API int pls_hip_synchronize(pls_hip_handle h);

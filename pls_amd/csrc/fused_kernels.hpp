@@ -1,18 +1,221 @@
-// Row-tile-resident fused pass: one read of X per component instead of two (and, for the
-// NIPALS algo, the deflation write folded into the same sweep).  See DESIGN.md section 4.
+// Row-tile-resident fused pass: ONE sweep over X per component.
+//
+//   KERNEL algo :  t = X r ;  p_raw = X^T t ;  tt = t^T t                    (src/pls.cpp:419-421)
+//                  -> X is read once per component instead of twice.
+//   NIPALS algo :  X' = X - t_prev p_prev^T (written once) ;  t = X' w ;  p_raw = X'^T t ; tt
+//                  -> the north star's rank-1 deflation fused with the next component's score
+//                     and loading products: one read + one write of X per component.
+//
+// t_i needs the WHOLE row i before p can use it, so a workgroup keeps a full-width tile
+// (R rows x all K columns) resident in registers: thread (rp, cg) owns V consecutive rows
+// (one 16-byte access) of the columns cg, cg+CG, cg+2CG, ...  A tile is K separate R*s-byte
+// segments (column stride ld*s); R*s = 256 B is the shortest segment that still streams at full
+// HBM rate on MI355X (measured: profiles/r1/tile_probe.txt -- 5.9 TB/s read-only at R = 32 fp64
+// rows, 4.3 TB/s at R = 16), so R = 32 (fp64) keeps the register tile small enough for two
+// 512-thread workgroups per CU, which is what overlaps one workgroup's reduction phase with
+// the other's loads.
+//
+// Per tile: all loads issued back to back (CPT x 16 B per lane in flight), [deflate + store],
+// per-lane partial t over the lane's columns, butterfly over the lanes that share rows, one
+// LDS exchange between the waves (double-buffered: one barrier per tile), then the loading
+// accumulation into CPT per-lane accumulators that live across all tiles of the workgroup.
+// The column set of a lane belongs to exactly one wave, so the final X^T t partial needs only
+// an in-wave butterfly -- no atomics anywhere, results are bit-reproducible.
 #pragma once
 #include "common.hpp"
 
 namespace plsk {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// gfx9-family raw buffer descriptor word 3 (DST_SEL xyzw, 32-bit data format); stride 0:
+// offsets are plain byte offsets, range-checked against num_records -- an out-of-range load
+// returns 0 and an out-of-range store is dropped, which is how the ragged edges are handled.
+constexpr int BUF_WORD3 = 0x00020000;
+
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+    static_assert(sizeof(Pack<T, V>) == 16, "16-byte accesses");
+    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    Pack<T, V> p;
+    __builtin_memcpy(&p, &raw, 16);
+    return p;
+}
+template <typename T, int V>
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, const Pack<T, V> &p) {
+    u32x4 raw;
+    __builtin_memcpy(&raw, &p, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(raw, r, voff, 0, 0);
+}
+
+// Addressing: every access of a tile is (wave-uniform descriptor for the column group) +
+// (per-lane 32-bit byte offset that never changes): the descriptor base X + tile*R + j*CG*ld
+// lives in SGPRs, the lane offset (rp*V + cg*ld)*s in ONE VGPR, so the CPT loads in flight cost
+// no address registers.  Lanes whose rows lie beyond N use an offset past num_records.
+template <typename T, int V, int R, int NT, int CPT, bool DEFL>
+__global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pass_kernel(
+    const T *X, i64 ldx, T *dst, i64 ldd, i64 N, int K,  // dst may alias X (in-place deflation)
+    const double *__restrict__ v, const T *__restrict__ tprev, const double *__restrict__ pprev,
+    T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart) {
+    constexpr int RP = R / V;    // lanes along the rows of a tile
+    constexpr int CG = NT / RP;  // column groups
+    constexpr int NW = NT / WAVE;
+    static_assert(RP <= WAVE && WAVE % RP == 0 && NT % RP == 0, "tile shape");
+    __shared__ double vs[CG * CPT];
+    __shared__ double ps[DEFL ? CG * CPT : 1];
+    __shared__ double tred[2][NW][R];
+    __shared__ double sred[NW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int rp = tid % RP, cg = tid / RP;
+    for (int k = tid; k < CG * CPT; k += NT) {
+        vs[k] = (k < K) ? v[k] : 0.0;
+        if (DEFL) ps[k] = (k < K) ? pprev[k] : 0.0;
+    }
+    __syncthreads();
+
+    double pacc[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) pacc[j] = 0.0;
+    double ss = 0.0;
+    int buf = 0;
+    const uint32_t xoff = (uint32_t)(((i64)rp * V + (i64)cg * ldx) * (i64)sizeof(T));
+    const uint32_t doff = DEFL ? (uint32_t)(((i64)rp * V + (i64)cg * ldd) * (i64)sizeof(T)) : 0u;
+    constexpr uint32_t OOR = 0x80000000u;  // beyond every num_records the launcher allows
+
+    for (i64 tile = blockIdx.x; tile * R < N; tile += gridDim.x, buf ^= 1) {
+        const i64 i0 = tile * R + (i64)rp * V;
+        const bool rowok = (i0 < N);  // N % V == 0 (launcher): a pack is all-valid or all-invalid
+        const uint32_t xo = rowok ? xoff : OOR, dof = rowok ? doff : OOR;
+        // LDS operands (v, p_prev) are re-read every tile: an index the compiler cannot prove
+        // loop-invariant keeps 2*CPT fp64 values out of the register file
+        int cgz = cg;
+        asm volatile("" : "+v"(cgz));
+        Pack<T, V> x[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int cols = min(CG, K - CG * j);  // columns of this group that exist (may be <= 0)
+            const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldx * (i64)sizeof(T)) : 0u;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<T *>(X + tile * R + (i64)j * CG * ldx), (short)0, (int)nrec, BUF_WORD3);
+            x[j] = buf_ld<T, V>(rs, xo);
+            __builtin_amdgcn_sched_barrier(0);  // build one descriptor, issue its load, repeat
+        }
+        if (DEFL) {
+            double tp[V];
+            if (rowok) {
+                const Pack<T, V> tpk = ld_pack<T, V>(tprev + i0);
+#pragma unroll
+                for (int e = 0; e < V; ++e) tp[e] = -(double)tpk.v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) tp[e] = 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const double pk = ps[cgz + CG * j];
+#pragma unroll
+                for (int e = 0; e < V; ++e) x[j].v[e] = (T)fma(tp[e], pk, (double)x[j].v[e]);
+                const int cols = min(CG, K - CG * j);
+                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldd * (i64)sizeof(T)) : 0u;
+                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+                    dst + tile * R + (i64)j * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
+                buf_st<T, V>(rd, dof, x[j]);
+            }
+        }
+        // score: partial over this lane's columns, then over the lanes / waves sharing the rows
+        double tp2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) tp2[e] = 0.0;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const double vk = vs[cgz + CG * j];
+#pragma unroll
+            for (int e = 0; e < V; ++e) tp2[e] = fma((double)x[j].v[e], vk, tp2[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+#pragma unroll
+            for (int m = RP; m < WAVE; m <<= 1) tp2[e] += shfl_xor_f64(tp2[e], m);
+        if (lane < RP)
+#pragma unroll
+            for (int e = 0; e < V; ++e) tred[buf][wv][rp * V + e] = tp2[e];
+        __syncthreads();
+        double t[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += tred[buf][w][rp * V + e];
+            t[e] = (double)(T)s;  // the score as stored
+        }
+        if (cg == 0 && rowok) {
+            Pack<T, V> o;
+#pragma unroll
+            for (int e = 0; e < V; ++e) o.v[e] = (T)t[e];
+            st_pack<T, V>(tout + i0, o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) ss = fma(t[e], t[e], ss);
+        }
+        // loading: p_raw[k] += sum over the lane's rows of x[i,k] * t[i]   (rows >= N hold x = 0)
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+#pragma unroll
+            for (int e = 0; e < V; ++e) pacc[j] = fma((double)x[j].v[e], t[e], pacc[j]);
+    }
+
+    // epilogue: sum over the RP lanes that share a column group (low lane bits), then one lane
+    // per column group writes this workgroup's partial row
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        double s = pacc[j];
+#pragma unroll
+        for (int m = 1; m < RP; m <<= 1) s += shfl_xor_f64(s, m);
+        const int k = cg + CG * j;
+        if (rp == 0 && k < K) part[(i64)blockIdx.x * K + k] = s;
+    }
+    ss = block_sum<NW>(ss, sred);
+    if (tid == 0) sspart[blockIdx.x] = ss;
+}
+
 // rc: 0 = launched, 1 = shape/alignment not covered (caller falls back to the one-product
-// kernels), <0 = launch error.
+// kernels), <0 = launch error.  grid_hint: 0 = auto.
 template <typename T>
-int launch_fused_pass(hipStream_t, int /*num_cu*/, const T * /*X*/, i64 /*ldx*/, T * /*dst*/,
-                      i64 /*ldd*/, i64 /*N*/, int /*K*/, const double * /*v*/, const T * /*tprev*/,
-                      const double * /*pprev*/, T * /*tout*/, double * /*part*/, int /*max_rows*/,
-                      double * /*sspart*/, int * /*nb*/, int * /*nss*/) {
-    return 1;
+int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, T *dst, i64 ldd, i64 N,
+                      int K, const double *v, const T *tprev, const double *pprev, T *tout,
+                      double *part, int max_rows, double *sspart, int *nb, int *nss, int grid_hint) {
+    constexpr int V = 16 / sizeof(T);
+    constexpr int R = 32, NT = 512;
+    constexpr int CG = NT / (R / V);
+    const bool defl = (tprev != nullptr);
+    auto al = [](const void *p, i64 ld) { return ((uintptr_t)p % 16 == 0) && (ld % V == 0); };
+    if (!al(X, ldx) || !al(tout, V) || (defl && (!al(dst, ldd) || !al(tprev, V)))) return 1;
+    if (K > CG * 32 || N < 1 || N % V != 0) return 1;
+    // a column group's byte span (its num_records, and every lane offset) must stay below 2^31
+    if ((i64)CG * ldx * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    const i64 ntiles = (N + R - 1) / R;
+    i64 grid = grid_hint > 0 ? grid_hint : 8 * (i64)num_cu;
+    grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows);
+    if (grid < 1) return 1;
+    const dim3 g((unsigned)grid), b(NT);
+#define FUSED_CASE(CPT_)                                                                          \
+    do {                                                                                          \
+        if (defl)                                                                                 \
+            hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, true>), g, b, 0, stream, X,  \
+                               ldx, dst, ldd, N, K, v, tprev, pprev, tout, part, sspart);         \
+        else                                                                                      \
+            hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, false>), g, b, 0, stream, X, \
+                               ldx, dst, ldd, N, K, v, tprev, pprev, tout, part, sspart);         \
+    } while (0)
+    if (K <= CG * 4) FUSED_CASE(4);
+    else if (K <= CG * 8) FUSED_CASE(8);
+    else if (K <= CG * 16) FUSED_CASE(16);
+    else FUSED_CASE(32);
+#undef FUSED_CASE
+    *nb = (int)grid;
+    *nss = (int)grid;
+    return 0;
 }
 
 }  // namespace plsk

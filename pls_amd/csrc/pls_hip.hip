@@ -43,6 +43,7 @@ struct pls_hip_context {
     double *user_red = nullptr;
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
+    i64 opt_fused_grid = 0;
     DevBuf part, sspart, red, xy, v, tab, work, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
@@ -165,7 +166,7 @@ i64 max_partial_rows(pls_hip_context *c, i64 N, int K) {
     const int nkg32 = (K + XTY_KCMT - 1) / XTY_KCMT;
     const i64 nch = (N + plsk::WG - 1) / plsk::WG;  // vec = 1 is the worst case
     const i64 G = std::min<i64>(std::max<i64>(1, (8 * c->num_cu) / nkg32), std::max<i64>(nch, 1));
-    return std::max<i64>(G, 4 * (i64)c->num_cu);
+    return std::max<i64>(G, std::max<i64>(8 * (i64)c->num_cu, c->opt_fused_grid));
 }
 
 // ---- typed launchers --------------------------------------------------------------------
@@ -273,10 +274,9 @@ int launch_deflate(pls_hip_context *c, const T *src, i64 lds, T *dst, i64 ldd, i
 
 int launch_reduce(pls_hip_context *c, const double *part, int nb, int L, const double *sspart,
                   int nss, double *red) {
-    Scope s(c, PLS_HIP_FAM_SMALL, ((i64)nb * L + nss + L) * 8);
-    const int nblk = (L + 63) / 64 + (nss > 0 ? 1 : 0);
-    hipLaunchKernelGGL(plsk::reduce_partials_kernel, dim3(nblk), dim3(plsk::WG), 0, c->stream, part,
-                       nb, L, sspart, nss, red);
+    Scope s(c, PLS_HIP_FAM_SMALL, ((i64)nb * L + nss + (i64)plsk::RED_SLICES * (L + 1)) * 8);
+    hipLaunchKernelGGL(plsk::reduce_partials_kernel, dim3((L + 63) / 64, plsk::RED_SLICES),
+                       dim3(plsk::WG), 0, c->stream, part, nb, L, sspart, nss, red);
     LAUNCH_CHECK(c);
     return PLS_HIP_OK;
 }
@@ -304,7 +304,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                int A, double *W, double *P, double *Q, double *R, T *Tm, i64 ldt, double *B) {
     const bool nipals = (c->opt_algo == PLS_HIP_ALGO_NIPALS);
     const i64 L0 = (i64)K * M;
-    const i64 redn = std::max<i64>(L0, K + 1);
+    const i64 redn = (i64)plsk::RED_SLICES * std::max<i64>(L0, K + 1);
     const i64 prow = max_partial_rows(c, N, K);
     CHK(ensure(c, c->part, (size_t)prow * (size_t)std::max<i64>(L0, K) * 8));
     const i64 ssmax = std::max<i64>((N + plsk::WG - 1) / plsk::WG, 1);
@@ -330,9 +330,9 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         CHK(launch_xty<T>(c, X, ldx, Y, ldy, N, K, M, part, &nb));
         CHK(launch_reduce(c, part, nb, (int)L0, nullptr, 0, red));
     } else {
-        HIPCHK(c, hipMemsetAsync(red, 0, (size_t)L0 * 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(red, 0, (size_t)plsk::RED_SLICES * L0 * 8, c->stream));
     }
-    CHK(do_allreduce(c, red, L0));
+    CHK(do_allreduce(c, red, (i64)plsk::RED_SLICES * L0));
     CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, -1));
 
     const T *Xc = X;
@@ -352,7 +352,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     Scope s(c, PLS_HIP_FAM_FUSED, bytes);
                     rc = plsk::launch_fused_pass<T>(c->stream, c->num_cu, Xc, ldc, tprev ? work : nullptr,
                                                     N, N, K, v, tprev, pprev, Tm + (i64)a * ldt, part,
-                                                    (int)prow, sspart, &nb, &nss);
+                                                    (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid);
                     if (rc != 0) s.on = false;  // nothing was launched: drop the event pair
                 }
                 if (rc == 0) {
@@ -377,9 +377,9 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
             }
         } else {
-            HIPCHK(c, hipMemsetAsync(red, 0, (size_t)(K + 1) * 8, c->stream));
+            HIPCHK(c, hipMemsetAsync(red, 0, (size_t)plsk::RED_SLICES * (K + 1) * 8, c->stream));
         }
-        CHK(do_allreduce(c, red, K + 1));
+        CHK(do_allreduce(c, red, (i64)plsk::RED_SLICES * (K + 1)));
         CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a));  // :427-433 and :403-416 of a+1
     }
     if (B) {
@@ -495,6 +495,10 @@ int pls_hip_set_option(pls_hip_handle h, int option, int64_t value) {
             if (value < 1 || value > 4096) return fail(h, PLS_HIP_ERR_INVALID, "power iters out of range");
             h->opt_power_iters = value;
             return PLS_HIP_OK;
+        case PLS_HIP_OPT_FUSED_GRID:
+            if (value < 0 || value > (1 << 20)) return fail(h, PLS_HIP_ERR_INVALID, "fused grid out of range");
+            h->opt_fused_grid = value;
+            return PLS_HIP_OK;
         default: return fail(h, PLS_HIP_ERR_INVALID, "unknown option");
     }
 }
@@ -507,6 +511,7 @@ int pls_hip_get_option(pls_hip_handle h, int option, int64_t *value) {
         case PLS_HIP_OPT_FUSE: *value = h->opt_fuse; return PLS_HIP_OK;
         case PLS_HIP_OPT_PROFILE: *value = h->opt_profile; return PLS_HIP_OK;
         case PLS_HIP_OPT_POWER_ITERS: *value = h->opt_power_iters; return PLS_HIP_OK;
+        case PLS_HIP_OPT_FUSED_GRID: *value = h->opt_fused_grid; return PLS_HIP_OK;
         default: return fail(h, PLS_HIP_ERR_INVALID, "unknown option");
     }
 }
@@ -710,7 +715,13 @@ int pls_hip_xty(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
         CHK(launch_xty<double>(h, (const double *)X, ldx, (const double *)Y, ldy, N, (int)K, (int)M, (double *)h->part.p, &nb));
     else
         CHK(launch_xty<float>(h, (const float *)X, ldx, (const float *)Y, ldy, N, (int)K, (int)M, (double *)h->part.p, &nb));
-    return launch_reduce(h, (const double *)h->part.p, nb, (int)(K * M), nullptr, 0, XY);
+    CHK(ensure(h, h->red, (size_t)plsk::RED_SLICES * (size_t)(K * M) * 8));
+    CHK(launch_reduce(h, (const double *)h->part.p, nb, (int)(K * M), nullptr, 0, (double *)h->red.p));
+    const int nblk = (int)((K * M + plsk::WG - 1) / plsk::WG);
+    hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3(nblk), dim3(plsk::WG), 0, h->stream,
+                       (const double *)h->red.p, (int)(K * M), XY);
+    LAUNCH_CHECK(h);
+    return PLS_HIP_OK;
 }
 
 int pls_hip_deflate(pls_hip_handle h, const void *src, int64_t lds, void *dst, int64_t ldd, int64_t N,

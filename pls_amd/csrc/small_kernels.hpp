@@ -4,8 +4,17 @@
 // inputs (the all-reduced partials) and therefore derives bit-identical w, r, p, q.
 #pragma once
 #include "common.hpp"
+#include "stream_kernels.hpp"  // RED_SLICES
 
 namespace plsk {
+
+// fixed-order sum of the RED_SLICES slices of reduced value j (slice stride LP)
+__device__ __forceinline__ double red_sum(const double *red, int LP, int j) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < RED_SLICES; ++i) s += red[(i64)i * LP + j];
+    return s;
+}
 
 constexpr int UPD_THREADS = 1024;
 constexpr int UPD_WAVES = UPD_THREADS / WAVE;
@@ -70,6 +79,7 @@ __device__ inline void dominant_eigvec_lds(double *G, double *Bm, double *Cm, do
 }
 
 // a = index of the component whose pass just finished (-1: prologue, red holds X^T Y).
+// red is the RED_SLICES-sliced output of reduce_partials_kernel (summed over ranks when sharded).
 //   a >= 0 : red = [X^T t (K), t^T t];  p = red/tt (:427) -> P[:,a];  q = XY^T r_a / tt (:428)
 //            -> Q[:,a];  XY -= (p q^T) tt (:429).
 //   then, when a+1 < A: w from XY (:403-411) -> W[:,a+1];  r (:412-416) -> R[:,a+1];
@@ -86,9 +96,9 @@ __global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     if (a < 0) {
-        for (int j = tid; j < K * M; j += UPD_THREADS) XY[j] = red[j];
+        for (int j = tid; j < K * M; j += UPD_THREADS) XY[j] = red_sum(red, K * M, j);
     } else {
-        const double tt = red[K];
+        const double tt = red_sum(red, K + 1, K);
         const double *ra = R + (i64)a * K;
         for (int m = wv; m < M; m += UPD_WAVES) {  // q_m = (r^T XY[:,m]) / tt
             double s = 0.0;
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
         }
         __syncthreads();
         for (int k = tid; k < K; k += UPD_THREADS) {
-            const double p = red[k] / tt;
+            const double p = red_sum(red, K + 1, k) / tt;
             P[k + (i64)a * K] = p;
             for (int m = 0; m < M; ++m) XY[k + (i64)m * K] -= (p * qs[m]) * tt;
         }
@@ -158,6 +168,13 @@ __global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
         rn[k] = r;
         vnext[k] = nipals ? w : r;
     }
+}
+
+// out[j] = sum of the RED_SLICES slices (stand-alone X^T Y entry point)
+__global__ __launch_bounds__(WG) void sum_slices_kernel(const double *__restrict__ red, int L,
+                                                        double *__restrict__ out) {
+    const int j = blockIdx.x * WG + threadIdx.x;
+    if (j < L) out[j] = red_sum(red, L, j);
 }
 
 // B[k + m*K] = sum_{j<c} R[k + j*K] * Q[m + j*M]     Model::coefficients, src/pls.cpp:444-447

@@ -246,30 +246,45 @@ __global__ __launch_bounds__(WG) void deflate_kernel(const T *__restrict__ src, 
 }
 
 // ------------------------------------------------------------------------------------
-// red[j] = sum_b part[b*L + j]  (j < L), and red[L] = sum_b sspart[b] when nss > 0.
-// grid = ceil(L/64) + (nss > 0); 256 threads = 64 columns x 4 row-slices, fixed order.
+// Fixed-order sum of per-workgroup partials, in RED_SLICES independent slices so that enough
+// workgroups take part:   red[s*LP + j] = sum_{b in slice s} part[b*L + j]   (j < L),
+// and, when nss > 0,      red[s*LP + L] = sum_{b in slice s of nss} sspart[b]     (LP = L+1).
+// With nss == 0, LP = L.  The consumer (component_update_kernel, after the all-reduce of the
+// whole RED_SLICES*LP buffer in a sharded fit) adds the slices in index order.
+// grid = (ceil(L/64), RED_SLICES); 256 threads = 64 columns x 4 interleaved sub-slices.
 // ------------------------------------------------------------------------------------
+constexpr int RED_SLICES = 8;
+
 __global__ __launch_bounds__(WG) void reduce_partials_kernel(const double *__restrict__ part,
                                                              int nb, int L,
                                                              const double *__restrict__ sspart,
                                                              int nss, double *__restrict__ red) {
     __shared__ double sm[4][64];
     __shared__ double sm1[WG / WAVE];
-    const int nblk = (L + 63) / 64;
-    if ((int)blockIdx.x < nblk) {
-        const int jl = threadIdx.x & 63, s = threadIdx.x >> 6;
-        const int j = blockIdx.x * 64 + jl;
-        double a = 0.0;
-        if (j < L)
-            for (int b = s; b < nb; b += 4) a += part[(i64)b * L + j];
-        sm[s][jl] = a;
-        __syncthreads();
-        if (s == 0 && j < L) red[j] = (sm[0][jl] + sm[1][jl]) + (sm[2][jl] + sm[3][jl]);
-    } else {
-        double a = 0.0;
-        for (int b = threadIdx.x; b < nss; b += WG) a += sspart[b];
-        a = block_sum<WG / WAVE>(a, sm1);
-        if (threadIdx.x == 0) red[L] = a;
+    const int LP = L + (nss > 0 ? 1 : 0);
+    const int sl = blockIdx.y;
+    const int jl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
+    const int lo = (int)((i64)nb * sl / RED_SLICES), hi = (int)((i64)nb * (sl + 1) / RED_SLICES);
+    double a = 0.0;
+    if (j < L) {
+        int b = lo + q;
+        for (; b + 12 < hi; b += 16) {  // 4 independent loads in flight per lane
+            const double x0 = part[(i64)b * L + j], x1 = part[(i64)(b + 4) * L + j];
+            const double x2 = part[(i64)(b + 8) * L + j], x3 = part[(i64)(b + 12) * L + j];
+            a += x0; a += x1; a += x2; a += x3;
+        }
+        for (; b < hi; b += 4) a += part[(i64)b * L + j];
+    }
+    sm[q][jl] = a;
+    __syncthreads();
+    if (q == 0 && j < L) red[(i64)sl * LP + j] = (sm[0][jl] + sm[1][jl]) + (sm[2][jl] + sm[3][jl]);
+    if (nss > 0 && blockIdx.x == 0) {
+        const int slo = (int)((i64)nss * sl / RED_SLICES), shi = (int)((i64)nss * (sl + 1) / RED_SLICES);
+        double s = 0.0;
+        for (int b = slo + threadIdx.x; b < shi; b += WG) s += sspart[b];
+        s = block_sum<WG / WAVE>(s, sm1);
+        if (threadIdx.x == 0) red[(i64)sl * LP + L] = s;
     }
 }
 

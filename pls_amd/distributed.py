@@ -2,7 +2,8 @@
 
 One process per GPU.  Rank r owns a contiguous block of rows of X and Y; every O(N*K) product
 is a sum over rows, so the only exchange is an all-reduce of the K x M partial of X^T Y (once)
-and of the packed (K+1)-vector [X^T t, t^T t] (once per component).  Those messages are a few KB:
+and of the packed (K+1)-vector [X^T t, t^T t] (once per component), each as 8 fixed-order slices.
+Those messages are a few tens of KB:
 latency-bound, so they go through torch.distributed's all_reduce (RCCL over xGMI with the "nccl"
 backend) on a buffer this module allocates and hands to the library, stream-ordered with the
 library's kernels -- no host synchronisation inside the A-loop on the nccl path.
@@ -36,7 +37,7 @@ def attach_reducer(handle, K: int, M: int, group=None):
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    count = max(K * M, K + 1)
+    count = L.REDUCE_SLICES * max(K * M, K + 1)
     dev = torch.device("cuda", handle.device)
     stage = torch.zeros(count, dtype=torch.float64, device=dev)
     backend = dist.get_backend(group)
