@@ -27,6 +27,29 @@ __device__ __forceinline__ void st_pack(T *p, const Pack<T, V> &x) {
     *reinterpret_cast<Pack<T, V> *>(p) = x;
 }
 
+// Streaming (nt) forms for the big matrix: X is touched once per pass and never fits a cache, so
+// its traffic should not evict the vectors that ARE reused (scores, partial sums).
+template <typename T, int V>
+struct NtVec { typedef T type __attribute__((ext_vector_type(V))); };
+template <typename T>
+struct NtVec<T, 1> { typedef T type; };
+
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> ld_pack_nt(const T *p) {
+    typedef typename NtVec<T, V>::type VT;
+    const VT r = __builtin_nontemporal_load(reinterpret_cast<const VT *>(p));
+    Pack<T, V> o;
+    __builtin_memcpy(&o, &r, sizeof(o));
+    return o;
+}
+template <typename T, int V>
+__device__ __forceinline__ void st_pack_nt(T *p, const Pack<T, V> &x) {
+    typedef typename NtVec<T, V>::type VT;
+    VT r;
+    __builtin_memcpy(&r, &x, sizeof(r));
+    __builtin_nontemporal_store(r, reinterpret_cast<VT *>(p));
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double x, int mask) {
     int lo = __double2loint(x), hi = __double2hiint(x);
     lo = __shfl_xor(lo, mask, WAVE);

@@ -33,26 +33,33 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // returns 0 and an out-of-range store is dropped, which is how the ragged edges are handled.
 constexpr int BUF_WORD3 = 0x00020000;
 
-template <typename T, int V>
+// AUX: cache-policy bits of the buffer instruction (gfx94x/gfx950: bit0 sc0, bit1 nt, bit4 sc1)
+template <typename T, int V, int AUX = 0>
 __device__ __forceinline__ Pack<T, V> buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
     static_assert(sizeof(Pack<T, V>) == 16, "16-byte accesses");
-    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, AUX);
     Pack<T, V> p;
     __builtin_memcpy(&p, &raw, 16);
     return p;
 }
-template <typename T, int V>
+template <typename T, int V, int AUX = 0>
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, const Pack<T, V> &p) {
     u32x4 raw;
     __builtin_memcpy(&raw, &p, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(raw, r, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(raw, r, voff, 0, AUX);
 }
 
 // Addressing: every access of a tile is (wave-uniform descriptor for the column group) +
 // (per-lane 32-bit byte offset that never changes): the descriptor base X + tile*R + j*CG*ld
 // lives in SGPRs, the lane offset (rp*V + cg*ld)*s in ONE VGPR, so the CPT loads in flight cost
 // no address registers.  Lanes whose rows lie beyond N use an offset past num_records.
-template <typename T, int V, int R, int NT, int CPT, bool DEFL>
+// X is streamed exactly once per pass and is far larger than the 256 MiB Infinity Cache: its
+// loads and stores carry the nt (streaming) policy so they do not evict the small reused vectors
+// (scores, partials).  Measured on config 3: read-only pass 0.80 -> 0.71 ms (6.05 TB/s),
+// read+write pass 1.81 -> 1.70 ms (profiles/r1/tune_fused_cache_policy.txt).
+constexpr int AUX_NT = 2;
+
+template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX = AUX_NT, int STAUX = AUX_NT>
 __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pass_kernel(
     const T *X, i64 ldx, T *dst, i64 ldd, i64 N, int K,  // dst may alias X (in-place deflation)
     const double *__restrict__ v, const T *__restrict__ tprev, const double *__restrict__ pprev,
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
             const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldx * (i64)sizeof(T)) : 0u;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<T *>(X + tile * R + (i64)j * CG * ldx), (short)0, (int)nrec, BUF_WORD3);
-            x[j] = buf_ld<T, V>(rs, xo);
+            x[j] = buf_ld<T, V, LDAUX>(rs, xo);
             __builtin_amdgcn_sched_barrier(0);  // build one descriptor, issue its load, repeat
         }
         if (DEFL) {
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
                 const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldd * (i64)sizeof(T)) : 0u;
                 const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
                     dst + tile * R + (i64)j * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
-                buf_st<T, V>(rd, dof, x[j]);
+                buf_st<T, V, STAUX>(rd, dof, x[j]);
             }
         }
         // score: partial over this lane's columns, then over the lanes / waves sharing the rows
@@ -178,6 +185,76 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
     if (tid == 0) sspart[blockIdx.x] = ss;
 }
 
+// Stand-alone rank-1 deflation dst = src - t p^T in the same tile access pattern (256-byte column
+// segments, descriptor + one lane offset, nt policy), no reductions and no barriers.  Any K: a
+// workgroup walks the column groups of its tile CPT at a time.
+template <typename T, int V, int R, int NT, int CPT>
+__global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_tile_kernel(
+    const T *src, i64 lds_, T *dst, i64 ldd, i64 N, int K, const T *__restrict__ t,
+    const double *__restrict__ p) {
+    constexpr int RP = R / V, CG = NT / RP;
+    const int rp = threadIdx.x % RP, cg = threadIdx.x / RP;
+    const uint32_t soff = (uint32_t)(((i64)rp * V + (i64)cg * lds_) * (i64)sizeof(T));
+    const uint32_t doff = (uint32_t)(((i64)rp * V + (i64)cg * ldd) * (i64)sizeof(T));
+    constexpr uint32_t OOR = 0x80000000u;
+    const int ngroups = (K + CG - 1) / CG;
+    for (i64 tile = blockIdx.x; tile * R < N; tile += gridDim.x) {
+        const i64 i0 = tile * R + (i64)rp * V;
+        const bool rowok = (i0 < N);
+        const uint32_t so = rowok ? soff : OOR, dof = rowok ? doff : OOR;
+        double tp[V];
+        if (rowok) {
+            const Pack<T, V> tpk = ld_pack<T, V>(t + i0);
+#pragma unroll
+            for (int e = 0; e < V; ++e) tp[e] = -(double)tpk.v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) tp[e] = 0.0;
+        }
+        for (int g0 = 0; g0 < ngroups; g0 += CPT) {
+            Pack<T, V> x[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int cols = min(CG, K - CG * (g0 + j));
+                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * lds_ * (i64)sizeof(T)) : 0u;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<T *>(src + tile * R + (i64)(g0 + j) * CG * lds_), (short)0, (int)nrec, BUF_WORD3);
+                x[j] = buf_ld<T, V, AUX_NT>(rs, so);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int k = cg + CG * (g0 + j);
+                const double pk = (k < K) ? p[k] : 0.0;
+#pragma unroll
+                for (int e = 0; e < V; ++e) x[j].v[e] = (T)fma(tp[e], pk, (double)x[j].v[e]);
+                const int cols = min(CG, K - CG * (g0 + j));
+                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldd * (i64)sizeof(T)) : 0u;
+                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+                    dst + tile * R + (i64)(g0 + j) * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
+                buf_st<T, V, AUX_NT>(rd, dof, x[j]);
+            }
+        }
+    }
+}
+
+// rc as launch_fused_pass
+template <typename T>
+int launch_deflate_tile(hipStream_t stream, int num_cu, const T *src, i64 lds_, T *dst, i64 ldd, i64 N,
+                        int K, const T *t, const double *p) {
+    constexpr int V = 16 / sizeof(T);
+    constexpr int R = 32, NT = 512, CPT = 8;
+    constexpr int CG = NT / (R / V);
+    auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
+    if (!al(src, lds_) || !al(dst, ldd) || !al(t, V) || N < 1 || N % V != 0) return 1;
+    if ((i64)CG * lds_ * (i64)sizeof(T) >= (1ll << 31) || (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    const i64 ntiles = (N + R - 1) / R;
+    const i64 grid = std::min<i64>(ntiles, 2 * (i64)num_cu);
+    hipLaunchKernelGGL((deflate_tile_kernel<T, V, R, NT, CPT>), dim3((unsigned)grid), dim3(NT), 0, stream, src,
+                       lds_, dst, ldd, N, K, t, p);
+    return 0;
+}
+
 // rc: 0 = launched, 1 = shape/alignment not covered (caller falls back to the one-product
 // kernels), <0 = launch error.  grid_hint: 0 = auto.
 template <typename T>
@@ -195,7 +272,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, T *ds
     if ((i64)CG * ldx * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     const i64 ntiles = (N + R - 1) / R;
-    i64 grid = grid_hint > 0 ? grid_hint : 8 * (i64)num_cu;
+    i64 grid = grid_hint > 0 ? grid_hint : 2 * (i64)num_cu;  // two resident 512-thread workgroups per CU
     grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows);
     if (grid < 1) return 1;
     const dim3 g((unsigned)grid), b(NT);

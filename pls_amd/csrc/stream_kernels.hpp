@@ -37,7 +37,7 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
         for (; k + U <= K; k += U) {
             Pack<T, VEC> x[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = ld_pack<T, VEC>(xp + (i64)(k + u) * ldx);
+            for (int u = 0; u < U; ++u) x[u] = ld_pack_nt<T, VEC>(xp + (i64)(k + u) * ldx);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
                 }
         }
         for (; k < K; ++k) {
-            Pack<T, VEC> x = ld_pack<T, VEC>(xp + (i64)k * ldx);
+            Pack<T, VEC> x = ld_pack_nt<T, VEC>(xp + (i64)k * ldx);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const double b = Bm[k + m * ldb];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(WG) void xty_kernel(const T *__restrict__ X, i64 ld
                 for (int kb = 0; kb < KC; kb += U) {
                     Pack<T, VEC> x[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) x[u] = ld_pack<T, VEC>(X + i0 + (i64)(k0 + kb + u) * ldx);
+                    for (int u = 0; u < U; ++u) x[u] = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + kb + u) * ldx);
 #pragma unroll
                     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(WG) void xty_kernel(const T *__restrict__ X, i64 ld
 #pragma unroll
                 for (int kc = 0; kc < KC; ++kc)
                     if (kc < kn) {
-                        Pack<T, VEC> x = ld_pack<T, VEC>(X + i0 + (i64)(k0 + kc) * ldx);
+                        Pack<T, VEC> x = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + kc) * ldx);
 #pragma unroll
                         for (int m = 0; m < MT; ++m)
                             if (m < mn)
@@ -213,22 +213,22 @@ __global__ __launch_bounds__(WG) void deflate_kernel(const T *__restrict__ src, 
                 for (int kb = 0; kb < KC; kb += U) {
                     Pack<T, VEC> x[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) x[u] = ld_pack<T, VEC>(src + i0 + (i64)(k0 + kb + u) * lds);
+                    for (int u = 0; u < U; ++u) x[u] = ld_pack_nt<T, VEC>(src + i0 + (i64)(k0 + kb + u) * lds);
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const double pk = p[k0 + kb + u];
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) x[u].v[v] = (T)fma(td[v], pk, (double)x[u].v[v]);
-                        st_pack<T, VEC>(dst + i0 + (i64)(k0 + kb + u) * ldd, x[u]);
+                        st_pack_nt<T, VEC>(dst + i0 + (i64)(k0 + kb + u) * ldd, x[u]);
                     }
                 }
             } else {
                 for (int kc = 0; kc < kn; ++kc) {
-                    Pack<T, VEC> x = ld_pack<T, VEC>(src + i0 + (i64)(k0 + kc) * lds);
+                    Pack<T, VEC> x = ld_pack_nt<T, VEC>(src + i0 + (i64)(k0 + kc) * lds);
                     const double pk = p[k0 + kc];
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) x.v[v] = (T)fma(td[v], pk, (double)x.v[v]);
-                    st_pack<T, VEC>(dst + i0 + (i64)(k0 + kc) * ldd, x);
+                    st_pack_nt<T, VEC>(dst + i0 + (i64)(k0 + kc) * ldd, x);
                 }
             }
         } else if (i0 < N) {
