@@ -50,6 +50,8 @@ def parse():
                     help="nipals: north-star sequence with the rank-1 deflation of X (headline); "
                          "kernel: the reference's own sequence, X read-only")
     ap.add_argument("--fuse", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (gloo: rehearsal with ranks sharing one GPU)")
     ap.add_argument("--no-alt", action="store_true", help="skip the alternative execution plans")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=1 << 20, help="rows of the CPU baseline sample (default: the whole workload, ~10 s on one core)")
@@ -72,7 +74,7 @@ def timed_fits(h, torch, dist, world, X, Y, A, steps, warmup, out):
         dist.barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     return el, h.timing()
@@ -130,9 +132,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    local = local if a.backend == "nccl" else local % max(ndev, 1)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     N, K, M, A, dt = WORKLOADS[a.workload]
     tdt = torch.float64 if dt == "f64" else torch.float32

@@ -1,6 +1,6 @@
 // Device generator of the synthetic benchmark inputs (spec: DESIGN.md "Synthetic inputs").
 // Counter-based, libm-free, exact in fp64 (24-bit dyadic uniforms times {0, +-1/2, +-1}), so the
-// device output is bit-identical to oracle/pls_oracle.c::oracle_synth_x/_y and to the numpy twin.
+// device output can be checked bit for bit against a host implementation of the same spec.
 //   X[i,k] = 1/4 * E(i,k) + sum_{f<8} z(i,f) * L(f,k)
 //   Y[i,j] = 2^-(j%16) * sum_{f<8} z(i,f) * C(f,j) + 1/8 * Nz(i,j)
 // i is the GLOBAL row index, so row shards of one matrix can be generated independently.

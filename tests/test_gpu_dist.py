@@ -1,0 +1,77 @@
+"""Row-sharded fit on the real HIP path: two (and three) ranks share the one GPU of the test box,
+each owning a row block, the small partial products summed through pls_amd.distributed's reducer
+(gloo here -- RCCL refuses two ranks on one device; the nccl branch of the same reducer is what
+bench.py uses on a multi-GPU node).  The sharded result must match the oracle's unsharded fit and be
+bit-identical across ranks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, N, K, M, A, algo, fuse, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import pls_amd
+    from pls_amd.distributed import attach_reducer, row_partition
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        h = pls_amd.Handle()
+        h.set_option(pls_amd.OPT_ALGO, algo)
+        h.set_option(pls_amd.OPT_FUSE, fuse)
+        row0, nrows = row_partition(N, world, rank)
+        X = h.synth_x(row0, nrows, K, pls_amd.SEED_DEFAULT)
+        Y = h.synth_y(row0, nrows, M, pls_amd.SEED_DEFAULT)
+        attach_reducer(h, K, M)
+        out = h.fit_device(X, Y, A)
+        h.synchronize()
+        q.put((rank, {k: v.cpu().numpy() for k, v in out.items()}))
+        h.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,K,M,A,world,algo,fuse", [
+    (4098, 64, 1, 6, 2, 0, 1), (4098, 64, 1, 6, 2, 1, 1), (3001, 40, 3, 5, 2, 1, 0), (2, 5, 1, 2, 3, 0, 1),
+    (65536, 512, 1, 4, 3, 1, 1)])
+def test_sharded_fit_matches_oracle(N, K, M, A, world, algo, fuse):
+    import torch.multiprocessing as mp
+    from oracle import pls_oracle as po
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, K, M, A, algo, fuse, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ora = po.OracleLib()
+    X = ora.synth_x(0, N, K); Y = ora.synth_y(0, N, M)
+    ref = ora.plsr(X, Y, A)
+    Bref = ora.coefficients(ref["R"], ref["Q"])
+    for rank, out in res:
+        assert po.rel_fro(out["B"], Bref) < 1e-10
+        for k in "WPQRB":  # every rank derives the same bits from the reduced partials
+            assert np.array_equal(out[k], res[0][1][k]), (rank, k)
+    T = np.concatenate([out["T"] for _, out in res], axis=0)
+    s = po.sign_align(ref["W"], res[0][1]["W"])
+    alt = ora.plsr(X, Y, A, nipals=True)
+    lim = np.maximum(1e-9, 20 * po.column_errors(ref, alt))
+    err = np.linalg.norm(T * s - ref["T"], axis=0) / np.linalg.norm(ref["T"], axis=0)
+    assert (err <= lim).all()
