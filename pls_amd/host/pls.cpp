@@ -1,0 +1,498 @@
+// pls.cpp -- host side of the MI355X-native PLS library: the drop-in for the reference's
+// src/pls.cpp.  Everything that touches N-sized data in the fit / predict path goes through
+// the C-ABI of pls_hip.h to the HIP kernels (there is no CPU implementation of that path here:
+// if the device or the library is missing, Model::plsr throws).  The remaining functions are the
+// reference's host utilities -- CSV reader, column statistics, validation statistics and the
+// cross-validation drivers that call the fit -- rewritten on plain loops over the column-major
+// matrix interface shared by Eigen and PLS/dense.h.
+//
+// Reference behaviour is cited as (ref :line) = tjhladish/PLS src/pls.cpp.
+#include <PLS/pls.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <mutex>
+#include <stdexcept>
+
+#include "pls_hip.h"
+
+namespace {
+
+typedef Eigen::Index Index;
+
+// One device context per process, created on first use; the library keeps its workspace in
+// it, so the O(N) refits of the cross-validation drivers reuse the same device buffers.
+std::mutex g_mu;
+pls_hip_handle g_handle = nullptr;
+
+pls_hip_handle device() {
+    if (!g_handle) {
+        int dev = 0;
+        if (const char *e = std::getenv("PLS_HIP_DEVICE")) dev = std::atoi(e);
+        const int rc = pls_hip_create(&g_handle, dev, nullptr);
+        if (rc != PLS_HIP_OK)
+            throw std::runtime_error("PLS: no usable MI355X (gfx950) device (pls_hip_create status " +
+                                     std::to_string(rc) + "); this library has no CPU path");
+        if (const char *e = std::getenv("PLS_HIP_ALGO"))  // "nipals": explicit X deflation
+            pls_hip_set_option(g_handle, PLS_HIP_OPT_ALGO,
+                               std::string(e) == "nipals" ? PLS_HIP_ALGO_NIPALS : PLS_HIP_ALGO_KERNEL);
+    }
+    return g_handle;
+}
+
+void check(int rc, const char *what) {
+    if (rc != PLS_HIP_OK)
+        throw std::runtime_error(std::string("PLS: ") + what + " failed: " + pls_hip_last_error(g_handle));
+}
+
+Row column_means(const Mat2D &mat) {
+    Row m(mat.cols());
+    for (Index j = 0; j < mat.cols(); ++j) {
+        float_type s = 0;
+        for (Index i = 0; i < mat.rows(); ++i) s += mat(i, j);
+        m[j] = s / static_cast<float_type>(mat.rows());
+    }
+    return m;
+}
+
+// real K x c (or N x c) block -> the API's complex container (imaginary parts are zero: the
+// reference only uses complex types because Eigen::EigenSolver returns them, ref :401-402)
+Mat2Dc to_complex(const std::vector<float_type> &re, Index rows, Index cols) {
+    Mat2Dc out(rows, cols);
+    for (Index j = 0; j < cols; ++j)
+        for (Index i = 0; i < rows; ++i) out(i, j) = std::complex<float_type>(re[static_cast<size_t>(i + j * rows)], 0);
+    return out;
+}
+
+std::vector<float_type> real_part(const Mat2Dc &m, Index cols) {
+    std::vector<float_type> re(static_cast<size_t>(m.rows() * cols));
+    for (Index j = 0; j < cols; ++j)
+        for (Index i = 0; i < m.rows(); ++i) re[static_cast<size_t>(i + j * m.rows())] = m(i, j).real();
+    return re;
+}
+
+}  // namespace
+
+namespace PLS {
+
+// ---------------------------------------------------------------------------------------------
+// text input (ref :23-67)
+// ---------------------------------------------------------------------------------------------
+std::vector<std::string> split(const std::string &s, const char separator) {
+    std::vector<std::string> fields;
+    size_t start = 0;
+    for (size_t pos = s.find(separator); pos != std::string::npos; pos = s.find(separator, start)) {
+        fields.push_back(s.substr(start, pos - start));
+        start = pos + 1;
+    }
+    fields.push_back(s.substr(start));  // the tail after the last separator (possibly empty)
+    return fields;
+}
+
+Mat2D read_matrix_file(const std::string &filename, const char separator) {
+    std::ifstream in(filename);
+    std::vector<std::vector<float_type> > rows;
+    std::string line;
+    while (in.is_open() && std::getline(in, line)) {
+        const std::vector<std::string> fields = split(line, separator);
+        std::vector<float_type> r(fields.size());
+        for (size_t i = 0; i < fields.size(); ++i) r[i] = std::stod(fields[i]);  // throws like the reference (ref :53)
+        if (!rows.empty() && rows[0].size() != r.size()) {
+            std::cerr << "Error: row " << rows.size() << " has " << r.size()
+                      << " columns, but previous row(s) have " << rows[0].size() << " columns." << std::endl;
+            std::exit(1);  // ref :54-58
+        }
+        rows.push_back(r);
+    }
+    if (rows.empty()) {  // the reference dereferences M[0] here (UB, ref :64); fail cleanly instead
+        std::cerr << "Error: could not read any rows from " << filename << std::endl;
+        std::exit(1);
+    }
+    Mat2D X(static_cast<Index>(rows.size()), static_cast<Index>(rows[0].size()));
+    for (Index i = 0; i < X.rows(); ++i)
+        for (Index j = 0; j < X.cols(); ++j) X(i, j) = rows[static_cast<size_t>(i)][static_cast<size_t>(j)];
+    return X;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column statistics (ref :69-111)
+// ---------------------------------------------------------------------------------------------
+Row SST(const Mat2D &mat, const Row &means) {
+    Row out = Row::Zero(mat.cols());
+    if (mat.rows() < 2) return out;  // ref :71
+    for (Index j = 0; j < mat.cols(); ++j) {
+        float_type s = 0;
+        for (Index i = 0; i < mat.rows(); ++i) {
+            const float_type d = mat(i, j) - means[j];
+            s += d * d;
+        }
+        out[j] = s;
+    }
+    return out;
+}
+
+Row SST(const Mat2D &mat) { return SST(mat, column_means(mat)); }
+
+Row colwise_stdev(const Mat2D &mat, const Row &means) {
+    Row out = SST(mat, means);
+    const float_type n1 = static_cast<float_type>(mat.rows()) - 1;  // unbiased: N-1 (ref :82)
+    for (Index j = 0; j < out.size(); ++j) out[j] = std::sqrt(out[j] / n1);
+    return out;
+}
+
+Row colwise_stdev(const Mat2D &mat) { return colwise_stdev(mat, column_means(mat)); }
+
+Row z_scores(const Row &obs, const Row &mean, const Row &stdev) {
+    Row out(obs.size());
+    for (Index j = 0; j < obs.size(); ++j) out[j] = (obs[j] - mean[j]) / stdev[j];
+    return out;
+}
+
+Mat2D colwise_z_scores(const Mat2D &mat, const Row &mean, const Row &stdev) {
+    // The reference prepares a zero-guarded copy of stdev but then divides by the unguarded
+    // one (ref :94-103), so a constant column comes out as NaN; kept, so that results match.
+    Mat2D zs(mat.rows(), mat.cols());
+    for (Index j = 0; j < mat.cols(); ++j)
+        for (Index i = 0; i < mat.rows(); ++i) zs(i, j) = (mat(i, j) - mean[j]) / stdev[j];
+    return zs;
+}
+
+Mat2D colwise_z_scores(const Mat2D &mat) {
+    const Row means = column_means(mat);
+    return colwise_z_scores(mat, means, colwise_stdev(mat, means));
+}
+
+// ---------------------------------------------------------------------------------------------
+// validation statistics (ref :144-305)
+// ---------------------------------------------------------------------------------------------
+// Abramowitz & Stegun 26.2.19 polynomial approximation of the normal CDF (ref :152-160)
+float_type normalcdf(const float_type z) {
+    const float_type a = std::fabs(z);
+    const float_type poly = 1 + 0.196854 * a + 0.115194 * a * a + 0.000344 * a * a * a + 0.019527 * a * a * a * a;
+    const float_type p = 0.5 / std::pow(poly, 4);
+    return z < 0 ? p : 1.0 - p;
+}
+
+// Wilcoxon signed-rank statistic on |err_1| - |err_2|, normal approximation (ref :190-211)
+float_type wilcoxon(const Col &err_1, const Col &err_2) {
+    const size_t n = static_cast<size_t>(err_1.size());
+    std::vector<float_type> mag(n);
+    std::vector<int> sign(n);
+    for (size_t i = 0; i < n; ++i) {
+        const float_type d = std::fabs(err_1[static_cast<Index>(i)]) - std::fabs(err_2[static_cast<Index>(i)]);
+        sign[i] = (0 < d) - (d < 0);
+        mag[i] = std::fabs(d);
+    }
+    const std::vector<size_t> order = ordered(mag);
+    float_type d = 0;
+    for (size_t rank = 0; rank < n; ++rank) d += static_cast<float_type>(rank + 1) * sign[order[rank]];
+    const float_type t = static_cast<float_type>(n * (n + 1)) / 2.0;
+    const float_type v = (t - d) / 2.0;
+    const float_type ev = t / 2.0;
+    const float_type sv = std::sqrt(static_cast<float_type>(n * (n + 1) * (2 * n + 1)) / 24.0);
+    return 1.0 - normalcdf((v - ev) / sv);
+}
+
+// shuffle `full`, then split it into the leading sample and the trailing complement (ref :218-227)
+void rand_nchoosek(std::mt19937 &rng, std::vector<Eigen::Index> &full, std::vector<Eigen::Index> &sample,
+                   std::vector<Eigen::Index> &complement) {
+    std::shuffle(full.begin(), full.end(), rng);
+    std::copy(full.begin(), full.begin() + static_cast<std::ptrdiff_t>(sample.size()), sample.begin());
+    std::copy(full.begin() + static_cast<std::ptrdiff_t>(sample.size()), full.end(), complement.begin());
+}
+
+// rows = Y variable, cols = number of components; RESS = sum of squared residuals, MSE = RESS/N
+Mat2D validation(const Residual &residual, const VALIDATION_OUTPUT out_type) {
+    const std::vector<Mat2D> errors = residual.errors();
+    if (errors.empty()) return Mat2D::Zero(0, 0);
+    Mat2D out = Mat2D::Zero(static_cast<Index>(errors.size()), errors[0].cols());
+    for (size_t y = 0; y < errors.size(); ++y)
+        for (Index c = 0; c < errors[y].cols(); ++c) {
+            float_type s = 0;
+            for (Index i = 0; i < errors[y].rows(); ++i) s += errors[y](i, c) * errors[y](i, c);
+            out(static_cast<Index>(y), c) = s;
+        }
+    if (out_type == MSE) {
+        const float_type n = static_cast<float_type>(errors[0].rows());
+        for (Index j = 0; j < out.cols(); ++j)
+            for (Index i = 0; i < out.rows(); ++i) out(i, j) /= n;
+    }
+    return out;
+}
+
+// per Y variable: the smallest number of components whose errors are not significantly worse
+// (Wilcoxon, ALPHA) than those at the PRESS minimum (ref :265-289)
+Colsz optimal_num_components(const Residual &residual, const float_type ALPHA) {
+    const std::vector<Mat2D> errors = residual.errors();
+    const Mat2D press = validation(residual, RESS);
+    Colsz best(press.rows());
+    for (size_t y = 0; y < errors.size(); ++y) {
+        size_t ref_min = 0;
+        for (Index c = 1; c < press.cols(); ++c)
+            if (press(static_cast<Index>(y), c) < press(static_cast<Index>(y), static_cast<Index>(ref_min)))
+                ref_min = static_cast<size_t>(c);
+        size_t pick = ref_min;
+        const Col err_ref = errors[y].col(static_cast<Index>(ref_min));
+        for (size_t alt = 0; alt < ref_min; ++alt) {
+            const Col err_alt = errors[y].col(static_cast<Index>(alt));
+            if (wilcoxon(err_ref, err_alt) > ALPHA) {
+                pick = alt;
+                break;
+            }
+        }
+        best[static_cast<Index>(y)] = pick + 1;  // component counts start at 1
+    }
+    return best;
+}
+
+void print_validation(const Residual &residual, const VALIDATION_OUTPUT out_type, std::ostream &os) {
+    os << residual.method() << " Validation:" << std::endl;
+    Mat2D em = validation(residual, out_type);
+    if (out_type == MSE) {
+        os << "RMSE ";
+        for (Index j = 0; j < em.cols(); ++j)
+            for (Index i = 0; i < em.rows(); ++i) em(i, j) = std::sqrt(em(i, j));
+    } else if (out_type == RESS) {
+        os << "PRESS ";
+    } else {
+        os << "UNKNOWN ";
+    }
+    os << " Matrix (rows = Y variable; cols = # of components):" << std::endl << em << std::endl;
+    os << "Optimal number of components (by Y variable):\t" << optimal_num_components(residual) << std::endl;
+}
+
+}  // namespace PLS
+
+using namespace PLS;
+
+// ---------------------------------------------------------------------------------------------
+// Model: constructors (ref :323-359)
+// ---------------------------------------------------------------------------------------------
+Model::Model(const size_t &num_predictors, const size_t &num_responses, const METHOD &algorithm,
+             const size_t &max_components)
+    : A(max_components), method(algorithm) {
+    if (max_components > num_predictors) throw std::invalid_argument("PLS::Model: max_components > predictors");
+    const Index K = static_cast<Index>(num_predictors), M = static_cast<Index>(num_responses);
+    P.setZero(K, static_cast<Index>(A));
+    W.setZero(K, static_cast<Index>(A));
+    R.setZero(K, static_cast<Index>(A));
+    Q.setZero(M, static_cast<Index>(A));
+}
+
+Model::Model(const size_t &num_predictors, const size_t &num_responses, const METHOD &algorithm)
+    : Model(num_predictors, num_responses, algorithm, num_predictors) {}
+
+Model::Model(const Mat2D &X, const Mat2D &Y, const METHOD &algorithm, const size_t &max_components)
+    : _X(X), _Y(Y), A(max_components), method(algorithm) {
+    // the reference only assert()s these (ref :345-347); a Release build would run into UB
+    if (max_components > static_cast<size_t>(_X.cols()) || _X.rows() == 0 || _X.rows() != _Y.rows())
+        throw std::invalid_argument("PLS::Model: need max_components <= X.cols(), X.rows() > 0, X.rows() == Y.rows()");
+    const Index K = _X.cols(), M = _Y.cols();
+    P.setZero(K, static_cast<Index>(A));
+    W.setZero(K, static_cast<Index>(A));
+    R.setZero(K, static_cast<Index>(A));
+    Q.setZero(M, static_cast<Index>(A));
+    plsr(_X, _Y, algorithm);
+}
+
+Model::Model(const Mat2D &X, const Mat2D &Y, const METHOD &algorithm)
+    : Model(X, Y, algorithm, static_cast<size_t>(X.cols())) {}
+
+// ---------------------------------------------------------------------------------------------
+// the fit (ref :390-437): one call into the device library
+// ---------------------------------------------------------------------------------------------
+void Model::plsr(const Mat2D &X, const Mat2D &Y, const METHOD &algorithm) {
+    method = algorithm;
+    const Index N = X.rows(), K = X.cols(), M = Y.cols();
+    const Index Ai = static_cast<Index>(A);
+    std::vector<float_type> w(static_cast<size_t>(K * Ai)), p(w.size()), r(w.size());
+    std::vector<float_type> q(static_cast<size_t>(M * Ai)), t(static_cast<size_t>(N * Ai));
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        check(pls_hip_fit(device(), X.data(), N, Y.data(), N, N, K, M, Ai,
+                          algorithm == KERNEL_TYPE1 ? PLS_HIP_KERNEL_TYPE1 : PLS_HIP_KERNEL_TYPE2, PLS_HIP_F64,
+                          PLS_HIP_MEM_HOST, w.data(), p.data(), q.data(), r.data(), t.data(), N, nullptr),
+              "pls_hip_fit");
+    }
+    W = to_complex(w, K, Ai);
+    P = to_complex(p, K, Ai);
+    R = to_complex(r, K, Ai);
+    Q = to_complex(q, M, Ai);
+    if (algorithm == KERNEL_TYPE1) T = to_complex(t, N, Ai);  // T exists for KERNEL_TYPE1 only (ref :394,434)
+}
+
+// ---------------------------------------------------------------------------------------------
+// predict and metrics (ref :439-467)
+// ---------------------------------------------------------------------------------------------
+const Mat2Dc Model::scores(const Mat2D &X_new, const size_t comp) const {
+    if (comp > A) throw std::invalid_argument("PLS::Model::scores: comp > A");  // assert in the reference (ref :440)
+    const Index N = X_new.rows(), K = X_new.cols(), c = static_cast<Index>(comp);
+    const std::vector<float_type> r = real_part(R, c);
+    std::vector<float_type> out(static_cast<size_t>(N * c));
+    if (N > 0 && c > 0) {
+        std::lock_guard<std::mutex> lock(g_mu);
+        check(pls_hip_xb(device(), X_new.data(), N, N, K, r.data(), K, c, PLS_HIP_F64, PLS_HIP_MEM_HOST, out.data(), N),
+              "pls_hip_xb");
+    }
+    return to_complex(out, N, c);
+}
+
+const Mat2Dc Model::loadingsX(const size_t comp) const { return P.leftCols(static_cast<Index>(comp)); }
+const Mat2Dc Model::loadingsY(const size_t comp) const { return Q.leftCols(static_cast<Index>(comp)); }
+
+const Mat2Dc Model::coefficients(const size_t comp) const {
+    if (comp > A) throw std::invalid_argument("PLS::Model::coefficients: comp > A");  // ref :445
+    const Index K = R.rows(), M = Q.rows(), Ai = static_cast<Index>(A);
+    const std::vector<float_type> r = real_part(R, Ai), q = real_part(Q, Ai);
+    std::vector<float_type> b(static_cast<size_t>(K * M));
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        check(pls_hip_coefficients(device(), r.data(), q.data(), K, M, Ai, static_cast<Index>(comp), PLS_HIP_MEM_HOST,
+                                   b.data()),
+              "pls_hip_coefficients");
+    }
+    return to_complex(b, K, M);
+}
+
+const Mat2D Model::fitted_values(const Mat2D &X_new, const size_t comp) const {
+    const Mat2Dc Bc = coefficients(comp);
+    const Index N = X_new.rows(), K = X_new.cols(), M = Bc.cols();
+    const std::vector<float_type> b = real_part(Bc, M);
+    Mat2D out(N, M);
+    if (N > 0) {
+        std::lock_guard<std::mutex> lock(g_mu);
+        check(pls_hip_xb(device(), X_new.data(), N, N, K, b.data(), K, M, PLS_HIP_F64, PLS_HIP_MEM_HOST, out.data(), N),
+              "pls_hip_xb");
+    }
+    return out;
+}
+
+const Mat2D Model::residuals(const Mat2D &X_new, const Mat2D &Y_new, const size_t comp) const {
+    Mat2D res = fitted_values(X_new, comp);
+    for (Index j = 0; j < res.cols(); ++j)
+        for (Index i = 0; i < res.rows(); ++i) res(i, j) = Y_new(i, j) - res(i, j);
+    return res;
+}
+
+const Row Model::SSE(const Mat2D &X_new, const Mat2D &Y_new, const size_t comp) const {
+    const Mat2D res = residuals(X_new, Y_new, comp);
+    Row out = Row::Zero(res.cols());
+    for (Index j = 0; j < res.cols(); ++j)
+        for (Index i = 0; i < res.rows(); ++i) out[j] += res(i, j) * res(i, j);
+    return out;
+}
+
+const Row Model::explained_variance(const Mat2D &X_new, const Mat2D &Y_new, const size_t comp) const {
+    const Row sse = SSE(X_new, Y_new, comp), sst = SST(Y_new);
+    Row out(sse.size());
+    for (Index j = 0; j < sse.size(); ++j) out[j] = 1.0 - sse[j] / sst[j];
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cross-validation drivers: callers of the fit (ref :469-549)
+//
+// Deliberate difference: the reference builds its inner models with A = X.cols() components
+// (the 3-argument constructors, ref :334-337, :356-359, used at :477 and :531) although only the
+// outer model's A are ever read (:479, :540).  Components are computed strictly in sequence, so the
+// first A are identical either way; the inner models here fit A components and skip the
+// K - A unused (and, for K > N, rank-deficient) ones.
+// ---------------------------------------------------------------------------------------------
+Residual Model::cv_LOO() const {
+    const Index N = _X.rows(), K = _X.cols(), M = _Y.cols();
+    Mat2D Xv(N - 1, K), Yv(N - 1, M);  // rows 1..N-1: row 0 is left out first
+    for (Index j = 0; j < K; ++j)
+        for (Index i = 1; i < N; ++i) Xv(i - 1, j) = _X(i, j);
+    for (Index j = 0; j < M; ++j)
+        for (Index i = 1; i < N; ++i) Yv(i - 1, j) = _Y(i, j);
+    std::vector<Mat2D> Ev(static_cast<size_t>(M), Mat2D::Zero(N, static_cast<Index>(A)));
+
+    Model fold(Xv, Yv, method, A);
+    for (Index out = 0; out < N; ++out) {
+        Mat2D x1(1, K), y1(1, M);
+        for (Index j = 0; j < K; ++j) x1(0, j) = _X(out, j);
+        for (Index j = 0; j < M; ++j) y1(0, j) = _Y(out, j);
+        for (size_t nc = 1; nc <= A; ++nc) {
+            const Mat2D res = fold.residuals(x1, y1, nc);
+            for (Index m = 0; m < M; ++m) Ev[static_cast<size_t>(m)](out, static_cast<Index>(nc - 1)) = res(0, m);
+        }
+        if (out < N - 1) {  // put this row back in place of the next one to be left out, refit
+            for (Index j = 0; j < K; ++j) Xv(out, j) = _X(out, j);
+            for (Index j = 0; j < M; ++j) Yv(out, j) = _Y(out, j);
+            fold.plsr(Xv, Yv, method);
+        }
+    }
+    return Residual(Ev, "LOO");
+}
+
+Residual Model::cv_NEW_DATA(const Mat2D &X_new, const Mat2D &Y_new) const {
+    if (X_new.cols() != _X.cols() || Y_new.cols() != _Y.cols())
+        throw std::invalid_argument("PLS::Model::cv_NEW_DATA: column counts differ from the training data");
+    std::vector<Mat2D> Ev(static_cast<size_t>(Y_new.cols()), Mat2D::Zero(X_new.rows(), static_cast<Index>(A)));
+    for (size_t nc = 1; nc <= A; ++nc) {
+        const Mat2D res = residuals(X_new, Y_new, nc);
+        for (Index m = 0; m < res.cols(); ++m)
+            for (Index i = 0; i < res.rows(); ++i) Ev[static_cast<size_t>(m)](i, static_cast<Index>(nc - 1)) = res(i, m);
+    }
+    return Residual(Ev, "NEW DATA");
+}
+
+Residual Model::cv_LSO(const float_type test_fraction, const size_t num_trials, std::mt19937 &rng) const {
+    const size_t N = static_cast<size_t>(_X.rows());
+    const size_t test_size = static_cast<size_t>(test_fraction * N + 0.5);
+    const size_t train_size = N - test_size;
+    if (test_size == 0 || train_size == 0) throw std::invalid_argument("PLS::Model::cv_LSO: empty train or test split");
+    const Index K = _X.cols(), M = _Y.cols();
+
+    std::vector<Mat2D> Ev(static_cast<size_t>(M),
+                          Mat2D::Zero(static_cast<Index>(num_trials * test_size), static_cast<Index>(A)));
+    std::vector<Eigen::Index> sample(train_size), complement(test_size), full(N);
+    std::iota(full.begin(), full.end(), Eigen::Index(0));
+
+    Mat2D Xv(static_cast<Index>(train_size), K), Yv(static_cast<Index>(train_size), M);
+    Mat2D Xp(static_cast<Index>(test_size), K), Yp(static_cast<Index>(test_size), M);
+    Model fold(static_cast<size_t>(K), static_cast<size_t>(M), method, A);
+
+    for (size_t rep = 0; rep < num_trials; ++rep) {
+        rand_nchoosek(rng, full, sample, complement);
+        for (Index j = 0; j < K; ++j) {
+            for (size_t i = 0; i < train_size; ++i) Xv(static_cast<Index>(i), j) = _X(sample[i], j);
+            for (size_t i = 0; i < test_size; ++i) Xp(static_cast<Index>(i), j) = _X(complement[i], j);
+        }
+        for (Index j = 0; j < M; ++j) {
+            for (size_t i = 0; i < train_size; ++i) Yv(static_cast<Index>(i), j) = _Y(sample[i], j);
+            for (size_t i = 0; i < test_size; ++i) Yp(static_cast<Index>(i), j) = _Y(complement[i], j);
+        }
+        fold.plsr(Xv, Yv, method);
+        for (size_t nc = 1; nc <= A; ++nc) {
+            const Mat2D res = fold.residuals(Xp, Yp, nc);
+            for (Index m = 0; m < M; ++m)
+                for (size_t i = 0; i < test_size; ++i)
+                    Ev[static_cast<size_t>(m)](static_cast<Index>(rep * test_size + i), static_cast<Index>(nc - 1)) +=
+                        res(static_cast<Index>(i), m);
+        }
+    }
+    return Residual(Ev, "LSO");
+}
+
+// ---------------------------------------------------------------------------------------------
+// text output (ref :551-580)
+// ---------------------------------------------------------------------------------------------
+void Model::print_explained_variance(const Mat2D &X, const Mat2D &Y, std::ostream &os) const {
+    const int wd = static_cast<int>(std::ceil(std::log10(static_cast<double>(A))));
+    for (size_t nc = 1; nc <= A; ++nc) {
+        os << std::setw(wd) << nc << " components explained variance: " << explained_variance(X, Y, nc);
+        os << "  - SSE: " << SSE(X, Y, nc) << std::endl;
+    }
+}
+
+void Model::print_state(std::ostream &os) const {
+    os << "P:" << std::endl << P << std::endl;
+    os << "W:" << std::endl << W << std::endl;
+    os << "R:" << std::endl << R << std::endl;
+    os << "Q:" << std::endl << Q << std::endl;
+    os << "T:" << std::endl << T << std::endl;
+    os << "coefficients:" << std::endl << coefficients() << std::endl;
+}
