@@ -80,6 +80,24 @@ def timed_fits(h, torch, dist, world, X, Y, A, steps, warmup, out):
     return el, h.timing()
 
 
+def pmc_traffic(workload, algo, fuse, family):
+    """HBM bytes per launch of `family` from the committed rocprofv3 PMC summary of this configuration
+    (profiles/rNN/pmc_traffic_<workload>_<algo>_<fused|unfused>.json, written by
+    tools/summarize_pmc.py from separate FETCH_SIZE / WRITE_SIZE passes); None if there is none."""
+    import glob
+    name = f"pmc_traffic_{workload}_{algo}_{'fused' if fuse else 'unfused'}.json"
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
+    if not cands:
+        return None, None
+    d = json.load(open(cands[-1]))
+    pref = {"fused": "fused_pass_kernel", "deflate": "deflate", "xb": "xb_kernel", "xty": "xty_kernel"}[family]
+    rows = [v for k, v in d.items() if k.startswith(pref)]
+    if not rows:
+        return None, None
+    n = sum(r["launches_fetch_pass"] for r in rows)
+    return int(sum(r["hbm_bytes_per_launch"] * r["launches_fetch_pass"] for r in rows) / n), os.path.relpath(cands[-1], ROOT)
+
+
 def roofline_of(tm):
     fams = [f for f in ("fused", "deflate", "xb", "xty") if tm["launches"][f] > 0]
     if not fams:
@@ -171,6 +189,10 @@ def main():
         "effective_gbs": round(2 * A * N * K * es / (el / a.steps) / 1e9, 1),
     }
 
+    if line["roofline"] is not None:
+        tr, src = pmc_traffic(a.workload, a.algo, a.fuse, line["roofline"]["kernel"])
+        line["roofline"]["traffic"] = tr
+        line["roofline"]["traffic_source"] = src
     if rank == 0 or world > 1:
         alt = {}
         if not a.no_alt and world == 1:
