@@ -243,7 +243,7 @@ template <typename T>
 int launch_deflate_tile(hipStream_t stream, int num_cu, const T *src, i64 lds_, T *dst, i64 ldd, i64 N,
                         int K, const T *t, const double *p) {
     constexpr int V = 16 / sizeof(T);
-    constexpr int R = 32, NT = 512, CPT = 8;
+    constexpr int R = 256 / sizeof(T), NT = 512, CPT = 8;  // 256-byte column segments
     constexpr int CG = NT / (R / V);
     auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
     if (!al(src, lds_) || !al(dst, ldd) || !al(t, V) || N < 1 || N % V != 0) return 1;
@@ -262,7 +262,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, T *ds
                       int K, const double *v, const T *tprev, const double *pprev, T *tout,
                       double *part, int max_rows, double *sspart, int *nb, int *nss, int grid_hint) {
     constexpr int V = 16 / sizeof(T);
-    constexpr int R = 32, NT = 512;
+    constexpr int R = 256 / sizeof(T), NT = 512;  // 256-byte column segments: 32 fp64 / 64 fp32 rows
     constexpr int CG = NT / (R / V);
     const bool defl = (tprev != nullptr);
     auto al = [](const void *p, i64 ld) { return ((uintptr_t)p % 16 == 0) && (ld % V == 0); };

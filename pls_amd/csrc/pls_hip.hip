@@ -44,7 +44,7 @@ struct pls_hip_context {
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
     i64 opt_fused_grid = 0;
-    DevBuf part, sspart, red, xy, v, tab, work, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
+    DevBuf part, sspart, red, xy, v, cs, tab, work, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
     std::vector<hipEvent_t> ev_pool;  // grows until pls_hip_get_timing harvests and recycles it
@@ -286,18 +286,32 @@ int launch_reduce(pls_hip_context *c, const double *part, int nb, int L, const d
     return PLS_HIP_OK;
 }
 
+// n*K (values of P and of R the r update must read) above which it is split over many workgroups
+constexpr i64 ROTATE_SPLIT_MIN = 16384;
+
 int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, double *P,
                   double *Q, double *R, double *v, int K, int M, int A, int a) {
+    const int n = a + 1;
+    const int nip = (int)(c->opt_algo == PLS_HIP_ALGO_NIPALS);
+    const bool split = n < A && n > 0 && (i64)n * K >= ROTATE_SPLIT_MIN;
     Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * M * 3 + (i64)K * (2 * (a + 2)) + K) * 8);
     hipLaunchKernelGGL(plsk::component_update_kernel, dim3(1), dim3(plsk::UPD_THREADS),
-                       (size_t)A * sizeof(double), c->stream, red, XY, W, P, Q, R, v, K, M, A, a,
-                       (int)(c->opt_algo == PLS_HIP_ALGO_NIPALS), (int)c->opt_power_iters);
+                       (size_t)A * sizeof(double), c->stream, red, XY, W, P, Q, R, v, K, M, A, a, nip,
+                       (int)c->opt_power_iters, (int)split);
     LAUNCH_CHECK(c);
+    if (split) {
+        double *cs = (double *)c->cs.p;
+        hipLaunchKernelGGL(plsk::rotate_dots_kernel, dim3(n), dim3(plsk::WG), 0, c->stream, P, W, K, n, cs);
+        LAUNCH_CHECK(c);
+        hipLaunchKernelGGL(plsk::rotate_apply_kernel, dim3((K + plsk::WG - 1) / plsk::WG), dim3(plsk::WG), 0,
+                           c->stream, W, R, cs, v, K, n, nip);
+        LAUNCH_CHECK(c);
+    }
     return PLS_HIP_OK;
 }
 
 int do_allreduce(pls_hip_context *c, double *buf, i64 count) {
-    if (!c->reducer || c->nranks <= 1) return PLS_HIP_OK;
+    if (!c->reducer) return PLS_HIP_OK;  // an installed reducer is called even for one rank
     const int rc = c->reducer(c->reducer_user, buf, count, (void *)c->stream);
     if (rc != 0) return fail(c, PLS_HIP_ERR_REDUCER, "all-reduce callback returned " + std::to_string(rc));
     return PLS_HIP_OK;
@@ -316,6 +330,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     CHK(ensure(c, c->sspart, (size_t)ssmax * 8));
     CHK(ensure(c, c->xy, (size_t)L0 * 8));
     CHK(ensure(c, c->v, (size_t)K * 8));
+    CHK(ensure(c, c->cs, (size_t)A * 8));
     double *red;
     if (c->user_red) {
         if (c->user_red_count < redn) return fail(c, PLS_HIP_ERR_INVALID, "reduce buffer too small");
@@ -469,7 +484,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->part, &h->sspart, &h->red, &h->xy, &h->v, &h->tab, &h->work, &h->hX, &h->hY,
+    DevBuf *bufs[] = {&h->part, &h->sspart, &h->red, &h->xy, &h->v, &h->cs, &h->tab, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);

@@ -22,7 +22,8 @@ constexpr int MMAX = 32;  // responses supported by the on-device direction solv
 
 // Dominant eigenvector of G = S^T S (M x M, symmetric PSD) by power iteration carried out as
 // repeated squaring: B_0 = G/tr G, B_{j+1} = B_j^2 / tr(B_j^2) -> v1 v1^T with the error
-// contracting as (lambda2/lambda1)^(2^j); then two plain power steps q <- G q / |G q| on the
+// contracting as (lambda2/lambda1)^(2^j), stopped at the fixed point (at most `iters`
+// squarings); then two plain power steps q <- G q / |G q| on the
 // original G polish the vector to working precision.  This replaces the reference's general
 // EigenSolver + find_dominant_ev (src/pls.cpp:406-408, :113-141).  Sign (left open by the
 // reference): largest-|.| entry positive, lowest index on ties.
@@ -45,8 +46,13 @@ __device__ inline void dominant_eigvec_lds(double *G, double *Bm, double *Cm, do
         __syncthreads();
         double t2 = 0.0;
         for (int c = 0; c < M; ++c) t2 += Cm[c + c * M];
-        if (act) Bm[a + b * M] = Cm[a + b * M] / t2;
-        __syncthreads();
+        int same = 1;
+        if (act) {
+            const double nb = Cm[a + b * M] / t2, ob = Bm[a + b * M];
+            same = fabs(nb - ob) <= 4.0e-16 * fabs(nb) + 1.0e-300;  // fixed point: B has become v1 v1^T
+            Bm[a + b * M] = nb;
+        }
+        if (__syncthreads_and(same)) break;  // uniform exit; also the barrier that publishes Bm
     }
     // column with the largest diagonal entry spans the dominant direction
     int best = 0;
@@ -88,7 +94,8 @@ __device__ inline void dominant_eigvec_lds(double *G, double *Bm, double *Cm, do
 __global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
     const double *__restrict__ red, double *__restrict__ XY, double *__restrict__ W,
     double *__restrict__ P, double *__restrict__ Q, double *__restrict__ R,
-    double *__restrict__ vnext, int K, int M, int A, int a, int nipals, int power_iters) {
+    double *__restrict__ vnext, int K, int M, int A, int a, int nipals, int power_iters,
+    int split_rotate) {
     extern __shared__ double cs[];  // [A]
     __shared__ double sred[UPD_WAVES];
     __shared__ double qs[MMAX];
@@ -151,12 +158,23 @@ __global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
         const double nrm = sqrt(ss);
         for (int k = tid; k < K; k += UPD_THREADS) wn[k] = wn[k] / nrm;  // own element: no hazard
     }
+    if (split_rotate) return;  // r is finished by rotate_dots_kernel + rotate_apply_kernel
     __syncthreads();
+    // The two loops below touch O(n*K) values from one workgroup: latency-bound unless several
+    // independent loads are in flight per lane, hence the 4-way unrolling.
     for (int j = wv; j < n; j += UPD_WAVES) {  // c_j = P[:,j]^T w  (against the ORIGINAL w, :415)
         const double *pj = P + (i64)j * K;
-        double s = 0.0;
-        for (int k = lane; k < K; k += WAVE) s = fma(pj[k], wn[k], s);
-        s = wave_sum(s);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = lane;
+        for (; k + 3 * WAVE < K; k += 4 * WAVE) {
+            const double a0 = pj[k], a1 = pj[k + WAVE], a2 = pj[k + 2 * WAVE], a3 = pj[k + 3 * WAVE];
+            s0 = fma(a0, wn[k], s0);
+            s1 = fma(a1, wn[k + WAVE], s1);
+            s2 = fma(a2, wn[k + 2 * WAVE], s2);
+            s3 = fma(a3, wn[k + 3 * WAVE], s3);
+        }
+        for (; k < K; k += WAVE) s0 = fma(pj[k], wn[k], s0);
+        const double s = wave_sum((s0 + s1) + (s2 + s3));
         if (lane == 0) cs[j] = s;
     }
     __syncthreads();
@@ -164,10 +182,58 @@ __global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
     for (int k = tid; k < K; k += UPD_THREADS) {
         const double w = wn[k];
         double r = w;
-        for (int j = 0; j < n; ++j) r -= cs[j] * R[k + (i64)j * K];
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {  // same subtraction order as the reference, loads issued together
+            const double r0 = R[k + (i64)j * K], r1 = R[k + (i64)(j + 1) * K];
+            const double r2 = R[k + (i64)(j + 2) * K], r3 = R[k + (i64)(j + 3) * K];
+            r -= cs[j] * r0;
+            r -= cs[j + 1] * r1;
+            r -= cs[j + 2] * r2;
+            r -= cs[j + 3] * r3;
+        }
+        for (; j < n; ++j) r -= cs[j] * R[k + (i64)j * K];
         rn[k] = r;
         vnext[k] = nipals ? w : r;
     }
+}
+
+// Multi-workgroup form of the r update (src/pls.cpp:412-416) for large n*K, where one workgroup
+// would be latency-bound on the 2*n*K values of P and R:
+//   rotate_dots_kernel   grid n      : cs[j] = P[:,j]^T w_n
+//   rotate_apply_kernel  grid K/256  : r_n = w_n - sum_{j<n} cs[j] R[:,j]   (j ascending, as the reference)
+__global__ __launch_bounds__(WG) void rotate_dots_kernel(const double *__restrict__ P,
+                                                         const double *__restrict__ W, int K, int n,
+                                                         double *__restrict__ cs) {
+    __shared__ double sm[WG / WAVE];
+    const int j = blockIdx.x;
+    const double *pj = P + (i64)j * K, *wn = W + (i64)n * K;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < K; k += WG) s = fma(pj[k], wn[k], s);
+    s = block_sum<WG / WAVE>(s, sm);
+    if (threadIdx.x == 0) cs[j] = s;
+}
+
+__global__ __launch_bounds__(WG) void rotate_apply_kernel(const double *__restrict__ W,
+                                                          double *__restrict__ R,
+                                                          const double *__restrict__ cs,
+                                                          double *__restrict__ vnext, int K, int n,
+                                                          int nipals) {
+    const int k = blockIdx.x * WG + threadIdx.x;
+    if (k >= K) return;
+    const double w = W[k + (i64)n * K];
+    double r = w;
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+        const double r0 = R[k + (i64)j * K], r1 = R[k + (i64)(j + 1) * K];
+        const double r2 = R[k + (i64)(j + 2) * K], r3 = R[k + (i64)(j + 3) * K];
+        r -= cs[j] * r0;
+        r -= cs[j + 1] * r1;
+        r -= cs[j + 2] * r2;
+        r -= cs[j + 3] * r3;
+    }
+    for (; j < n; ++j) r -= cs[j] * R[k + (i64)j * K];
+    R[k + (i64)n * K] = r;
+    vnext[k] = nipals ? w : r;
 }
 
 // out[j] = sum of the RED_SLICES slices (stand-alone X^T Y entry point)

@@ -75,3 +75,40 @@ def test_sharded_fit_matches_oracle(N, K, M, A, world, algo, fuse):
     lim = np.maximum(1e-9, 20 * po.column_errors(ref, alt))
     err = np.linalg.norm(T * s - ref["T"], axis=0) / np.linalg.norm(ref["T"], axis=0)
     assert (err <= lim).all()
+
+
+def _nccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import pls_amd
+    from pls_amd.distributed import attach_reducer
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        N, K, M, A = 8192, 128, 2, 5
+        h = pls_amd.Handle()
+        X = h.synth_x(0, N, K, 1); Y = h.synth_y(0, N, M, 1)
+        plain = h.fit_device(X, Y, A); h.synchronize()
+        attach_reducer(h, K, M)          # RCCL all-reduce (a 1-rank communicator) between the kernels
+        red = h.fit_device(X, Y, A); h.synchronize()
+        q.put({k: bool(torch.equal(plain[k], red[k])) for k in "WPQRTB"})
+        h.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nccl_reducer_single_rank():
+    """the nccl (RCCL) branch of the reducer, stream-ordered between the library's kernels: with one
+    rank the sum is the identity, so the fit must be bit-identical to the reducer-free fit."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    same = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert all(same.values()), same
