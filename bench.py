@@ -225,7 +225,7 @@ def main():
         line["alt"] = alt
 
     if rank == 0:
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:  # the CPU leg runs on rank 0 at N = 1 only
             try:
                 base, omp = cpu_baseline(N, K, M, A, a.cpu_rows)
                 line["cpu_baseline"] = base

@@ -139,7 +139,8 @@ PLS_HIP_API int pls_hip_get_timing(pls_hip_handle h, pls_hip_timing *out);
 
 /*
  * Fit A components: the body of Model::plsr (src/pls.cpp:390-437).
- * X, Y are never written.  T may be NULL for PLS_HIP_KERNEL_TYPE2 only.  B (K x M, ld K)
+ * X, Y are never written.  PLS_HIP_KERNEL_TYPE2 (XX = X^T X once, no pass over X per component,
+ * src/pls.cpp:398,422-425) does not compute T: T may be NULL and is left untouched.  B (K x M, ld K)
  * may be NULL; otherwise it receives coefficients(A) = R Q^T (src/pls.cpp:444-447).
  * mem == DEVICE: all pointers are device pointers, the call only enqueues work on the
  * stream (pls_hip_synchronize or the caller's own stream sync completes it).

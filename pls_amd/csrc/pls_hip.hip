@@ -44,7 +44,7 @@ struct pls_hip_context {
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
     i64 opt_fused_grid = 0;
-    DevBuf part, sspart, red, xy, v, cs, tab, work, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
+    DevBuf part, sspart, red, red2, xx, praw, xy, v, cs, tab, work, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
     std::vector<hipEvent_t> ev_pool;  // grows until pls_hip_get_timing harvests and recycles it
@@ -290,9 +290,9 @@ int launch_reduce(pls_hip_context *c, const double *part, int nb, int L, const d
 constexpr i64 ROTATE_SPLIT_MIN = 16384;
 
 int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, double *P,
-                  double *Q, double *R, double *v, int K, int M, int A, int a) {
+                  double *Q, double *R, double *v, int K, int M, int A, int a, bool next_is_w) {
     const int n = a + 1;
-    const int nip = (int)(c->opt_algo == PLS_HIP_ALGO_NIPALS);
+    const int nip = (int)next_is_w;
     const bool split = n < A && n > 0 && (i64)n * K >= ROTATE_SPLIT_MIN;
     Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * M * 3 + (i64)K * (2 * (a + 2)) + K) * 8);
     hipLaunchKernelGGL(plsk::component_update_kernel, dim3(1), dim3(plsk::UPD_THREADS),
@@ -320,8 +320,9 @@ int do_allreduce(pls_hip_context *c, double *buf, i64 count) {
 // ---- the fit on device pointers -----------------------------------------------------------
 template <typename T>
 int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64 N, int K, int M,
-               int A, double *W, double *P, double *Q, double *R, T *Tm, i64 ldt, double *B) {
-    const bool nipals = (c->opt_algo == PLS_HIP_ALGO_NIPALS);
+               int A, int method, double *W, double *P, double *Q, double *R, T *Tm, i64 ldt, double *B) {
+    const bool type2 = (method == PLS_HIP_KERNEL_TYPE2);
+    const bool nipals = !type2 && (c->opt_algo == PLS_HIP_ALGO_NIPALS);
     const i64 L0 = (i64)K * M;
     const i64 redn = (i64)plsk::RED_SLICES * std::max<i64>(L0, K + 1);
     const i64 prow = max_partial_rows(c, N, K);
@@ -353,7 +354,48 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         HIPCHK(c, hipMemsetAsync(red, 0, (size_t)plsk::RED_SLICES * L0 * 8, c->stream));
     }
     CHK(do_allreduce(c, red, (i64)plsk::RED_SLICES * L0));
-    CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, -1));
+    CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, -1, nipals));
+
+    if (type2) {
+        // KERNEL_TYPE2 (src/pls.cpp:398, :422-425): XX = X^T X once, then the A-loop never touches X:
+        // tt = r^T XX r, p = XX r / tt; T is not computed.  XX is formed in 32-column blocks with the
+        // same column-reduction kernel as X^T Y (functional; an MFMA SYRK is the planned fast form).
+        constexpr int CB = 32;
+        CHK(ensure(c, c->xx, (size_t)K * K * 8));
+        CHK(ensure(c, c->praw, (size_t)K * 8));
+        CHK(ensure(c, c->part, (size_t)prow * (size_t)K * CB * 8));
+        CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * CB * 8));
+        part = (double *)c->part.p;
+        double *XX = (double *)c->xx.p, *red2 = (double *)c->red2.p, *praw = (double *)c->praw.p;
+        for (int c0 = 0; c0 < K; c0 += CB) {
+            const int cb = std::min(CB, K - c0);
+            if (N > 0) {
+                int nb = 0;
+                CHK(launch_xty<T>(c, X, ldx, X + (i64)c0 * ldx, ldx, N, K, cb, part, &nb));
+                CHK(launch_reduce(c, part, nb, K * cb, nullptr, 0, red2));
+            } else {
+                HIPCHK(c, hipMemsetAsync(red2, 0, (size_t)plsk::RED_SLICES * K * cb * 8, c->stream));
+            }
+            CHK(do_allreduce(c, red2, (i64)plsk::RED_SLICES * K * cb));
+            hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((K * cb + plsk::WG - 1) / plsk::WG), dim3(plsk::WG), 0,
+                               c->stream, (const double *)red2, K * cb, XX + (i64)c0 * K);
+            LAUNCH_CHECK(c);
+        }
+        for (int a = 0; a < A; ++a) {
+            int nss = 0;
+            CHK(launch_xb<double>(c, XX, K, K, K, v, K, 1, praw, K, nullptr, &nss));  // XX symmetric: XX r
+            hipLaunchKernelGGL(plsk::type2_pack_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream,
+                               (const double *)praw, (const double *)v, K, red);
+            LAUNCH_CHECK(c);
+            CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a, false));
+        }
+        if (B) {
+            const int nblk = (int)((L0 + plsk::WG - 1) / plsk::WG);
+            hipLaunchKernelGGL(plsk::coefficients_kernel, dim3(nblk), dim3(plsk::WG), 0, c->stream, R, Q, K, M, A, B);
+            LAUNCH_CHECK(c);
+        }
+        return PLS_HIP_OK;
+    }
 
     const T *Xc = X;
     i64 ldc = ldx;
@@ -400,7 +442,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             HIPCHK(c, hipMemsetAsync(red, 0, (size_t)plsk::RED_SLICES * (K + 1) * 8, c->stream));
         }
         CHK(do_allreduce(c, red, (i64)plsk::RED_SLICES * (K + 1)));
-        CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a));  // :427-433 and :403-416 of a+1
+        CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a, nipals));  // :427-433 and :403-416 of a+1
     }
     if (B) {
         Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * A + (i64)M * A + (i64)K * M) * 8);
@@ -484,7 +526,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->part, &h->sspart, &h->red, &h->xy, &h->v, &h->cs, &h->tab, &h->work, &h->hX, &h->hY,
+    DevBuf *bufs[] = {&h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->tab, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -597,16 +639,14 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
     if (mem != PLS_HIP_MEM_HOST && mem != PLS_HIP_MEM_DEVICE) return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
     if (method != PLS_HIP_KERNEL_TYPE1 && method != PLS_HIP_KERNEL_TYPE2)
         return fail(h, PLS_HIP_ERR_INVALID, "bad method");
-    if (method == PLS_HIP_KERNEL_TYPE2)
-        return fail(h, PLS_HIP_ERR_UNSUPPORTED, "KERNEL_TYPE2 (X^T X form) is not implemented on the device yet");
     const bool sharded = h->nranks > 1;
     if (N < 0 || (N == 0 && !sharded) || K < 1 || M < 1 || A < 1 || A > K)
         return fail(h, PLS_HIP_ERR_INVALID, "bad shape: need N>=1, K>=1, M>=1, 1<=A<=K");
     if (K > (1 << 30) || M > (1 << 20) || (M > 1 && M > plsk::MMAX))
         return fail(h, PLS_HIP_ERR_UNSUPPORTED, "M > 32 responses (or K > 2^30) not supported on the device");
-    if (N > 0 && (!X || !Y || !T)) return fail(h, PLS_HIP_ERR_INVALID, "null X/Y/T");
+    if (N > 0 && (!X || !Y || (!T && method == PLS_HIP_KERNEL_TYPE1))) return fail(h, PLS_HIP_ERR_INVALID, "null X/Y/T");
     if (!W || !P || !Q || !R) return fail(h, PLS_HIP_ERR_INVALID, "null W/P/Q/R");
-    if (ldx < std::max<i64>(N, 1) || ldy < std::max<i64>(N, 1) || ldt < std::max<i64>(N, 1))
+    if (ldx < std::max<i64>(N, 1) || ldy < std::max<i64>(N, 1) || (T && ldt < std::max<i64>(N, 1)))
         return fail(h, PLS_HIP_ERR_INVALID, "leading dimension smaller than N");
     CHK(set_device(h));
     const size_t es = esize(dtype);
@@ -636,11 +676,11 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
     begin_fit_timing(h);
     int rc;
     if (dtype == PLS_HIP_F64)
-        rc = fit_device<double>(h, (const double *)dX, dldx, (const double *)dY, dldy, N, Ki, Mi, Ai, dW,
-                                dP, dQ, dR, (double *)dT, dldt, dB);
+        rc = fit_device<double>(h, (const double *)dX, dldx, (const double *)dY, dldy, N, Ki, Mi, Ai, method,
+                                dW, dP, dQ, dR, (double *)dT, dldt, dB);
     else
-        rc = fit_device<float>(h, (const float *)dX, dldx, (const float *)dY, dldy, N, Ki, Mi, Ai, dW, dP,
-                               dQ, dR, (float *)dT, dldt, dB);
+        rc = fit_device<float>(h, (const float *)dX, dldx, (const float *)dY, dldy, N, Ki, Mi, Ai, method, dW,
+                               dP, dQ, dR, (float *)dT, dldt, dB);
     end_fit_timing(h);
     if (rc != PLS_HIP_OK) return rc;
     if (mem == PLS_HIP_MEM_HOST) {
@@ -649,7 +689,7 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
         CHK(d2h(h, R, K, dR, K, K, A, 8));
         CHK(d2h(h, Q, M, dQ, M, M, A, 8));
         if (B) CHK(d2h(h, B, K, dB, K, K, M, 8));
-        CHK(d2h(h, T, ldt, dT, dldt, N, A, es));
+        if (method == PLS_HIP_KERNEL_TYPE1) CHK(d2h(h, T, ldt, dT, dldt, N, A, es));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return PLS_HIP_OK;

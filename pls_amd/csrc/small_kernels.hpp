@@ -236,6 +236,26 @@ __global__ __launch_bounds__(WG) void rotate_apply_kernel(const double *__restri
     vnext[k] = nipals ? w : r;
 }
 
+// KERNEL_TYPE2 (src/pls.cpp:422-425): given praw = XX r, emit what component_update_kernel expects
+// from a pass -- red slice 0 = [praw (K), tt = r^T XX r], the other slices zero.
+__global__ __launch_bounds__(UPD_THREADS) void type2_pack_kernel(const double *__restrict__ praw,
+                                                                const double *__restrict__ r, int K,
+                                                                double *__restrict__ red) {
+    __shared__ double sm[UPD_WAVES];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < K; k += UPD_THREADS) {
+        const double p = praw[k];
+        s = fma(r[k], p, s);
+        red[k] = p;
+        for (int i = 1; i < RED_SLICES; ++i) red[(i64)i * (K + 1) + k] = 0.0;
+    }
+    s = block_sum<UPD_WAVES>(s, sm);
+    if (threadIdx.x == 0) {
+        red[K] = s;
+        for (int i = 1; i < RED_SLICES; ++i) red[(i64)i * (K + 1) + K] = 0.0;
+    }
+}
+
 // out[j] = sum of the RED_SLICES slices (stand-alone X^T Y entry point)
 __global__ __launch_bounds__(WG) void sum_slices_kernel(const double *__restrict__ red, int L,
                                                         double *__restrict__ out) {

@@ -217,6 +217,18 @@ def test_power_iteration_close_eigenvalues(handle, oracle, po):
     check_against(po, out, ref, Bref, ref["T"], col_err=cerr)
 
 
+@pytest.mark.parametrize("N,K,M,A", [(9, 7, 2, 4), (1000, 64, 1, 12), (777, 33, 3, 8), (2048, 130, 8, 6)])
+def test_kernel_type2(handle, oracle, po, N, K, M, A):
+    """METHOD::KERNEL_TYPE2 (src/pls.cpp:398,422-425): XX = X^T X once, no pass over X in the loop, T
+    not computed.  Same W,P,Q,R,B as KERNEL_TYPE1 up to rounding."""
+    import pls_amd
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    ref = oracle.plsr(Xh, Yh, A, method=1)
+    _, _, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    out = handle.fit_device(to_dev(Xh), to_dev(Yh), A, method=pls_amd.KERNEL_TYPE2); handle.synchronize()
+    check_against(po, out, ref, oracle.coefficients(ref["R"], ref["Q"]), None, col_err=cerr)
+
+
 def test_fp32_storage(handle, oracle, po, mode):
     """BASELINE config 4 is fp32 (no reference counterpart: float_type is double, pls.h:22).
     fp32 storage of X, Y, T with fp64 accumulation, checked against the fp64 oracle run on the
@@ -240,14 +252,43 @@ def test_bad_arguments(handle):
     with pytest.raises(pls_amd.PlsHipError) as e:
         handle.fit_device(X, Y, 6)  # A > K
     assert e.value.code == 1
-    with pytest.raises(pls_amd.PlsHipError) as e:
-        handle.fit_device(X, Y, 2, method=pls_amd.KERNEL_TYPE2)
-    assert e.value.code == 4
     with pytest.raises(pls_amd.PlsHipError):
         handle.fit_device(X, handle.synth_y(0, 50, 40, 1), 2)  # m > 32
     # the handle stays usable after an error
     out = handle.fit_device(X, Y, 2); handle.synchronize()
     assert torch.isfinite(out["B"]).all()
+
+
+@pytest.mark.parametrize("N,K,M,A", [(1, 3, 1, 1), (40, 1, 1, 1), (2, 2, 2, 2), (300, 20, 32, 3), (64, 600, 2, 5)])
+def test_extreme_shapes(handle, oracle, po, mode, N, K, M, A):
+    """single row, single predictor, the widest supported response block (m = 32), K > N."""
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    out = handle.fit_device(to_dev(Xh), to_dev(Yh), A); handle.synchronize()
+    check_against(po, out, ref, Bref, ref["T"], col_err=cerr, tol_inv=1e-7)
+
+
+def test_padded_leading_dimensions(handle, oracle, po, mode):
+    """ld > rows for X, Y and T (the C-ABI takes explicit leading dimensions)."""
+    import ctypes
+    import pls_amd
+    from pls_amd import _lib as L
+    torch = _torch()
+    N, K, M, A = 1000, 48, 2, 6
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    X = pls_amd.colmajor_empty(N, K, torch.float64, "cuda", ld=N + 24); X.copy_(torch.from_numpy(Xh))
+    Y = pls_amd.colmajor_empty(N, M, torch.float64, "cuda", ld=N + 8); Y.copy_(torch.from_numpy(Yh))
+    out = {k: pls_amd.colmajor_empty(K, A, torch.float64, "cuda", ld=K) for k in "WPR"}
+    out["Q"] = pls_amd.colmajor_empty(M, A, torch.float64, "cuda", ld=M)
+    out["B"] = pls_amd.colmajor_empty(K, M, torch.float64, "cuda", ld=K)
+    out["T"] = pls_amd.colmajor_empty(N, A, torch.float64, "cuda", ld=N + 40)
+    out["T"].untyped_storage()  # keep a reference
+    guard = torch.full((A, N + 40), 7.0, dtype=torch.float64, device="cuda")
+    out["T"] = guard[:, :N].t()
+    handle.fit_device(X, Y, A, out=out); handle.synchronize()
+    check_against(po, out, ref, Bref, ref["T"], col_err=cerr)
+    assert bool((guard[:, N:] == 7.0).all()), "the padding between T columns must not be written"
 
 
 def test_rank_deficient_leading_components(handle, oracle, po):
