@@ -36,6 +36,7 @@ WORKLOADS = {
     "C3": (1 << 20, 512, 1, 20, "f64"),
     "C4": (131072, 4096, 8, 50, "f32"),
     "C5rank": (2097152, 1024, 4, 20, "f64"),  # one rank's shard of config 5
+    "C3eighth": (131072, 512, 1, 20, "f64"),  # one rank's share of config 3 on 8 GPUs (overhead study)
     "tiny": (4096, 64, 1, 5, "f64"),
 }
 

@@ -78,7 +78,7 @@ typedef enum { PLS_HIP_ALGO_KERNEL = 0, PLS_HIP_ALGO_NIPALS = 1 } pls_hip_algo;
 typedef enum {
     PLS_HIP_OPT_ALGO = 1,       /* pls_hip_algo; default PLS_HIP_ALGO_KERNEL */
     PLS_HIP_OPT_FUSE = 2,       /* 0: one kernel per product (Xv, X^T t, deflate); 1 (default): row-tile-resident fused pass when the shape allows */
-    PLS_HIP_OPT_PROFILE = 3,    /* 1: bracket every kernel family with HIP events on the launch stream */
+    PLS_HIP_OPT_PROFILE = 3,    /* HIP events on the launch stream: 1 = around the streaming kernels over X, 2 = around every kernel */
     PLS_HIP_OPT_POWER_ITERS = 4, /* squarings of the S^T S power iteration (m > 1); default 48 */
     PLS_HIP_OPT_FUSED_GRID = 5   /* workgroups of the fused pass; 0 (default) = 8 per CU */
 } pls_hip_option;

@@ -111,7 +111,10 @@ struct Scope {  // brackets one launch with events when profiling is on
     pls_hip_context *c;
     Launch l{};
     bool on;
-    Scope(pls_hip_context *ctx, int fam, i64 bytes) : c(ctx), on(ctx->opt_profile != 0) {
+    // profile level 1 brackets only the streaming kernels over X (the K-sized bookkeeping kernels
+    // run unbracketed, so that event records do not widen the gaps of the A-loop); level 2: all
+    Scope(pls_hip_context *ctx, int fam, i64 bytes)
+        : c(ctx), on(ctx->opt_profile >= 2 || (ctx->opt_profile == 1 && fam != PLS_HIP_FAM_SMALL)) {
         if (!on) return;
         l.fam = fam;
         l.bytes = bytes;
@@ -552,7 +555,7 @@ int pls_hip_set_option(pls_hip_handle h, int option, int64_t value) {
             h->opt_algo = value;
             return PLS_HIP_OK;
         case PLS_HIP_OPT_FUSE: h->opt_fuse = value ? 1 : 0; return PLS_HIP_OK;
-        case PLS_HIP_OPT_PROFILE: h->opt_profile = value ? 1 : 0; return PLS_HIP_OK;
+        case PLS_HIP_OPT_PROFILE: h->opt_profile = value < 0 ? 0 : (value > 2 ? 2 : value); return PLS_HIP_OK;
         case PLS_HIP_OPT_POWER_ITERS:
             if (value < 1 || value > 4096) return fail(h, PLS_HIP_ERR_INVALID, "power iters out of range");
             h->opt_power_iters = value;

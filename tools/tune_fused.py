@@ -8,12 +8,12 @@ import torch
 
 import pls_amd
 
-N, K, M, A = 1 << 20, 512, 1, 6
+N, K, M, A = int(os.environ.get('TUNE_N', 1 << 20)), 512, 1, 6
 h = pls_amd.Handle()
 X = h.synth_x(0, N, K, pls_amd.SEED_DEFAULT)
 Y = h.synth_y(0, N, M, pls_amd.SEED_DEFAULT)
 h.set_option(pls_amd.OPT_PROFILE, 1)
-grids = [int(g) for g in sys.argv[1:]] or [512, 2048]
+grids = [int(g) for g in sys.argv[1:]] or [256, 512, 1024, 2048]
 out = None
 import itertools
 for algo, var, rep in itertools.product((1, 0), (0,), (0, 1)):
