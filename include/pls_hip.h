@@ -173,6 +173,28 @@ PLS_HIP_API int pls_hip_xty(pls_hip_handle h, const void *X, int64_t ldx, const 
 PLS_HIP_API int pls_hip_deflate(pls_hip_handle h, const void *src, int64_t lds, void *dst, int64_t ldd,
                     int64_t N, int64_t K, const void *t, const double *p, int dtype);
 
+/* ---- callers either side of the path, on DEVICE pointers ---- */
+
+/* Column z-scores as the reference's main applies them before the fit (src/pls.cpp:69-111,
+ * src/main.cpp:24-25): mean[k], sd[k] = sqrt(SST/(n_total-1)), Z = (X - mean)/sd (Z may be NULL to get
+ * the statistics only, or equal to X for an in-place transform).  A constant column yields NaN, as
+ * upstream (:103).  n_total = rows over all ranks of a sharded matrix (= N on one GPU). */
+PLS_HIP_API int pls_hip_colwise_z_scores(pls_hip_handle h, const void *X, int64_t ldx, int64_t N,
+                                         int64_t n_total, int64_t K, int dtype, void *Z, int64_t ldz,
+                                         double *mean, double *sd);
+/* SSE(M x A, ld M)[m, c-1] = sum_i (Y[i,m] - (S[:, :c] Q[:, :c]^T)[i,m])^2 for c = 1..A in one sweep
+ * over the scores S = X R (N x A): Model::SSE for every component count (src/pls.cpp:457-459) without the
+ * A separate X*B passes of print_explained_variance (:551-562). */
+PLS_HIP_API int pls_hip_sse_by_components(pls_hip_handle h, const void *S, int64_t lds, const void *Y,
+                                          int64_t ldy, int64_t N, int64_t A, int64_t M, const double *Q,
+                                          int dtype, double *SSE);
+
+/* The same for a model (R: K x A, Q: M x A, ld = rows) and data (X, Y) in host or device memory:
+ * S = X R (one pass over X, kept on the device) followed by the sweep above. */
+PLS_HIP_API int pls_hip_model_sse(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy,
+                                  int64_t N, int64_t K, int64_t M, int64_t A, const double *R,
+                                  const double *Q, int dtype, int mem, double *SSE);
+
 /* ---- synthetic inputs, generated on the device (DESIGN.md "Synthetic inputs") ------ */
 
 /* rows [row0, row0+nrows) of the global matrix -> X (nrows x K, ld ldx) / Y (nrows x M) */

@@ -799,6 +799,150 @@ int pls_hip_deflate(pls_hip_handle h, const void *src, int64_t lds, void *dst, i
     return launch_deflate<float>(h, (const float *)src, lds, (float *)dst, ldd, N, (int)K, (const float *)t, p);
 }
 
+}  // extern "C"
+
+namespace {
+
+// column mean / sd / z-scores on the device (two column-reduction passes + one scale pass)
+template <typename T>
+int zscores_device(pls_hip_context *c, const T *X, i64 ldx, i64 N, i64 n_total, int K, T *Z, i64 ldz,
+                   double *mean, double *sd) {
+    constexpr int FV = 16 / sizeof(T);
+    constexpr int KC = 16;
+    const bool wide = vec_ok<T>(X, ldx, FV) && (!Z || vec_ok<T>(Z, ldz, FV));
+    const int vec = wide ? FV : 1;
+    const int nkg = (K + KC - 1) / KC;
+    const i64 nch = std::max<i64>(1, (N + (i64)plsk::WG * vec - 1) / ((i64)plsk::WG * vec));
+    const int G = (int)std::min<i64>(nch, std::max<i64>(1, (8 * c->num_cu) / nkg));
+    CHK(ensure(c, c->part, (size_t)G * K * 8));
+    CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * 8));
+    double *part = (double *)c->part.p, *red = (double *)c->red2.p;
+    const dim3 grid(G, nkg), blk(plsk::WG);
+    for (int mode = 0; mode < 2; ++mode) {
+        if (N > 0) {
+            Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) + (i64)K * 8);
+#define CS_CASE(V_, M_) hipLaunchKernelGGL((plsk::colstat_kernel<T, V_, KC, M_>), grid, blk, 0, c->stream, X, ldx, N, K, mean, part)
+            if (wide) { if (mode == 0) CS_CASE(FV, 0); else CS_CASE(FV, 1); }
+            else { if (mode == 0) CS_CASE(1, 0); else CS_CASE(1, 1); }
+#undef CS_CASE
+            LAUNCH_CHECK(c);
+            CHK(launch_reduce(c, part, G, K, nullptr, 0, red));
+        } else {
+            HIPCHK(c, hipMemsetAsync(red, 0, (size_t)plsk::RED_SLICES * K * 8, c->stream));
+        }
+        CHK(do_allreduce(c, red, (i64)plsk::RED_SLICES * K));
+        hipLaunchKernelGGL(plsk::colstat_finish_kernel, dim3((K + plsk::WG - 1) / plsk::WG), blk, 0, c->stream,
+                           (const double *)red, K, (double)n_total, mode, mode == 0 ? mean : sd);
+        LAUNCH_CHECK(c);
+    }
+    if (Z && N > 0) {
+        Scope s(c, PLS_HIP_FAM_DEFLATE, 2 * (i64)N * K * sizeof(T) + 2 * (i64)K * 8);
+        const dim3 g2((unsigned)std::min<i64>(nch, std::max<i64>(1, (16 * c->num_cu) / nkg)), nkg);
+        if (wide) hipLaunchKernelGGL((plsk::zscale_kernel<T, FV, KC>), g2, blk, 0, c->stream, X, ldx, Z, ldz, N, K, mean, sd);
+        else hipLaunchKernelGGL((plsk::zscale_kernel<T, 1, KC>), g2, blk, 0, c->stream, X, ldx, Z, ldz, N, K, mean, sd);
+        LAUNCH_CHECK(c);
+    }
+    return PLS_HIP_OK;
+}
+
+template <typename T>
+int sse_device(pls_hip_context *c, const T *S, i64 lds, const T *Y, i64 ldy, i64 N, int A, int M,
+               const double *Q, double *SSE) {
+    const int AM = A * M;
+    const int G = (int)std::min<i64>(std::max<i64>(1, (N + plsk::WG - 1) / plsk::WG), 4 * (i64)c->num_cu);
+    CHK(ensure(c, c->part, (size_t)G * AM * 8));
+    CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * AM * 8));
+    {
+        Scope s(c, PLS_HIP_FAM_XB, (i64)N * (A + M) * sizeof(T) + (i64)AM * 8);
+        hipLaunchKernelGGL((plsk::sse_components_kernel<T>), dim3(G), dim3(plsk::WG),
+                           (size_t)(plsk::WG / plsk::WAVE) * AM * 8, c->stream, S, lds, Y, ldy, N, A, M, Q,
+                           (double *)c->part.p);
+        LAUNCH_CHECK(c);
+    }
+    CHK(launch_reduce(c, (const double *)c->part.p, G, AM, nullptr, 0, (double *)c->red2.p));
+    CHK(do_allreduce(c, (double *)c->red2.p, (i64)plsk::RED_SLICES * AM));
+    hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((AM + plsk::WG - 1) / plsk::WG), dim3(plsk::WG), 0, c->stream,
+                       (const double *)c->red2.p, AM, SSE);
+    LAUNCH_CHECK(c);
+    return PLS_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pls_hip_colwise_z_scores(pls_hip_handle h, const void *X, int64_t ldx, int64_t N, int64_t n_total,
+                             int64_t K, int dtype, void *Z, int64_t ldz, double *mean, double *sd) {
+    CHK(check_handle(h));
+    if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
+    if (N < 0 || n_total < N || n_total < 1 || K < 1 || K > (1 << 30) || !mean || !sd || (N > 0 && !X) ||
+        ldx < std::max<i64>(N, 1) || (Z && ldz < std::max<i64>(N, 1)))
+        return fail(h, PLS_HIP_ERR_INVALID, "bad z-score arguments");
+    CHK(set_device(h));
+    if (dtype == PLS_HIP_F64)
+        return zscores_device<double>(h, (const double *)X, ldx, N, n_total, (int)K, (double *)Z, ldz, mean, sd);
+    return zscores_device<float>(h, (const float *)X, ldx, N, n_total, (int)K, (float *)Z, ldz, mean, sd);
+}
+
+int pls_hip_sse_by_components(pls_hip_handle h, const void *S, int64_t lds, const void *Y, int64_t ldy,
+                              int64_t N, int64_t A, int64_t M, const double *Q, int dtype, double *SSE) {
+    CHK(check_handle(h));
+    if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
+    if (N < 1 || A < 1 || M < 1 || A * M > 4096 || !S || !Y || !Q || !SSE || lds < N || ldy < N)
+        return fail(h, PLS_HIP_ERR_INVALID, "bad sse arguments");
+    CHK(set_device(h));
+    if (dtype == PLS_HIP_F64)
+        return sse_device<double>(h, (const double *)S, lds, (const double *)Y, ldy, N, (int)A, (int)M, Q, SSE);
+    return sse_device<float>(h, (const float *)S, lds, (const float *)Y, ldy, N, (int)A, (int)M, Q, SSE);
+}
+
+int pls_hip_model_sse(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy, int64_t N,
+                      int64_t K, int64_t M, int64_t A, const double *R, const double *Q, int dtype, int mem,
+                      double *SSE) {
+    CHK(check_handle(h));
+    if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
+    if (mem != PLS_HIP_MEM_HOST && mem != PLS_HIP_MEM_DEVICE) return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
+    if (N < 1 || K < 1 || M < 1 || A < 1 || A * M > 4096 || K > (1 << 30) || !X || !Y || !R || !Q || !SSE ||
+        ldx < N || ldy < N)
+        return fail(h, PLS_HIP_ERR_INVALID, "bad model_sse arguments");
+    CHK(set_device(h));
+    const size_t es = esize(dtype);
+    const i64 ldn = N + (N & 1);
+    const void *dX = X, *dY = Y;
+    const double *dR = R, *dQ = Q;
+    double *dE = SSE;
+    i64 dldx = ldx, dldy = ldy;
+    if (mem == PLS_HIP_MEM_HOST) {
+        CHK(ensure(h, h->hIn, (size_t)ldn * K * es));
+        CHK(ensure(h, h->hY, (size_t)ldn * M * es));
+        CHK(ensure(h, h->hR, (size_t)K * A * 8));
+        CHK(ensure(h, h->hQ, (size_t)M * A * 8));
+        CHK(ensure(h, h->hB, (size_t)M * A * 8));
+        CHK(h2d(h, h->hIn.p, ldn, X, ldx, N, K, es));
+        CHK(h2d(h, h->hY.p, ldn, Y, ldy, N, M, es));
+        CHK(h2d(h, h->hR.p, K, R, K, K, A, 8));
+        CHK(h2d(h, h->hQ.p, M, Q, M, M, A, 8));
+        dX = h->hIn.p; dY = h->hY.p; dR = (const double *)h->hR.p; dQ = (const double *)h->hQ.p;
+        dE = (double *)h->hB.p;
+        dldx = dldy = ldn;
+    }
+    CHK(ensure(h, h->hOut, (size_t)ldn * A * es));  // the scores S = X R stay on the device
+    int nss = 0, rc;
+    if (dtype == PLS_HIP_F64) {
+        CHK(launch_xb<double>(h, (const double *)dX, dldx, N, (int)K, dR, K, (int)A, (double *)h->hOut.p, ldn, nullptr, &nss));
+        rc = sse_device<double>(h, (const double *)h->hOut.p, ldn, (const double *)dY, dldy, N, (int)A, (int)M, dQ, dE);
+    } else {
+        CHK(launch_xb<float>(h, (const float *)dX, dldx, N, (int)K, dR, K, (int)A, (float *)h->hOut.p, ldn, nullptr, &nss));
+        rc = sse_device<float>(h, (const float *)h->hOut.p, ldn, (const float *)dY, dldy, N, (int)A, (int)M, dQ, dE);
+    }
+    if (rc != PLS_HIP_OK) return rc;
+    if (mem == PLS_HIP_MEM_HOST) {
+        CHK(d2h(h, SSE, M, dE, M, M, A, 8));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return PLS_HIP_OK;
+}
+
 int pls_hip_synth_x(pls_hip_handle h, void *X, int64_t ldx, int64_t row0, int64_t nrows, int64_t K,
                     uint64_t seed, int dtype) {
     CHK(check_handle(h));

@@ -256,6 +256,16 @@ __global__ __launch_bounds__(UPD_THREADS) void type2_pack_kernel(const double *_
     }
 }
 
+// mode 0: out = mean = (sum of slices)/n ;  mode 1: out = sd = sqrt(SST/(n-1)), SST = 0 when n < 2
+// (src/pls.cpp:69-83)
+__global__ __launch_bounds__(WG) void colstat_finish_kernel(const double *__restrict__ red, int K,
+                                                            double n, int mode, double *__restrict__ out) {
+    const int k = blockIdx.x * WG + threadIdx.x;
+    if (k >= K) return;
+    const double s = red_sum(red, K, k);
+    out[k] = (mode == 0) ? s / n : sqrt((n < 2.0 ? 0.0 : s) / (n - 1.0));
+}
+
 // out[j] = sum of the RED_SLICES slices (stand-alone X^T Y entry point)
 __global__ __launch_bounds__(WG) void sum_slices_kernel(const double *__restrict__ red, int L,
                                                         double *__restrict__ out) {

@@ -246,6 +246,127 @@ __global__ __launch_bounds__(WG) void deflate_kernel(const T *__restrict__ src, 
 }
 
 // ------------------------------------------------------------------------------------
+// Column statistics for the pre-processing in front of the fit (src/pls.cpp:69-111, src/main.cpp:24-25):
+//   MODE 0: part[g][k] = sum_i X[i,k]                 (-> column mean)
+//   MODE 1: part[g][k] = sum_i (X[i,k] - mean[k])^2   (-> SST, :69-73; sd = sqrt(SST/(N-1)), :79-83)
+// Two passes like the reference (mean first, then squared deviations about it), same grid and
+// reduction structure as xty_kernel.
+// ------------------------------------------------------------------------------------
+template <typename T, int VEC, int KC, int MODE>
+__global__ __launch_bounds__(WG) void colstat_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K,
+                                                     const double *__restrict__ mean,
+                                                     double *__restrict__ part) {
+    __shared__ double red[WG / WAVE][KC];
+    const int k0 = blockIdx.y * KC;
+    const int kn = min(KC, K - k0);
+    double acc[KC], mu[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        acc[kc] = 0.0;
+        mu[kc] = (MODE == 1 && kc < kn) ? mean[k0 + kc] : 0.0;
+    }
+    constexpr i64 CH = (i64)WG * VEC;
+    for (i64 c = blockIdx.x; c * CH < N; c += gridDim.x) {
+        const i64 i0 = c * CH + (i64)threadIdx.x * VEC;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+            if (kc < kn) {
+                if (i0 + VEC <= N) {
+                    const Pack<T, VEC> x = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + kc) * ldx);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double d = (double)x.v[v] - mu[kc];
+                        acc[kc] = (MODE == 0) ? acc[kc] + d : fma(d, d, acc[kc]);
+                    }
+                } else {
+                    for (int v = 0; v < VEC; ++v)
+                        if (i0 + v < N) {
+                            const double d = (double)X[i0 + v + (i64)(k0 + kc) * ldx] - mu[kc];
+                            acc[kc] = (MODE == 0) ? acc[kc] + d : fma(d, d, acc[kc]);
+                        }
+                }
+            }
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        const double s = wave_sum(acc[kc]);
+        if (lane == 0) red[w][kc] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < kn) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < WG / WAVE; ++i) s += red[i][threadIdx.x];
+        part[(i64)blockIdx.x * K + k0 + threadIdx.x] = s;
+    }
+}
+
+// Z[i,k] = (X[i,k] - mean[k]) / sd[k]   (src/pls.cpp:93-105: the division is by the UNGUARDED stdev,
+// so a constant column becomes NaN exactly as in the reference).  grid = (row groups, column groups).
+template <typename T, int VEC, int KC>
+__global__ __launch_bounds__(WG) void zscale_kernel(const T *X, i64 ldx, T *Z, i64 ldz, i64 N, int K,
+                                                    const double *__restrict__ mean,
+                                                    const double *__restrict__ sd) {
+    const int k0 = blockIdx.y * KC;
+    const int kn = min(KC, K - k0);
+    constexpr i64 CH = (i64)WG * VEC;
+    for (i64 c = blockIdx.x; c * CH < N; c += gridDim.x) {
+        const i64 i0 = c * CH + (i64)threadIdx.x * VEC;
+        for (int kc = 0; kc < kn; ++kc) {
+            const double m = mean[k0 + kc], s = sd[k0 + kc];
+            if (i0 + VEC <= N) {
+                Pack<T, VEC> x = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + kc) * ldx);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) x.v[v] = (T)(((double)x.v[v] - m) / s);
+                st_pack_nt<T, VEC>(Z + i0 + (i64)(k0 + kc) * ldz, x);
+            } else {
+                for (int v = 0; v < VEC; ++v)
+                    if (i0 + v < N) Z[i0 + v + (i64)(k0 + kc) * ldz] = (T)(((double)X[i0 + v + (i64)(k0 + kc) * ldx] - m) / s);
+            }
+        }
+    }
+}
+
+// SSE of the model with 1..A components in ONE sweep over the scores (src/pls.cpp:453-459, and the
+// per-ncomp loop of print_explained_variance :551-562, which upstream costs A full X*B passes):
+// with S = X R (N x A) the fitted values are Yhat_c = S[:, :c] Q[:, :c]^T, so a row's residuals for
+// c = 1..A follow from one running sum.  part[g][m + c*M] = sum over the group's rows of
+// (Y[i,m] - Yhat_c[i,m])^2.  One thread per row; Q (M x A) read through the scalar cache.
+template <typename T>
+__global__ __launch_bounds__(WG) void sse_components_kernel(const T *__restrict__ S, i64 lds_,
+                                                            const T *__restrict__ Y, i64 ldy, i64 N,
+                                                            int A, int M, const double *__restrict__ Q,
+                                                            double *__restrict__ part) {
+    extern __shared__ double acc[];  // [WG/WAVE][A*M] per-wave running sums (no barrier in the sweep)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int AM = A * M;
+    double *mine = acc + (i64)wv * AM;
+    for (int j = lane; j < AM; j += WAVE) mine[j] = 0.0;
+    for (i64 i0 = (i64)blockIdx.x * WG; i0 < N; i0 += (i64)gridDim.x * WG) {
+        const i64 i = i0 + threadIdx.x;
+        for (int m = 0; m < M; ++m) {
+            const double y = (i < N) ? (double)Y[i + (i64)m * ldy] : 0.0;
+            double yhat = 0.0;
+            for (int c = 0; c < A; ++c) {
+                const double s = (i < N) ? (double)S[i + (i64)c * lds_] : 0.0;
+                yhat = fma(s, Q[m + (i64)c * M], yhat);
+                const double e = y - yhat;
+                const double tot = wave_sum(e * e);
+                if (lane == 0) mine[m + c * M] += tot;
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < AM; j += WG) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < WG / WAVE; ++w) t += acc[(i64)w * AM + j];
+        part[(i64)blockIdx.x * AM + j] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Fixed-order sum of per-workgroup partials, in RED_SLICES independent slices so that enough
 // workgroups take part:   red[s*LP + j] = sum_{b in slice s} part[b*L + j]   (j < L),
 // and, when nss > 0,      red[s*LP + L] = sum_{b in slice s of nss} sspart[b]     (LP = L+1).

@@ -480,11 +480,29 @@ Residual Model::cv_LSO(const float_type test_fraction, const size_t num_trials, 
 // ---------------------------------------------------------------------------------------------
 // text output (ref :551-580)
 // ---------------------------------------------------------------------------------------------
+// Same lines as the reference prints (ref :551-562), but the A calls of explained_variance -- A
+// full X*B passes upstream -- are replaced by one X*R pass and one sweep over the scores
+// (pls_hip_model_sse): SSE_c follows from Yhat_c = S[:, :c] Q[:, :c]^T.
 void Model::print_explained_variance(const Mat2D &X, const Mat2D &Y, std::ostream &os) const {
     const int wd = static_cast<int>(std::ceil(std::log10(static_cast<double>(A))));
+    const Index N = X.rows(), K = X.cols(), M = Y.cols(), Ai = static_cast<Index>(A);
+    const std::vector<float_type> r = real_part(R, Ai), q = real_part(Q, Ai);
+    std::vector<float_type> sse(static_cast<size_t>(M * Ai));
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        check(pls_hip_model_sse(device(), X.data(), N, Y.data(), N, N, K, M, Ai, r.data(), q.data(), PLS_HIP_F64,
+                                PLS_HIP_MEM_HOST, sse.data()),
+              "pls_hip_model_sse");
+    }
+    const Row sst = SST(Y);
     for (size_t nc = 1; nc <= A; ++nc) {
-        os << std::setw(wd) << nc << " components explained variance: " << explained_variance(X, Y, nc);
-        os << "  - SSE: " << SSE(X, Y, nc) << std::endl;
+        Row ev(M), se(M);
+        for (Index m = 0; m < M; ++m) {
+            se[m] = sse[static_cast<size_t>(m + static_cast<Index>(nc - 1) * M)];
+            ev[m] = 1.0 - se[m] / sst[m];
+        }
+        os << std::setw(wd) << nc << " components explained variance: " << ev;
+        os << "  - SSE: " << se << std::endl;
     }
 }
 

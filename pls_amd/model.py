@@ -240,6 +240,32 @@ class Handle:
         self._last_inputs = (src, t, p)
         return dst
 
+    def colwise_z_scores(self, X, n_total: int | None = None, inplace: bool = False):
+        """(Z, mean, sd) of a device matrix: colwise_z_scores of the reference (src/pls.cpp:107-111)."""
+        X = as_colmajor(X)
+        N, K = X.shape
+        Z = X if inplace else colmajor_empty(N, K, X.dtype, X.device)
+        mean = torch.empty(K, dtype=torch.float64, device=X.device)
+        sd = torch.empty(K, dtype=torch.float64, device=X.device)
+        L.check(self._lib.pls_hip_colwise_z_scores(self.h, X.data_ptr(), _ld(X), N, n_total or N, K, self._dt(X),
+                                                   Z.data_ptr(), _ld(Z), mean.data_ptr(), sd.data_ptr()), self.h)
+        self._last_inputs = (X,)
+        return Z, mean, sd
+
+    def sse_by_components(self, S, Y, Q):
+        """SSE (M x A) for 1..A components from the scores S = X R (one sweep)."""
+        S = as_colmajor(S); Y = as_colmajor(Y, S.dtype)
+        N, A = S.shape
+        M = Y.shape[1]
+        Q = as_colmajor(Q.to(torch.float64))
+        if _ld(Q) != M:
+            Q = colmajor_empty(M, A, torch.float64, Q.device, ld=M).copy_(Q)
+        out = colmajor_empty(M, A, torch.float64, S.device, ld=M)
+        L.check(self._lib.pls_hip_sse_by_components(self.h, S.data_ptr(), _ld(S), Y.data_ptr(), _ld(Y), N, A, M,
+                                                    Q.data_ptr(), self._dt(S), out.data_ptr()), self.h)
+        self._last_inputs = (S, Y, Q)
+        return out
+
     def synth_x(self, row0: int, nrows: int, K: int, seed: int, dtype=None, device=None):
         dtype = dtype or torch.float64
         X = colmajor_empty(nrows, K, dtype, device or f"cuda:{self.device}")
@@ -326,6 +352,22 @@ class Model:
     def SSE(self, X, Y, comp: int | None = None):
         r = self.residuals(X, Y, comp)
         return (r * r).sum(0)
+
+    def explained_variance_by_components(self, X, Y):
+        """(EV, SSE), each M x A: what print_explained_variance (src/pls.cpp:551-562) reports for
+        ncomp = 1..A, from one X*R pass and one sweep over the scores instead of A X*B passes.
+        Device tensors only."""
+        X = as_colmajor(X)
+        Y2 = as_colmajor(Y if Y.dim() == 2 else Y[:, None], X.dtype)
+        N, K = X.shape
+        M = Y2.shape[1]
+        sse = colmajor_empty(M, self.A, torch.float64, X.device, ld=M)
+        L.check(L.lib().pls_hip_model_sse(self.handle.h, X.data_ptr(), _ld(X), Y2.data_ptr(), _ld(Y2), N, K, M,
+                                          self.A, self.R.data_ptr(), self.Q.data_ptr(), self.handle._dt(X),
+                                          L.MEM_DEVICE, sse.data_ptr()), self.handle.h)
+        Yd = Y2.to(torch.float64)
+        sst = ((Yd - Yd.mean(0, keepdim=True)) ** 2).sum(0) if Yd.shape[0] >= 2 else torch.zeros(Yd.shape[1], device=Yd.device)
+        return 1.0 - sse / sst[:, None], sse
 
     def explained_variance(self, X, Y, comp: int | None = None):
         sse = self.SSE(X, Y, comp)

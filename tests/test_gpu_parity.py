@@ -243,6 +243,47 @@ def test_fp32_storage(handle, oracle, po, mode):
 
 
 # ------------------------------------------------------------------------------------------
+# callers either side of the path: pre-processing (f2) and per-component metrics (f3)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,K", [(10, 15), (60, 401), (4097, 33), (100000, 64)])
+def test_device_z_scores(handle, oracle, po, N, K):
+    torch = _torch()
+    rng = np.random.default_rng(5)
+    Xh = np.asfortranarray(oracle.synth_x(0, N, K) * rng.uniform(0.1, 30, K) + rng.uniform(-50, 50, K))
+    Z, mean, sd = handle.colwise_z_scores(to_dev(Xh)); handle.synchronize()
+    Zr = oracle.z_scores(Xh)
+    assert np.allclose(mean.cpu().numpy(), Xh.mean(0), rtol=1e-12, atol=1e-12)
+    assert np.allclose(sd.cpu().numpy(), Xh.std(0, ddof=1), rtol=1e-11)
+    assert np.abs(Z.cpu().numpy() - Zr).max() < 1e-9
+    # in place, and the reference's constant-column behaviour (NaN, src/pls.cpp:103)
+    Xc = Xh.copy(); Xc[:, 2] = 3.25
+    Xd = to_dev(Xc)
+    Z2, _, sd2 = handle.colwise_z_scores(Xd, inplace=True); handle.synchronize()
+    assert Z2.data_ptr() == Xd.data_ptr() and float(sd2[2]) == 0.0
+    z = Z2.cpu().numpy()
+    assert np.isnan(z[:, 2]).all() and np.isfinite(np.delete(z, 2, axis=1)).all()
+    # fp32 storage
+    Z32, m32, _ = handle.colwise_z_scores(to_dev(Xh.astype(np.float32))); handle.synchronize()
+    assert np.abs(Z32.cpu().numpy() - oracle.z_scores(Xh.astype(np.float32).astype(np.float64))).max() < 5e-5
+
+
+@pytest.mark.parametrize("N,K,M,A", [(10, 15, 2, 2), (60, 401, 1, 10), (5000, 40, 3, 7), (1 << 18, 64, 2, 20)])
+def test_sse_by_components(handle, oracle, po, N, K, M, A):
+    import pls_amd
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    X, Y = to_dev(Xh), to_dev(Yh)
+    m = pls_amd.Model(X, Y, pls_amd.KERNEL_TYPE1, A, handle=handle)
+    ev, sse = m.explained_variance_by_components(X, Y); handle.synchronize()
+    ref = oracle.plsr(Xh, Yh, A)
+    for c in range(1, A + 1):
+        evr, sser = po.explained_variance(Xh, Yh, ref["R"], ref["Q"], c)
+        assert np.allclose(sse[:, c - 1].cpu().numpy(), sser, rtol=1e-8)
+        assert np.allclose(ev[:, c - 1].cpu().numpy(), evr, rtol=1e-7, atol=1e-10)
+        # and it agrees with the reference's route (one X*B_c pass per component count)
+        assert np.allclose(m.SSE(X, Y, c).cpu().numpy(), sser, rtol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------
 # error behaviour at the boundary (reference: asserts only, src/pls.cpp:345-347)
 # ------------------------------------------------------------------------------------------
 def test_bad_arguments(handle):
