@@ -238,6 +238,135 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_tile_kernel(
     }
 }
 
+// Semi-fused sweep for matrices too wide for the resident tile (K > 32 column groups' worth):
+//   X' = X - t_prev p_prev^T (written),  t = X' w,  t^T t partials      -- the loading p = X'^T t then
+// takes one more READ of X' (xty_kernel): 3 N K s of traffic per component instead of 4.
+// Same tile access pattern as deflate_tile_kernel; the column groups of a tile are streamed CPT at
+// a time (nothing stays resident), the per-lane partial scores are combined once per tile.
+// Dynamic LDS: 2*K doubles (w and p_prev).
+template <typename T, int V, int R, int NT, int CPT>
+__global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
+    const T *src, i64 lds_, T *dst, i64 ldd, i64 N, int K, const T *__restrict__ tprev,
+    const double *__restrict__ pprev, const double *__restrict__ w, T *__restrict__ tout,
+    double *__restrict__ sspart) {
+    constexpr int RP = R / V, CG = NT / RP, NW = NT / WAVE;
+    extern __shared__ double dyn[];  // [2K]: w, p_prev
+    __shared__ double tred[2][NW][R];
+    __shared__ double sred[NW];
+    double *ws = dyn, *ps = dyn + K;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int rp = tid % RP, cg = tid / RP;
+    for (int k = tid; k < K; k += NT) {
+        ws[k] = w[k];
+        ps[k] = pprev[k];
+    }
+    __syncthreads();
+    const uint32_t soff = (uint32_t)(((i64)rp * V + (i64)cg * lds_) * (i64)sizeof(T));
+    const uint32_t doff = (uint32_t)(((i64)rp * V + (i64)cg * ldd) * (i64)sizeof(T));
+    constexpr uint32_t OOR = 0x80000000u;
+    const int ngroups = (K + CG - 1) / CG;
+    double ss = 0.0;
+    int buf = 0;
+    for (i64 tile = blockIdx.x; tile * R < N; tile += gridDim.x, buf ^= 1) {
+        const i64 i0 = tile * R + (i64)rp * V;
+        const bool rowok = (i0 < N);
+        const uint32_t so = rowok ? soff : OOR, dof = rowok ? doff : OOR;
+        double tp[V], tacc[V];
+        if (rowok) {
+            const Pack<T, V> tpk = ld_pack<T, V>(tprev + i0);
+#pragma unroll
+            for (int e = 0; e < V; ++e) tp[e] = -(double)tpk.v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) tp[e] = 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) tacc[e] = 0.0;
+        for (int g0 = 0; g0 < ngroups; g0 += CPT) {
+            Pack<T, V> x[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int cols = min(CG, K - CG * (g0 + j));
+                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * lds_ * (i64)sizeof(T)) : 0u;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<T *>(src + tile * R + (i64)(g0 + j) * CG * lds_), (short)0, (int)nrec, BUF_WORD3);
+                x[j] = buf_ld<T, V, AUX_NT>(rs, so);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int k = cg + CG * (g0 + j);
+                const double pk = (k < K) ? ps[k] : 0.0, wk = (k < K) ? ws[k] : 0.0;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    x[j].v[e] = (T)fma(tp[e], pk, (double)x[j].v[e]);
+                    tacc[e] = fma((double)x[j].v[e], wk, tacc[e]);
+                }
+                const int cols = min(CG, K - CG * (g0 + j));
+                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldd * (i64)sizeof(T)) : 0u;
+                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+                    dst + tile * R + (i64)(g0 + j) * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
+                buf_st<T, V, AUX_NT>(rd, dof, x[j]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+#pragma unroll
+            for (int m = RP; m < WAVE; m <<= 1) tacc[e] += shfl_xor_f64(tacc[e], m);
+        if (lane < RP)
+#pragma unroll
+            for (int e = 0; e < V; ++e) tred[buf][wv][rp * V + e] = tacc[e];
+        __syncthreads();
+        if (cg == 0 && rowok) {
+            Pack<T, V> o;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) s += tred[buf][q][rp * V + e];
+                o.v[e] = (T)s;
+                const double ts = (double)o.v[e];
+                ss = fma(ts, ts, ss);
+            }
+            st_pack<T, V>(tout + i0, o);
+        }
+    }
+    ss = block_sum<NW>(ss, sred);
+    if (tid == 0) sspart[blockIdx.x] = ss;
+}
+
+// rc as launch_fused_pass; *nss = number of t^T t partials written
+template <typename T>
+int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_, T *dst, i64 ldd, i64 N,
+                         int K, const T *tprev, const double *pprev, const double *w, T *tout,
+                         double *sspart, int max_rows, int *nss) {
+    constexpr int V = 16 / sizeof(T);
+    constexpr int R = 256 / sizeof(T), NT = 512, CPT = 8;
+    constexpr int CG = NT / (R / V);
+    auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
+    if (!al(src, lds_) || !al(dst, ldd) || !al(tprev, V) || !al(tout, V) || N < 1 || N % V != 0) return 1;
+    if ((i64)CG * lds_ * (i64)sizeof(T) >= (1ll << 31) || (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    const size_t dyn = (size_t)K * 16;  // w and p_prev
+    if (dyn > 72 * 1024) return 1;      // two workgroups per CU must fit the 160 KiB LDS
+    if (dyn > 48 * 1024) {
+        static bool raised = false;  // per instantiation
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&deflate_score_kernel<T, V, R, NT, CPT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess) {
+                (void)hipGetLastError();
+                return 1;
+            }
+            raised = true;
+        }
+    }
+    const i64 ntiles = (N + R - 1) / R;
+    const i64 grid = std::min<i64>(std::min<i64>(ntiles, 2 * (i64)num_cu), max_rows);
+    hipLaunchKernelGGL((deflate_score_kernel<T, V, R, NT, CPT>), dim3((unsigned)grid), dim3(NT), (size_t)K * 16,
+                       stream, src, lds_, dst, ldd, N, K, tprev, pprev, w, tout, sspart);
+    *nss = (int)grid;
+    return 0;
+}
+
 // rc as launch_fused_pass
 template <typename T>
 int launch_deflate_tile(hipStream_t stream, int num_cu, const T *src, i64 lds_, T *dst, i64 ldd, i64 N,

@@ -309,6 +309,26 @@ def test_extreme_shapes(handle, oracle, po, mode, N, K, M, A):
     check_against(po, out, ref, Bref, ref["T"], col_err=cerr, tol_inv=1e-7)
 
 
+@pytest.mark.parametrize("N,K,M,A", [(600, 1100, 2, 5), (257, 1500, 1, 4)])
+def test_wide_matrix(handle, oracle, po, mode, N, K, M, A):
+    """K beyond the resident-tile fused pass (fp64: K > 1024): the NIPALS plan takes the semi-fused
+    deflate+score sweep, the KERNEL plan the one-product kernels; same results."""
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    out = handle.fit_device(to_dev(Xh), to_dev(Yh), A); handle.synchronize()
+    check_against(po, out, ref, Bref, ref["T"], col_err=cerr)
+
+
+def test_wide_matrix_fp32(handle, oracle, po, mode):
+    torch = _torch()
+    N, K, M, A = 512, 2300, 3, 4
+    X = handle.synth_x(0, N, K, 11, dtype=torch.float32); Y = handle.synth_y(0, N, M, 11, dtype=torch.float32)
+    Xh = X.cpu().numpy().astype(np.float64); Yh = Y.cpu().numpy().astype(np.float64)
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    out = handle.fit_device(X, Y, A); handle.synchronize()
+    check_against(po, out, ref, Bref, ref["T"], tol_b=2e-5, tol_col=2e-5, col_err=cerr, tol_inv=1e-4)
+
+
 def test_padded_leading_dimensions(handle, oracle, po, mode):
     """ld > rows for X, Y and T (the C-ABI takes explicit leading dimensions)."""
     import ctypes
