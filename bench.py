@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--algo", default="nipals", choices=["nipals", "kernel"],
+    ap.add_argument("--algo", default="nipals", choices=["nipals", "kernel", "gram"],
                     help="nipals: north-star sequence with the rank-1 deflation of X (headline); "
                          "kernel: the reference's own sequence, X read-only")
     ap.add_argument("--fuse", type=int, default=1)
@@ -168,7 +168,7 @@ def main():
     Y = h.synth_y(row0, nrows, M, pls_amd.SEED_DEFAULT, dtype=tdt)
     if world > 1:
         attach_reducer(h, K, M)
-    algo = pls_amd.ALGO_NIPALS if a.algo == "nipals" else pls_amd.ALGO_KERNEL
+    algo = {"nipals": pls_amd.ALGO_NIPALS, "kernel": pls_amd.ALGO_KERNEL, "gram": pls_amd.ALGO_GRAM}[a.algo]
     h.set_option(pls_amd.OPT_ALGO, algo)
     h.set_option(pls_amd.OPT_FUSE, a.fuse)
     h.set_option(pls_amd.OPT_PROFILE, 1)
@@ -197,8 +197,10 @@ def main():
     if rank == 0 or world > 1:
         alt = {}
         if not a.no_alt and world == 1:
-            for name, (al, fu) in {"kernel_fused": (0, 1), "kernel_unfused": (0, 0), "nipals_fused": (1, 1),
-                                   "nipals_unfused": (1, 0)}.items():
+            plans = {"kernel_fused": (0, 1), "kernel_unfused": (0, 0), "nipals_fused": (1, 1), "nipals_unfused": (1, 0)}
+            if dt == "f64" and K <= 2048:
+                plans["gram_mfma_syrk"] = (2, 1)  # XX on the matrix cores + component loop on K x K + T = X R
+            for name, (al, fu) in plans.items():
                 if (al, fu) == (algo, a.fuse):
                     continue
                 h.set_option(pls_amd.OPT_ALGO, al)
@@ -207,6 +209,25 @@ def main():
                 st = max(2, a.steps // 2)
                 alt[name] = {"components_per_s": round(A * st / e2, 2), "ms_per_fit": round(e2 / st * 1e3, 3),
                              "roofline": roofline_of(t2)}
+            # METHOD::KERNEL_TYPE2 (XX = X^T X on the matrix cores, then no pass over X; T not computed)
+            if dt == "f64":
+                h.set_option(pls_amd.OPT_ALGO, 0)
+                st = max(2, a.steps // 2)
+                for _ in range(2):
+                    h.fit_device(X, Y, A, method=pls_amd.KERNEL_TYPE2, out=out)
+                torch.cuda.synchronize(); h.timing()
+                t0 = time.perf_counter()
+                for _ in range(st):
+                    h.fit_device(X, Y, A, method=pls_amd.KERNEL_TYPE2, out=out)
+                torch.cuda.synchronize()
+                e2 = time.perf_counter() - t0
+                t2 = h.timing()
+                n2 = max(t2["launches"]["xty"], 1)
+                syrk_ms = t2["ms"]["xty"] / t2["fits"] - tm["ms"]["xty"] / max(tm["fits"], 1)
+                alt["type2_mfma_syrk"] = {"components_per_s": round(A * st / e2, 2), "ms_per_fit": round(e2 / st * 1e3, 3),
+                                          "syrk_ms": round(syrk_ms, 3),
+                                          "syrk_tflops": round(2.0 * N * K * K / (syrk_ms * 1e-3) / 1e12, 2) if syrk_ms > 0 else None,
+                                          "note": "T (scores) not computed by this method"}
             # the stand-alone rank-1 deflation (the north star's "deflation step"), X -= t p^T in place
             h.set_option(pls_amd.OPT_ALGO, algo)
             h.set_option(pls_amd.OPT_FUSE, a.fuse)

@@ -72,8 +72,11 @@ typedef enum { PLS_HIP_MEM_HOST = 0, PLS_HIP_MEM_DEVICE = 1 } pls_hip_mem;
  *  KERNEL : the reference's operation sequence -- X is read-only, only the K x M matrix
  *           XY is deflated (src/pls.cpp:419-429).
  *  NIPALS : the north-star sequence -- t = X_a w, p = X_a^T t, then the rank-1 deflation
- *           X_{a+1} = X_a - t p^T on a library-owned working copy. */
-typedef enum { PLS_HIP_ALGO_KERNEL = 0, PLS_HIP_ALGO_NIPALS = 1 } pls_hip_algo;
+ *           X_{a+1} = X_a - t p^T on a library-owned working copy.
+ *  GRAM   : XX = X^T X once on the matrix cores (v_mfma_f64_16x16x4_f64 SYRK), the component loop on
+ *           K x K data as KERNEL_TYPE2 does (tt = r^T XX r, p = XX r / tt, src/pls.cpp:422-425), then
+ *           T = X R in one pass.  2 + A*0 passes over X; pays off when A exceeds ~K/50. */
+typedef enum { PLS_HIP_ALGO_KERNEL = 0, PLS_HIP_ALGO_NIPALS = 1, PLS_HIP_ALGO_GRAM = 2 } pls_hip_algo;
 
 typedef enum {
     PLS_HIP_OPT_ALGO = 1,       /* pls_hip_algo; default PLS_HIP_ALGO_KERNEL */

@@ -9,12 +9,14 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/pls_hip.h"
 #include "fused_kernels.hpp"
 #include "small_kernels.hpp"
 #include "stream_kernels.hpp"
+#include "syrk_kernels.hpp"
 #include "synth_kernels.hpp"
 
 using plsk::i64;
@@ -175,16 +177,16 @@ i64 max_partial_rows(pls_hip_context *c, i64 N, int K) {
 // ---- typed launchers --------------------------------------------------------------------
 template <typename T, int VEC, int MT>
 void launch_xb_t(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const double *Bm, i64 ldb,
-                 T *out, i64 ldo, double *sspart, int *nss) {
+                 int ncols, T *out, i64 ldo, double *sspart, int *nss) {
     const i64 per = (i64)plsk::WG * VEC;
     const int nblk = (int)((N + per - 1) / per);
-    if (sspart) {
-        hipLaunchKernelGGL((plsk::xb_kernel<T, VEC, MT, true>), dim3(nblk), dim3(plsk::WG), 0,
-                           c->stream, X, ldx, N, K, Bm, ldb, out, ldo, sspart);
+    if (sspart && MT == 1) {
+        hipLaunchKernelGGL((plsk::xb_kernel<T, VEC, 1, true>), dim3(nblk), dim3(plsk::WG), 0,
+                           c->stream, X, ldx, N, K, Bm, ldb, ncols, out, ldo, sspart);
         *nss = nblk;
     } else {
         hipLaunchKernelGGL((plsk::xb_kernel<T, VEC, MT, false>), dim3(nblk), dim3(plsk::WG), 0,
-                           c->stream, X, ldx, N, K, Bm, ldb, out, ldo, (double *)nullptr);
+                           c->stream, X, ldx, N, K, Bm, ldb, ncols, out, ldo, (double *)nullptr);
     }
 }
 
@@ -198,21 +200,40 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
     if (wide && N / ((i64)FV * plsk::WG) < 4 * (i64)c->num_cu) wide = false;
     int c0 = 0;
     while (c0 < C) {
-        const int mt = (C - c0 >= 4) ? 4 : (C - c0 >= 2 ? 2 : 1);
-        const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * mt * sizeof(T) + (i64)K * mt * 8;
+        // widest column tile first: X is read once per tile of up to 32 output columns
+        const int rem = C - c0;
+        // smallest tile >= rem, capped at 16 columns (32 fp64 accumulators per lane): the 32-column tile is
+        // VALU/occupancy-bound (measured 4.0 ms for 20 columns at C3 vs 1.5 ms as 16 + 4)
+        int mt = rem > 8 ? 16 : rem > 4 ? 8 : rem > 2 ? 4 : rem > 1 ? 2 : 1;
+        if (wide && FV * mt > 32) mt = 32 / FV;
+        const int use = std::min(mt, rem);  // a tile wider than what is left: the kernel masks columns >= use
+        const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
         Scope s(c, PLS_HIP_FAM_XB, bytes);
         const double *b = Bm + (i64)c0 * ldb;
         T *o = out + (i64)c0 * ldo;
-#define XB_CASE(V, M_)                                                                  \
-    launch_xb_t<T, V, M_>(c, X, ldx, N, K, b, ldb, o, ldo, sspart, nss)
+#define XB_CASE(V, M_) launch_xb_t<T, V, M_>(c, X, ldx, N, K, b, ldb, use, o, ldo, sspart, nss)
         if (wide) {
-            if (mt == 4) XB_CASE(FV, 4); else if (mt == 2) XB_CASE(FV, 2); else XB_CASE(FV, 1);
+            switch (mt) {
+                case 32: XB_CASE(FV, 32); break;
+                case 16: XB_CASE(FV, 16); break;
+                case 8: XB_CASE(FV, 8); break;
+                case 4: XB_CASE(FV, 4); break;
+                case 2: XB_CASE(FV, 2); break;
+                default: XB_CASE(FV, 1); break;
+            }
         } else {
-            if (mt == 4) XB_CASE(1, 4); else if (mt == 2) XB_CASE(1, 2); else XB_CASE(1, 1);
+            switch (mt) {
+                case 32: XB_CASE(1, 32); break;
+                case 16: XB_CASE(1, 16); break;
+                case 8: XB_CASE(1, 8); break;
+                case 4: XB_CASE(1, 4); break;
+                case 2: XB_CASE(1, 2); break;
+                default: XB_CASE(1, 1); break;
+            }
         }
 #undef XB_CASE
         LAUNCH_CHECK(c);
-        c0 += mt;
+        c0 += use;
     }
     return PLS_HIP_OK;
 }
@@ -324,7 +345,10 @@ int do_allreduce(pls_hip_context *c, double *buf, i64 count) {
 template <typename T>
 int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64 N, int K, int M,
                int A, int method, double *W, double *P, double *Q, double *R, T *Tm, i64 ldt, double *B) {
-    const bool type2 = (method == PLS_HIP_KERNEL_TYPE2);
+    // GRAM plan for a KERNEL_TYPE1 request: the K-sized loop runs on XX = X^T X exactly as KERNEL_TYPE2
+    // does (no pass over X per component), then the scores are formed in one pass, T = X R.
+    const bool gram = (method == PLS_HIP_KERNEL_TYPE1) && (c->opt_algo == PLS_HIP_ALGO_GRAM);
+    const bool type2 = (method == PLS_HIP_KERNEL_TYPE2) || gram;
     const bool nipals = !type2 && (c->opt_algo == PLS_HIP_ALGO_NIPALS);
     const i64 L0 = (i64)K * M;
     const i64 redn = (i64)plsk::RED_SLICES * std::max<i64>(L0, K + 1);
@@ -366,12 +390,40 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         constexpr int CB = 32;
         CHK(ensure(c, c->xx, (size_t)K * K * 8));
         CHK(ensure(c, c->praw, (size_t)K * 8));
-        CHK(ensure(c, c->part, (size_t)prow * (size_t)K * CB * 8));
-        CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * CB * 8));
-        part = (double *)c->part.p;
-        double *XX = (double *)c->xx.p, *red2 = (double *)c->red2.p, *praw = (double *)c->praw.p;
-        for (int c0 = 0; c0 < K; c0 += CB) {
+        double *XX = (double *)c->xx.p, *red2 = nullptr, *praw = (double *)c->praw.p;
+        bool have_xx = false;
+        if constexpr (std::is_same<T, double>::value) {
+            // matrix-core path: 128 x 128 blocks on v_mfma_f64_16x16x4_f64, row-split partial blocks
+            const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
+            const i64 S = std::max<i64>(1, (16 * (i64)c->num_cu + nbk * (nbk + 1) / 2 - 1) / (nbk * (nbk + 1) / 2));  // capacity bound
+            if (N > 0 && ensure(c, c->part, (size_t)S * K * K * 8) == PLS_HIP_OK &&
+                ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * K * 8) == PLS_HIP_OK) {
+                part = (double *)c->part.p;
+                red2 = (double *)c->red2.p;
+                int nb = 0;
+                int rc;
+                {
+                    Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) * ((nbk + 1)) + (i64)K * K * 8);
+                    rc = plsk::launch_syrk_f64(c->stream, c->num_cu, X, ldx, N, K, part, S * (i64)K * K, &nb);
+                    if (rc != 0) s.on = false;
+                }
+                if (rc == 0) {
+                    LAUNCH_CHECK(c);
+                    CHK(launch_reduce(c, part, nb, K * K, nullptr, 0, red2));
+                    CHK(do_allreduce(c, red2, (i64)plsk::RED_SLICES * K * K));
+                    hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((K * K + plsk::WG - 1) / plsk::WG), dim3(plsk::WG),
+                                       0, c->stream, (const double *)red2, K * K, XX);
+                    LAUNCH_CHECK(c);
+                    have_xx = true;
+                }
+            }
+        }
+        for (int c0 = 0; c0 < K && !have_xx; c0 += CB) {
             const int cb = std::min(CB, K - c0);
+            CHK(ensure(c, c->part, (size_t)prow * (size_t)K * CB * 8));
+            CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * CB * 8));
+            part = (double *)c->part.p;
+            red2 = (double *)c->red2.p;
             if (N > 0) {
                 int nb = 0;
                 CHK(launch_xty<T>(c, X, ldx, X + (i64)c0 * ldx, ldx, N, K, cb, part, &nb));
@@ -385,8 +437,12 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             LAUNCH_CHECK(c);
         }
         for (int a = 0; a < A; ++a) {
-            int nss = 0;
-            CHK(launch_xb<double>(c, XX, K, K, K, v, K, 1, praw, K, nullptr, &nss));  // XX symmetric: XX r
+            {
+                Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * K + 2 * K) * 8);
+                hipLaunchKernelGGL(plsk::symv_kernel, dim3((K + 3) / 4), dim3(plsk::WG), 0, c->stream,
+                                   (const double *)XX, (const double *)v, K, praw);  // XX symmetric: XX r
+                LAUNCH_CHECK(c);
+            }
             hipLaunchKernelGGL(plsk::type2_pack_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream,
                                (const double *)praw, (const double *)v, K, red);
             LAUNCH_CHECK(c);
@@ -396,6 +452,10 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             const int nblk = (int)((L0 + plsk::WG - 1) / plsk::WG);
             hipLaunchKernelGGL(plsk::coefficients_kernel, dim3(nblk), dim3(plsk::WG), 0, c->stream, R, Q, K, M, A, B);
             LAUNCH_CHECK(c);
+        }
+        if (gram && N > 0) {  // T = X R (src/pls.cpp:439-442 applied to the training data)
+            int nss = 0;
+            CHK(launch_xb<T>(c, X, ldx, N, K, R, K, A, Tm, ldt, nullptr, &nss));
         }
         return PLS_HIP_OK;
     }
@@ -566,7 +626,7 @@ int pls_hip_set_option(pls_hip_handle h, int option, int64_t value) {
     CHK(check_handle(h));
     switch (option) {
         case PLS_HIP_OPT_ALGO:
-            if (value != PLS_HIP_ALGO_KERNEL && value != PLS_HIP_ALGO_NIPALS)
+            if (value != PLS_HIP_ALGO_KERNEL && value != PLS_HIP_ALGO_NIPALS && value != PLS_HIP_ALGO_GRAM)
                 return fail(h, PLS_HIP_ERR_INVALID, "unknown algo");
             h->opt_algo = value;
             return PLS_HIP_OK;
@@ -664,6 +724,8 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
     if (K > (1 << 30) || M > (1 << 20) || (M > 1 && M > plsk::MMAX))
         return fail(h, PLS_HIP_ERR_UNSUPPORTED, "M > 32 responses (or K > 2^30) not supported on the device");
     if (N > 0 && (!X || !Y || (!T && method == PLS_HIP_KERNEL_TYPE1))) return fail(h, PLS_HIP_ERR_INVALID, "null X/Y/T");
+    if ((method == PLS_HIP_KERNEL_TYPE2 || h->opt_algo == PLS_HIP_ALGO_GRAM) && K > 16384)
+        return fail(h, PLS_HIP_ERR_UNSUPPORTED, "KERNEL_TYPE2 keeps a K x K matrix: K <= 16384");
     if (!W || !P || !Q || !R) return fail(h, PLS_HIP_ERR_INVALID, "null W/P/Q/R");
     if (ldx < std::max<i64>(N, 1) || ldy < std::max<i64>(N, 1) || (T && ldt < std::max<i64>(N, 1)))
         return fail(h, PLS_HIP_ERR_INVALID, "leading dimension smaller than N");

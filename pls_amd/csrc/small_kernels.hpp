@@ -236,6 +236,24 @@ __global__ __launch_bounds__(WG) void rotate_apply_kernel(const double *__restri
     vnext[k] = nipals ? w : r;
 }
 
+// praw = XX r for the symmetric K x K matrix XX (src/pls.cpp:424): one wave per output, reading
+// COLUMN k of XX (= row k by symmetry) contiguously.  grid = ceil(K/4) workgroups of 4 waves.
+__global__ __launch_bounds__(WG) void symv_kernel(const double *__restrict__ XX, const double *__restrict__ r,
+                                                  int K, double *__restrict__ praw) {
+    const int k = blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= K) return;
+    const double *col = XX + (i64)k * K;
+    double s0 = 0.0, s1 = 0.0;
+    int j = lane;
+    for (; j + WAVE < K; j += 2 * WAVE) {
+        s0 = fma(col[j], r[j], s0);
+        s1 = fma(col[j + WAVE], r[j + WAVE], s1);
+    }
+    if (j < K) s0 = fma(col[j], r[j], s0);
+    const double s = wave_sum(s0 + s1);
+    if (lane == 0) praw[k] = s;
+}
+
 // KERNEL_TYPE2 (src/pls.cpp:422-425): given praw = XX r, emit what component_update_kernel expects
 // from a pass -- red slice 0 = [praw (K), tt = r^T XX r], the other slices zero.
 __global__ __launch_bounds__(UPD_THREADS) void type2_pack_kernel(const double *__restrict__ praw,

@@ -14,12 +14,12 @@
 namespace plsk {
 
 // ------------------------------------------------------------------------------------
-// out[i, m] = sum_k X[i,k] * Bm[k + m*ldb],  m < MT.   One thread owns VEC consecutive rows.
+// out[i, m] = sum_k X[i,k] * Bm[k + m*ldb],  m < ncols <= MT.   One thread owns VEC consecutive rows.
 // SS: also emit sum_i out[i,0]^2 per workgroup (t^T t partial, src/pls.cpp:420).
 // ------------------------------------------------------------------------------------
 template <typename T, int VEC, int MT, bool SS>
 __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K,
-                                                const double *__restrict__ Bm, i64 ldb,
+                                                const double *__restrict__ Bm, i64 ldb, int ncols,
                                                 T *__restrict__ out, i64 ldo,
                                                 double *__restrict__ sspart) {
     __shared__ double red[WG / WAVE];
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const double b = Bm[(k + u) + m * ldb];
+                    const double b = (m < ncols) ? Bm[(k + u) + m * ldb] : 0.0;  // wave-uniform
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) acc[v][m] = fma((double)x[u].v[v], b, acc[v][m]);
                 }
@@ -51,18 +51,19 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
             Pack<T, VEC> x = ld_pack_nt<T, VEC>(xp + (i64)k * ldx);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const double b = Bm[k + m * ldb];
+                const double b = (m < ncols) ? Bm[k + m * ldb] : 0.0;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[v][m] = fma((double)x.v[v], b, acc[v][m]);
             }
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            Pack<T, VEC> o;
+        for (int m = 0; m < MT; ++m)
+            if (m < ncols) {
+                Pack<T, VEC> o;
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) o.v[v] = (T)acc[v][m];
-            st_pack<T, VEC>(out + i0 + m * ldo, o);
-        }
+                for (int v = 0; v < VEC; ++v) o.v[v] = (T)acc[v][m];
+                st_pack<T, VEC>(out + i0 + m * ldo, o);
+            }
     } else if (i0 < N) {  // ragged tail: element-wise
         const int nv = (int)(N - i0);
         for (int k = 0; k < K; ++k)
@@ -71,13 +72,15 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
                 if (v < nv) {
                     const double x = (double)X[i0 + v + (i64)k * ldx];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[v][m] = fma(x, Bm[k + m * ldb], acc[v][m]);
+                    for (int m = 0; m < MT; ++m)
+                        if (m < ncols) acc[v][m] = fma(x, Bm[k + m * ldb], acc[v][m]);
                 }
 #pragma unroll
         for (int v = 0; v < VEC; ++v)
             if (v < nv)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) out[i0 + v + m * ldo] = (T)acc[v][m];
+                for (int m = 0; m < MT; ++m)
+                    if (m < ncols) out[i0 + v + m * ldo] = (T)acc[v][m];
     }
     if (SS) {
         // the sum of squares uses the value as STORED (rounded to T), so that t^T t matches

@@ -1,0 +1,150 @@
+// XX = X^T X for KERNEL_TYPE2 (src/pls.cpp:398) -- the one contraction of the library that is
+// matrix-core shaped: 2*N*K^2 flops (550 GF at N = 2^20, K = 512) on K^2 outputs.
+//
+// v_mfma_f64_16x16x4_f64, D(16x16) += A(16x4) B(4x16): A rows = 16 columns a of X, B columns = 16
+// columns b of X, the contraction index = 4 rows of X.  Rows are the contiguous direction of the
+// column-major X, so operands cannot come straight from global memory (16 columns x 32 bytes per
+// wave-load); a workgroup stages a slab of RB = 32 rows x 128 columns per panel through LDS with
+// the tile access pattern (256-byte column segments), stored [column][row] with the row count
+// padded to 34 doubles so that the MFMA operand reads (lane: column l&15, row l>>4) hit 32 distinct
+// bank pairs per half-wave.
+//
+// Workgroup = 4 waves = one 128 x 128 block of XX (each wave a 64 x 64 quadrant = 4 x 4 MFMA tiles,
+// 64 fp64 accumulators per lane); 8 operand reads feed 16 MFMAs per 4-row step.  Only blocks on or
+// above the diagonal are computed (the mirror image is written from the same accumulators).  The
+// sum over rows is split over gridDim.y workgroups per block; their partial blocks are added by
+// reduce_partials_kernel in a fixed order.
+#pragma once
+#include "common.hpp"
+
+namespace plsk {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SYRK_TB = 128;  // block tile (columns of X per panel)
+constexpr int SYRK_RB = 32;   // rows per slab
+constexpr int SYRK_LDP = 34;  // padded slab rows in LDS (doubles)
+constexpr size_t SYRK_LDS_BYTES = 2 * (size_t)SYRK_TB * SYRK_LDP * sizeof(double);
+
+// blockIdx.x enumerates the nbk*(nbk+1)/2 blocks (bi <= bj); blockIdx.y = row split.
+__global__ __launch_bounds__(256, 2) void syrk_f64_kernel(const double *__restrict__ X, i64 ldx, i64 N,
+                                                          int K, int nbk, double *__restrict__ part) {
+    extern __shared__ double slab[];  // As[TB][LDP], Bs[TB][LDP]
+    double *As = slab, *Bs = slab + SYRK_TB * SYRK_LDP;
+
+    int bi = 0, rem = blockIdx.x;
+    while (rem >= nbk - bi) { rem -= nbk - bi; ++bi; }
+    const int bj = bi + rem;
+    const bool diag = (bi == bj);
+    if (diag) Bs = As;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // staging map: row pair rp (16 of them), column group cgi (16 of them); 8 columns per thread
+    const int rp = tid & 15, cgi = tid >> 4;
+    // compute map
+    const int a0 = (wv >> 1) * 64, b0 = (wv & 1) * 64;
+    const int li = lane & 15, lq = lane >> 4;
+
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    const i64 nslabs = (N + SYRK_RB - 1) / SYRK_RB;
+    Pack<double, 2> ga[8], gb[8];
+
+    auto load_slab = [&](i64 s) {
+        const i64 r0 = s * SYRK_RB + 2 * rp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ca = bi * SYRK_TB + cgi + 16 * j, cb = bj * SYRK_TB + cgi + 16 * j;
+            ga[j].v[0] = ga[j].v[1] = 0.0;
+            gb[j].v[0] = gb[j].v[1] = 0.0;
+            if (r0 + 1 < N) {  // N is even (launcher): a row pair is all-valid or all-invalid
+                if (ca < K) ga[j] = ld_pack_nt<double, 2>(X + r0 + (i64)ca * ldx);
+                if (!diag && cb < K) gb[j] = ld_pack_nt<double, 2>(X + r0 + (i64)cb * ldx);
+            }
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cgi + 16 * j;
+            *reinterpret_cast<Pack<double, 2> *>(As + c * SYRK_LDP + 2 * rp) = ga[j];
+            if (!diag) *reinterpret_cast<Pack<double, 2> *>(Bs + c * SYRK_LDP + 2 * rp) = gb[j];
+        }
+    };
+
+    // No software prefetch: the 64 staging registers would not fit beside the 128 accumulator
+    // registers without spilling (measured: 6.8 ms with prefetch + spills, 6.5 ms without); the
+    // second workgroup on the CU covers the load phase instead.
+    for (i64 s = blockIdx.y; s < nslabs; s += gridDim.y) {
+        load_slab(s);
+        __syncthreads();  // everyone is done reading the previous slab
+        store_slab();
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < SYRK_RB; kk += 4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = As[(a0 + 16 * m + li) * SYRK_LDP + kk + lq];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[n] = Bs[(b0 + 16 * n + li) * SYRK_LDP + kk + lq];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+    }
+
+    // f64 C/D layout: lane holds D[row = (lane>>4) + 4*reg][col = lane&15]; row <-> a, col <-> b
+    double *out = part + (i64)blockIdx.y * ((i64)K * K);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ga_ = bi * SYRK_TB + a0 + 16 * m + lq + 4 * r;
+                const int gb_ = bj * SYRK_TB + b0 + 16 * n + li;
+                if (ga_ < K && gb_ < K) {
+                    const double v = acc[m][n][r];
+                    out[ga_ + (i64)gb_ * K] = v;
+                    if (!diag) out[gb_ + (i64)ga_ * K] = v;  // the mirror block
+                }
+            }
+}
+
+// rc: 0 launched (part holds *nb partial K x K matrices), 1 shape not covered
+inline int launch_syrk_f64(hipStream_t stream, int num_cu, const double *X, i64 ldx, i64 N, int K,
+                           double *part, i64 part_capacity_doubles, int *nb) {
+    if (((uintptr_t)X % 16) != 0 || (ldx % 2) != 0 || (N % 2) != 0 || N < 2) return 1;
+    const int nbk = (K + SYRK_TB - 1) / SYRK_TB;
+    const int nblocks = nbk * (nbk + 1) / 2;
+    const i64 nslabs = (N + SYRK_RB - 1) / SYRK_RB;
+    // Row split: all workgroups resident at once (2 per CU) when the blocks allow it -- a grid that is
+    // one workgroup over a residency wave takes twice as long (measured: 520 workgroups 10.0 ms, 510
+    // workgroups 6.5 ms) -- otherwise at least ~8 waves so that the tail is small.
+    const i64 slots = 2 * (i64)num_cu;
+    i64 S = nblocks <= slots ? slots / nblocks : (8 * slots + nblocks - 1) / nblocks;
+    S = std::max<i64>(1, std::min<i64>(S, nslabs));
+    S = std::min<i64>(S, part_capacity_doubles / ((i64)K * K));
+    if (S < 1) return 1;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_f64_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYRK_LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;
+        }
+        raised = true;
+    }
+    hipLaunchKernelGGL(syrk_f64_kernel, dim3(nblocks, (unsigned)S), dim3(256), SYRK_LDS_BYTES, stream, X, ldx, N, K,
+                       nbk, part);
+    *nb = (int)S;
+    return 0;
+}
+
+}  // namespace plsk

@@ -62,7 +62,8 @@ def golden_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "s_*.npz")))
 
 
-@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1)], ids=["kernel-unfused", "kernel-fused", "nipals-unfused", "nipals-fused"])
+@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1), (2, 1)],
+                ids=["kernel-unfused", "kernel-fused", "nipals-unfused", "nipals-fused", "gram"])
 def mode(request, handle):
     import pls_amd
     algo, fuse = request.param
@@ -373,8 +374,8 @@ def test_full_size_properties(handle, po):
     N, K, M, A = 1 << 20, 512, 1, 4
     X = handle.synth_x(0, N, K, pls_amd.SEED_DEFAULT); Y = handle.synth_y(0, N, M, pls_amd.SEED_DEFAULT)
     outs = {}
-    for algo in (0, 1):
-        for fuse in (0, 1):
+    for algo, fuses in ((0, (0, 1)), (1, (0, 1)), (2, (1,))):
+        for fuse in fuses:
             handle.set_option(pls_amd.OPT_ALGO, algo); handle.set_option(pls_amd.OPT_FUSE, fuse)
             outs[(algo, fuse)] = handle.fit_device(X, Y, A)
             handle.synchronize()
