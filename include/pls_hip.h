@@ -27,6 +27,9 @@
  * All results are real: the reference's std::complex containers (include/PLS/pls.h:26-27)
  * always hold zero imaginary parts and are rebuilt at the C++ boundary.
  *
+ * A handle is not thread-safe: one caller at a time per handle (the reference's Model has no shared
+ * state either; use one handle per host thread, handles are independent).
+ *
  * No torch types, no C++ types, no exceptions cross this boundary; every entry point
  * returns a pls_hip_status and never calls exit().  There is NO CPU fallback: without a
  * gfx950 device every compute entry point fails with PLS_HIP_ERR_DEVICE.
@@ -150,7 +153,7 @@ PLS_HIP_API int pls_hip_get_timing(pls_hip_handle h, pls_hip_timing *out);
  * mem == HOST: pointers are host memory; the call copies in, fits, copies out and returns
  * with the results in place.
  * Shapes follow the reference's asserts (src/pls.cpp:345-347): 1 <= A <= K, N >= 1
- * (N may be 0 on a rank of a sharded fit), M >= 1 (M <= 32 when M > 1).
+ * (N may be 0 on a rank of a sharded fit), M >= 1 (M <= 32 when M > 1), A <= 6144.
  * A > rank(X) yields inf/NaN in the surplus columns, as in the reference (:427-428).
  */
 PLS_HIP_API int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy,

@@ -61,9 +61,12 @@ __global__ __launch_bounds__(256, 2) void syrk_f64_kernel(const double *__restri
             const int ca = bi * SYRK_TB + cgi + 16 * j, cb = bj * SYRK_TB + cgi + 16 * j;
             ga[j].v[0] = ga[j].v[1] = 0.0;
             gb[j].v[0] = gb[j].v[1] = 0.0;
-            if (r0 + 1 < N) {  // N is even (launcher): a row pair is all-valid or all-invalid
+            if (r0 + 1 < N) {
                 if (ca < K) ga[j] = ld_pack_nt<double, 2>(X + r0 + (i64)ca * ldx);
                 if (!diag && cb < K) gb[j] = ld_pack_nt<double, 2>(X + r0 + (i64)cb * ldx);
+            } else if (r0 < N) {  // odd N: the last row has no partner, its slot stays zero
+                if (ca < K) ga[j].v[0] = X[r0 + (i64)ca * ldx];
+                if (!diag && cb < K) gb[j].v[0] = X[r0 + (i64)cb * ldx];
             }
         }
     };
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void syrk_f64_kernel(const double *__restri
 // rc: 0 launched (part holds *nb partial K x K matrices), 1 shape not covered
 inline int launch_syrk_f64(hipStream_t stream, int num_cu, const double *X, i64 ldx, i64 N, int K,
                            double *part, i64 part_capacity_doubles, int *nb) {
-    if (((uintptr_t)X % 16) != 0 || (ldx % 2) != 0 || (N % 2) != 0 || N < 2) return 1;
+    if (((uintptr_t)X % 16) != 0 || (ldx % 2) != 0 || N < 1) return 1;
     const int nbk = (K + SYRK_TB - 1) / SYRK_TB;
     const int nblocks = nbk * (nbk + 1) / 2;
     const i64 nslabs = (N + SYRK_RB - 1) / SYRK_RB;
