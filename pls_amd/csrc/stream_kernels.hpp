@@ -30,6 +30,12 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[v][m] = 0.0;
 
+    // columns m >= ncols of a partially used tile read a valid column again and are never stored:
+    // no conditional loads (the masked form compiled to a branch per scalar load)
+    i64 boff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) boff[m] = (i64)min(m, ncols - 1) * ldb;
+
     if (i0 + VEC <= N) {
         const T *xp = X + i0;
         constexpr int U = 8;
@@ -42,7 +48,7 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const double b = (m < ncols) ? Bm[(k + u) + m * ldb] : 0.0;  // wave-uniform
+                    const double b = Bm[(k + u) + boff[m]];  // wave-uniform: scalar load
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) acc[v][m] = fma((double)x[u].v[v], b, acc[v][m]);
                 }
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
             Pack<T, VEC> x = ld_pack_nt<T, VEC>(xp + (i64)k * ldx);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const double b = (m < ncols) ? Bm[k + m * ldb] : 0.0;
+                const double b = Bm[k + boff[m]];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[v][m] = fma((double)x.v[v], b, acc[v][m]);
             }

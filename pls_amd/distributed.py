@@ -41,20 +41,30 @@ def attach_reducer(handle, K: int, M: int, group=None):
     dev = torch.device("cuda", handle.device)
     stage = torch.zeros(count, dtype=torch.float64, device=dev)
     backend = dist.get_backend(group)
-    host = torch.zeros(count, dtype=torch.float64).pin_memory() if backend != "nccl" else None
+    host = {"buf": torch.zeros(count, dtype=torch.float64).pin_memory()} if backend != "nccl" else None
     base = stage.data_ptr()
+
+    class _Raw:  # zero-copy view of a library-owned device buffer (CUDA array interface, v2)
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
     def _cb(_user, buf, n, _stream):
         try:
             off = (int(buf) - base) // 8
-            view = stage[off:off + n]
+            if 0 <= off and off + n <= count and (int(buf) - base) % 8 == 0:
+                view = stage[off:off + n]           # the staging tensor handed over with set_reduce_buffer
+            else:                                   # other reductions (X^T X blocks, column statistics, SSE)
+                view = torch.as_tensor(_Raw(int(buf), int(n)), device=dev)
             if backend == "nccl":
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
             else:
+                if host["buf"].numel() < n:  # bounce buffer grows with the largest message
+                    host["buf"] = torch.zeros(int(n), dtype=torch.float64).pin_memory()
+                hb = host["buf"][:n]
                 torch.cuda.current_stream(dev).synchronize()
-                host[:n].copy_(view)
-                dist.all_reduce(host[:n], op=dist.ReduceOp.SUM, group=group)
-                view.copy_(host[:n], non_blocking=False)
+                hb.copy_(view)
+                dist.all_reduce(hb, op=dist.ReduceOp.SUM, group=group)
+                view.copy_(hb, non_blocking=False)
             return 0
         except Exception:  # an exception must not unwind through the C frame
             import traceback

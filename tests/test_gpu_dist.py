@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, N, K, M, A, algo, fuse, q):
+def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import torch
@@ -37,10 +37,19 @@ def _worker(rank, world, port, N, K, M, A, algo, fuse, q):
         X = h.synth_x(row0, nrows, K, pls_amd.SEED_DEFAULT)
         Y = h.synth_y(row0, nrows, M, pls_amd.SEED_DEFAULT)
         attach_reducer(h, K, M)
-        out = h.fit_device(X, Y, A)
+        out = h.fit_device(X, Y, A, method=method)
         h.synchronize()
-        q.put((rank, {k: v.cpu().numpy() for k, v in out.items()}))
+        res = {k: v.cpu().numpy() for k, v in out.items()}
+        # sharded pre-processing and metrics use the same reducer (column statistics over all rows)
+        Z, mean, sd = h.colwise_z_scores(X, n_total=N)
+        h.synchronize()
+        res["mean"] = mean.cpu().numpy(); res["sd"] = sd.cpu().numpy()
+        q.put((rank, res))
         h.close()
+    except BaseException:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -57,7 +66,8 @@ def test_sharded_fit_matches_oracle(N, K, M, A, world, algo, fuse):
     procs = [ctx.Process(target=_worker, args=(r, world, port, N, K, M, A, algo, fuse, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    assert not any("error" in r[1] for r in res), [r[1].get("error") for r in res]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -75,6 +85,37 @@ def test_sharded_fit_matches_oracle(N, K, M, A, world, algo, fuse):
     lim = np.maximum(1e-9, 20 * po.column_errors(ref, alt))
     err = np.linalg.norm(T * s - ref["T"], axis=0) / np.linalg.norm(ref["T"], axis=0)
     assert (err <= lim).all()
+
+
+@pytest.mark.parametrize("algo,method", [(2, 0), (0, 1)], ids=["gram", "kernel_type2"])
+def test_sharded_gram_and_type2(algo, method):
+    """the X^T X partial blocks (8*K*K values, a library-owned buffer) go through the same reducer"""
+    import torch.multiprocessing as mp
+    from oracle import pls_oracle as po
+    N, K, M, A, world = 3000, 130, 2, 6, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, K, M, A, algo, 1, q, method)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    assert not any("error" in r[1] for r in res), [r[1].get("error") for r in res]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ora = po.OracleLib()
+    X = ora.synth_x(0, N, K); Y = ora.synth_y(0, N, M)
+    ref = ora.plsr(X, Y, A)
+    for rank, out in res:
+        assert po.rel_fro(out["B"], ora.coefficients(ref["R"], ref["Q"])) < 1e-10
+        assert np.array_equal(out["W"], res[0][1]["W"])
+        assert np.allclose(out["mean"], X.mean(0), rtol=1e-12, atol=1e-13)
+        assert np.allclose(out["sd"], X.std(0, ddof=1), rtol=1e-11)
+    if method == 0:
+        T = np.concatenate([out["T"] for _, out in res], axis=0)
+        s = po.sign_align(ref["W"], res[0][1]["W"])
+        assert po.rel_fro(T * s, ref["T"]) < 1e-8
 
 
 def _nccl_worker(port, q):
