@@ -399,3 +399,31 @@ def test_full_size_properties(handle, po):
     rows = slice(123456, 123456 + 2048)
     Xs = X[rows].cpu().numpy()
     assert po.rel_fro(T[rows, 0].cpu().numpy(), Xs @ R[:, 0]) < 1e-12
+
+
+def test_full_size_config4_fp32(handle, po):
+    """BASELINE config 4 at full size (131,072 x 4,096 fp32, m = 8): the plans agree with each other,
+    scores are orthogonal, P^T R = I -- fp32 storage tolerances."""
+    import pls_amd
+    torch = _torch()
+    N, K, M, A = 131072, 4096, 8, 5
+    X = handle.synth_x(0, N, K, pls_amd.SEED_DEFAULT, dtype=torch.float32)
+    Y = handle.synth_y(0, N, M, pls_amd.SEED_DEFAULT, dtype=torch.float32)
+    outs = {}
+    for algo, fuse in ((0, 1), (1, 1), (1, 0)):
+        handle.set_option(pls_amd.OPT_ALGO, algo); handle.set_option(pls_amd.OPT_FUSE, fuse)
+        outs[(algo, fuse)] = handle.fit_device(X, Y, A)
+        handle.synchronize()
+    handle.set_option(pls_amd.OPT_ALGO, 0); handle.set_option(pls_amd.OPT_FUSE, 1)
+    Bb = outs[(0, 1)]["B"].cpu().numpy()
+    assert np.isfinite(Bb).all()
+    for key, o in outs.items():
+        assert po.rel_fro(o["B"].cpu().numpy(), Bb) < 2e-5, key
+    base = outs[(0, 1)]
+    P = base["P"].cpu().numpy(); R = base["R"].cpu().numpy()
+    assert np.allclose(P.T @ R, np.eye(A), atol=1e-4)
+    T = base["T"].to(torch.float64)
+    G = (T.t() @ T).cpu().numpy()
+    assert np.abs(G - np.diag(np.diag(G))).max() < 1e-4 * np.diag(G).max()
+    rows = slice(77777, 77777 + 512)
+    assert po.rel_fro(T[rows, 0].cpu().numpy(), X[rows].cpu().numpy().astype(np.float64) @ R[:, 0]) < 1e-5
