@@ -201,6 +201,21 @@ PLS_HIP_API int pls_hip_model_sse(pls_hip_handle h, const void *X, int64_t ldx, 
                                   int64_t N, int64_t K, int64_t M, int64_t A, const double *R,
                                   const double *Q, int dtype, int mem, double *SSE);
 
+/*
+ * Cross-validation folds in one batched launch (Model::cv_LOO / cv_LSO,
+ * src/pls.cpp:469-549).  Fold f refits A components on every row EXCEPT test_idx[f*test_size .. +test_size)
+ * and records the residuals of those test rows:
+ *     E[m*(nobs*A) + (f*test_size + i) + c*nobs] = Y[row, m] - x_row^T B_{c+1}^{(f)},   nobs = num_folds*test_size
+ * i.e. M matrices of nobs x A, the layout of PLS::Residual::errors().  Leave-one-out = test_size 1,
+ * num_folds N, test_idx = 0..N-1.  test_idx is HOST memory (distinct indices within a fold); X, Y, E follow
+ * `mem`.  All folds share XX = X^T X and XY = X^T Y formed once; a fold works on
+ * XX - X_test^T X_test applied on the fly (the KERNEL_TYPE2 recurrence, src/pls.cpp:422-425): no per-fold
+ * pass over X.  fp64, single rank.  The call returns after the work has completed.
+ */
+PLS_HIP_API int pls_hip_cv_folds(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy,
+                                 int64_t N, int64_t K, int64_t M, int64_t A, const int64_t *test_idx,
+                                 int64_t test_size, int64_t num_folds, int dtype, int mem, double *E);
+
 /* ---- synthetic inputs, generated on the device (DESIGN.md "Synthetic inputs") ------ */
 
 /* rows [row0, row0+nrows) of the global matrix -> X (nrows x K, ld ldx) / Y (nrows x M) */

@@ -68,6 +68,7 @@ PROTOTYPES = [
     ("pls_hip_colwise_z_scores", _int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp]),
     ("pls_hip_sse_by_components", _int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
     ("pls_hip_model_sse", _int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _int, _vp]),
+    ("pls_hip_cv_folds", _int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _int, _int, _vp]),
     ("pls_hip_synth_x", _int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_uint64, _int]),
     ("pls_hip_synth_y", _int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_uint64, _int]),
 ]

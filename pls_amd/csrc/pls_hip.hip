@@ -17,6 +17,7 @@
 #include "small_kernels.hpp"
 #include "stream_kernels.hpp"
 #include "syrk_kernels.hpp"
+#include "cv_kernels.hpp"
 #include "synth_kernels.hpp"
 
 using plsk::i64;
@@ -46,7 +47,7 @@ struct pls_hip_context {
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
     i64 opt_fused_grid = 0;
-    DevBuf part, sspart, red, red2, xx, praw, xy, v, cs, tab, work, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
+    DevBuf part, sspart, red, red2, xx, praw, xy, v, cs, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
     std::vector<hipEvent_t> ev_pool;  // grows until pls_hip_get_timing harvests and recycles it
@@ -341,6 +342,61 @@ int do_allreduce(pls_hip_context *c, double *buf, i64 count) {
     return PLS_HIP_OK;
 }
 
+// XX(K x K, fp64) = X^T X summed over ranks: matrix-core SYRK when the layout allows it, otherwise the
+// column-reduction kernel in 32-column blocks.  Uses c->part / c->red2 as scratch.
+template <typename T>
+int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX) {
+    constexpr int CB = 32;
+    double *part = nullptr, *red2 = nullptr;
+    const i64 prow = max_partial_rows(c, N, K);
+    bool have_xx = false;
+    if constexpr (std::is_same<T, double>::value) {
+        // matrix-core path: 128 x 128 blocks on v_mfma_f64_16x16x4_f64, row-split partial blocks
+        const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
+        const i64 S = std::max<i64>(1, (16 * (i64)c->num_cu + nbk * (nbk + 1) / 2 - 1) / (nbk * (nbk + 1) / 2));  // capacity bound
+        if (N > 0 && ensure(c, c->part, (size_t)S * K * K * 8) == PLS_HIP_OK &&
+            ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * K * 8) == PLS_HIP_OK) {
+            part = (double *)c->part.p;
+            red2 = (double *)c->red2.p;
+            int nb = 0;
+            int rc;
+            {
+                Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) * ((nbk + 1)) + (i64)K * K * 8);
+                rc = plsk::launch_syrk_f64(c->stream, c->num_cu, X, ldx, N, K, part, S * (i64)K * K, &nb);
+                if (rc != 0) s.on = false;
+            }
+            if (rc == 0) {
+                LAUNCH_CHECK(c);
+                CHK(launch_reduce(c, part, nb, K * K, nullptr, 0, red2));
+                CHK(do_allreduce(c, red2, (i64)plsk::RED_SLICES * K * K));
+                hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((K * K + plsk::WG - 1) / plsk::WG), dim3(plsk::WG),
+                                   0, c->stream, (const double *)red2, K * K, XX);
+                LAUNCH_CHECK(c);
+                have_xx = true;
+            }
+        }
+    }
+    for (int c0 = 0; c0 < K && !have_xx; c0 += CB) {
+        const int cb = std::min(CB, K - c0);
+        CHK(ensure(c, c->part, (size_t)prow * (size_t)K * CB * 8));
+        CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * CB * 8));
+        part = (double *)c->part.p;
+        red2 = (double *)c->red2.p;
+        if (N > 0) {
+            int nb = 0;
+            CHK(launch_xty<T>(c, X, ldx, X + (i64)c0 * ldx, ldx, N, K, cb, part, &nb));
+            CHK(launch_reduce(c, part, nb, K * cb, nullptr, 0, red2));
+        } else {
+            HIPCHK(c, hipMemsetAsync(red2, 0, (size_t)plsk::RED_SLICES * K * cb * 8, c->stream));
+        }
+        CHK(do_allreduce(c, red2, (i64)plsk::RED_SLICES * K * cb));
+        hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((K * cb + plsk::WG - 1) / plsk::WG), dim3(plsk::WG), 0,
+                           c->stream, (const double *)red2, K * cb, XX + (i64)c0 * K);
+        LAUNCH_CHECK(c);
+    }
+    return PLS_HIP_OK;
+}
+
 // ---- the fit on device pointers -----------------------------------------------------------
 template <typename T>
 int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64 N, int K, int M,
@@ -387,55 +443,10 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         // KERNEL_TYPE2 (src/pls.cpp:398, :422-425): XX = X^T X once, then the A-loop never touches X:
         // tt = r^T XX r, p = XX r / tt; T is not computed.  XX is formed in 32-column blocks with the
         // same column-reduction kernel as X^T Y (functional; an MFMA SYRK is the planned fast form).
-        constexpr int CB = 32;
         CHK(ensure(c, c->xx, (size_t)K * K * 8));
         CHK(ensure(c, c->praw, (size_t)K * 8));
-        double *XX = (double *)c->xx.p, *red2 = nullptr, *praw = (double *)c->praw.p;
-        bool have_xx = false;
-        if constexpr (std::is_same<T, double>::value) {
-            // matrix-core path: 128 x 128 blocks on v_mfma_f64_16x16x4_f64, row-split partial blocks
-            const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
-            const i64 S = std::max<i64>(1, (16 * (i64)c->num_cu + nbk * (nbk + 1) / 2 - 1) / (nbk * (nbk + 1) / 2));  // capacity bound
-            if (N > 0 && ensure(c, c->part, (size_t)S * K * K * 8) == PLS_HIP_OK &&
-                ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * K * 8) == PLS_HIP_OK) {
-                part = (double *)c->part.p;
-                red2 = (double *)c->red2.p;
-                int nb = 0;
-                int rc;
-                {
-                    Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) * ((nbk + 1)) + (i64)K * K * 8);
-                    rc = plsk::launch_syrk_f64(c->stream, c->num_cu, X, ldx, N, K, part, S * (i64)K * K, &nb);
-                    if (rc != 0) s.on = false;
-                }
-                if (rc == 0) {
-                    LAUNCH_CHECK(c);
-                    CHK(launch_reduce(c, part, nb, K * K, nullptr, 0, red2));
-                    CHK(do_allreduce(c, red2, (i64)plsk::RED_SLICES * K * K));
-                    hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((K * K + plsk::WG - 1) / plsk::WG), dim3(plsk::WG),
-                                       0, c->stream, (const double *)red2, K * K, XX);
-                    LAUNCH_CHECK(c);
-                    have_xx = true;
-                }
-            }
-        }
-        for (int c0 = 0; c0 < K && !have_xx; c0 += CB) {
-            const int cb = std::min(CB, K - c0);
-            CHK(ensure(c, c->part, (size_t)prow * (size_t)K * CB * 8));
-            CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * CB * 8));
-            part = (double *)c->part.p;
-            red2 = (double *)c->red2.p;
-            if (N > 0) {
-                int nb = 0;
-                CHK(launch_xty<T>(c, X, ldx, X + (i64)c0 * ldx, ldx, N, K, cb, part, &nb));
-                CHK(launch_reduce(c, part, nb, K * cb, nullptr, 0, red2));
-            } else {
-                HIPCHK(c, hipMemsetAsync(red2, 0, (size_t)plsk::RED_SLICES * K * cb * 8, c->stream));
-            }
-            CHK(do_allreduce(c, red2, (i64)plsk::RED_SLICES * K * cb));
-            hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((K * cb + plsk::WG - 1) / plsk::WG), dim3(plsk::WG), 0,
-                               c->stream, (const double *)red2, K * cb, XX + (i64)c0 * K);
-            LAUNCH_CHECK(c);
-        }
+        double *XX = (double *)c->xx.p, *praw = (double *)c->praw.p;
+        CHK(compute_xx<T>(c, X, ldx, N, K, XX));
         for (int a = 0; a < A; ++a) {
             {
                 Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * K + 2 * K) * 8);
@@ -605,7 +616,8 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->tab, &h->work, &h->hX, &h->hY,
+    DevBuf *bufs[] = {&h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->tab,
+                      &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -973,6 +985,74 @@ int pls_hip_sse_by_components(pls_hip_handle h, const void *S, int64_t lds, cons
     if (dtype == PLS_HIP_F64)
         return sse_device<double>(h, (const double *)S, lds, (const double *)Y, ldy, N, (int)A, (int)M, Q, SSE);
     return sse_device<float>(h, (const float *)S, lds, (const float *)Y, ldy, N, (int)A, (int)M, Q, SSE);
+}
+
+int pls_hip_cv_folds(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy, int64_t N,
+                     int64_t K, int64_t M, int64_t A, const int64_t *test_idx, int64_t test_size,
+                     int64_t num_folds, int dtype, int mem, double *E) {
+    CHK(check_handle(h));
+    if (dtype != PLS_HIP_F64) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "cv_folds: fp64 only");
+    if (mem != PLS_HIP_MEM_HOST && mem != PLS_HIP_MEM_DEVICE) return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
+    if (h->reducer) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "cv_folds: not available on a sharded handle");
+    if (N < 2 || K < 1 || M < 1 || A < 1 || A > K || A > 6144 || K > 16384 || (M > 1 && M > plsk::MMAX) || !X || !Y ||
+        !test_idx || !E || test_size < 1 || test_size >= N || num_folds < 1 || ldx < N || ldy < N ||
+        num_folds > (1 << 22) || test_size > (1 << 20))
+        return fail(h, PLS_HIP_ERR_INVALID, "bad cv_folds arguments");
+    const i64 nobs = num_folds * test_size;
+    for (i64 j = 0; j < nobs; ++j)
+        if (test_idx[j] < 0 || test_idx[j] >= N) return fail(h, PLS_HIP_ERR_INVALID, "cv_folds: test index out of range");
+    CHK(set_device(h));
+    const int Ki = (int)K, Mi = (int)M, Ai = (int)A, ts = (int)test_size;
+    const double *dX = (const double *)X, *dY = (const double *)Y;
+    i64 dldx = ldx, dldy = ldy;
+    if (mem == PLS_HIP_MEM_HOST) {
+        const i64 ldn = N + (N & 1);
+        CHK(ensure(h, h->hX, (size_t)ldn * K * 8));
+        CHK(ensure(h, h->hY, (size_t)ldn * M * 8));
+        CHK(h2d(h, h->hX.p, ldn, X, ldx, N, K, 8));
+        CHK(h2d(h, h->hY.p, ldn, Y, ldy, N, M, 8));
+        dX = (const double *)h->hX.p; dY = (const double *)h->hY.p;
+        dldx = dldy = ldn;
+    }
+    const plsk::CvLayout L(Ki, Mi, Ai, ts);
+    CHK(ensure(h, h->xx, (size_t)K * K * 8));
+    CHK(ensure(h, h->xy, (size_t)K * M * 8));
+    CHK(ensure(h, h->cvidx, (size_t)nobs * 8));
+    CHK(ensure(h, h->cvx, (size_t)nobs * K * 8));
+    CHK(ensure(h, h->cvy, (size_t)nobs * M * 8));
+    CHK(ensure(h, h->cvws, (size_t)num_folds * (size_t)L.total * 8));
+    CHK(ensure(h, h->cve, (size_t)nobs * A * M * 8));
+    double *XX = (double *)h->xx.p, *XYd = (double *)h->xy.p;
+    // XX and XY of the whole matrix, once
+    CHK(compute_xx<double>(h, dX, dldx, N, Ki, XX));
+    {
+        CHK(ensure(h, h->part, (size_t)max_partial_rows(h, N, Ki) * (size_t)(K * M) * 8));
+        CHK(ensure(h, h->red, (size_t)plsk::RED_SLICES * std::max<i64>(K * M, K + 1) * 8));
+        int nb = 0;
+        CHK(launch_xty<double>(h, dX, dldx, dY, dldy, N, Ki, Mi, (double *)h->part.p, &nb));
+        CHK(launch_reduce(h, (const double *)h->part.p, nb, Ki * Mi, nullptr, 0, (double *)h->red.p));
+        hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((Ki * Mi + plsk::WG - 1) / plsk::WG), dim3(plsk::WG), 0,
+                           h->stream, (const double *)h->red.p, Ki * Mi, XYd);
+        LAUNCH_CHECK(h);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->cvidx.p, test_idx, (size_t)nobs * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(plsk::cv_gather_kernel, dim3((unsigned)nobs), dim3(plsk::WG), 0, h->stream, dX, dldx, dY, dldy,
+                       Ki, Mi, (const i64 *)h->cvidx.p, (double *)h->cvx.p, (double *)h->cvy.p);
+    LAUNCH_CHECK(h);
+    double *dE = (mem == PLS_HIP_MEM_HOST) ? (double *)h->cve.p : E;
+    {
+        Scope s(h, PLS_HIP_FAM_SMALL, (i64)num_folds * A * ((i64)K * K + 4 * K) * 8);
+        hipLaunchKernelGGL(plsk::cv_folds_kernel, dim3((unsigned)num_folds), dim3(plsk::UPD_THREADS), (size_t)A * 8,
+                           h->stream, (const double *)XX, (const double *)XYd, (const double *)h->cvx.p,
+                           (const double *)h->cvy.p, Ki, Mi, Ai, ts, (double *)h->cvws.p, dE, (int)h->opt_power_iters);
+        LAUNCH_CHECK(h);
+    }
+    if (mem == PLS_HIP_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(E, dE, (size_t)nobs * A * M * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    // the index list is host memory of the caller: the copy above must have consumed it before we return
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PLS_HIP_OK;
 }
 
 int pls_hip_model_sse(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy, int64_t N,

@@ -15,6 +15,20 @@ __device__ __forceinline__ double red_sum(const double *red, int LP, int j) {
     for (int i = 0; i < RED_SLICES; ++i) s += red[(i64)i * LP + j];
     return s;
 }
+// the same for a runtime slice count (1 for the per-fold cross-validation loop)
+__device__ __forceinline__ double red_sum_n(const double *red, int nsl, int LP, int j) {
+    if (nsl == RED_SLICES) return red_sum(red, LP, j);
+    double s = 0.0;
+    for (int i = 0; i < nsl; ++i) s += red[(i64)i * LP + j];
+    return s;
+}
+
+// LDS scratch of component_update_body (one workgroup of UPD_THREADS)
+struct UpdShared {
+    double sred[1024 / 64];
+    double qs[32];
+    double Gs[32 * 32], Bs[32 * 32], Cs[32 * 32];
+};
 
 constexpr int UPD_THREADS = 1024;
 constexpr int UPD_WAVES = UPD_THREADS / WAVE;
@@ -91,21 +105,22 @@ __device__ inline void dominant_eigvec_lds(double *G, double *Bm, double *Cm, do
 //   then, when a+1 < A: w from XY (:403-411) -> W[:,a+1];  r (:412-416) -> R[:,a+1];
 //   vnext = r (KERNEL algo: next pass is X r) or w (NIPALS algo: next pass is X_a w).
 // Dynamic LDS: A doubles (the p_j^T w inner products).
-__global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
-    const double *__restrict__ red, double *__restrict__ XY, double *__restrict__ W,
-    double *__restrict__ P, double *__restrict__ Q, double *__restrict__ R,
-    double *__restrict__ vnext, int K, int M, int A, int a, int nipals, int power_iters,
-    int split_rotate) {
-    extern __shared__ double cs[];  // [A]
-    __shared__ double sred[UPD_WAVES];
-    __shared__ double qs[MMAX];
-    __shared__ double Gs[MMAX * MMAX], Bs[MMAX * MMAX], Cs[MMAX * MMAX];
+// Body shared by component_update_kernel (one fit) and cv_folds_kernel (one fold per workgroup).
+// red == nullptr with a < 0: XY already holds the covariance.  nsl: slices in red.
+__device__ inline void component_update_body(const double *__restrict__ red, int nsl,
+                                             double *__restrict__ XY, double *__restrict__ W,
+                                             double *__restrict__ P, double *__restrict__ Q,
+                                             double *__restrict__ R, double *__restrict__ vnext, int K,
+                                             int M, int A, int a, int nipals, int power_iters,
+                                             int split_rotate, double *cs, UpdShared &sh) {
+    double *sred = sh.sred, *qs = sh.qs, *Gs = sh.Gs, *Bs = sh.Bs, *Cs = sh.Cs;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     if (a < 0) {
-        for (int j = tid; j < K * M; j += UPD_THREADS) XY[j] = red_sum(red, K * M, j);
+        if (red)
+            for (int j = tid; j < K * M; j += UPD_THREADS) XY[j] = red_sum_n(red, nsl, K * M, j);
     } else {
-        const double tt = red_sum(red, K + 1, K);
+        const double tt = red_sum_n(red, nsl, K + 1, K);
         const double *ra = R + (i64)a * K;
         for (int m = wv; m < M; m += UPD_WAVES) {  // q_m = (r^T XY[:,m]) / tt
             double s = 0.0;
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
         }
         __syncthreads();
         for (int k = tid; k < K; k += UPD_THREADS) {
-            const double p = red_sum(red, K + 1, k) / tt;
+            const double p = red_sum_n(red, nsl, K + 1, k) / tt;
             P[k + (i64)a * K] = p;
             for (int m = 0; m < M; ++m) XY[k + (i64)m * K] -= (p * qs[m]) * tt;
         }
@@ -195,6 +210,17 @@ __global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
         rn[k] = r;
         vnext[k] = nipals ? w : r;
     }
+}
+
+__global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
+    const double *__restrict__ red, double *__restrict__ XY, double *__restrict__ W,
+    double *__restrict__ P, double *__restrict__ Q, double *__restrict__ R,
+    double *__restrict__ vnext, int K, int M, int A, int a, int nipals, int power_iters,
+    int split_rotate) {
+    extern __shared__ double cs[];  // [A]
+    __shared__ UpdShared sh;
+    component_update_body(red, RED_SLICES, XY, W, P, Q, R, vnext, K, M, A, a, nipals, power_iters, split_rotate,
+                          cs, sh);
 }
 
 // Multi-workgroup form of the r update (src/pls.cpp:412-416) for large n*K, where one workgroup

@@ -392,39 +392,50 @@ const Row Model::explained_variance(const Mat2D &X_new, const Mat2D &Y_new, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// cross-validation drivers: callers of the fit (ref :469-549)
+// cross-validation drivers (ref :469-549)
 //
-// Deliberate difference: the reference builds its inner models with A = X.cols() components
-// (the 3-argument constructors, ref :334-337, :356-359, used at :477 and :531) although only the
-// outer model's A are ever read (:479, :540).  Components are computed strictly in sequence, so the
-// first A are identical either way; the inner models here fit A components and skip the
-// K - A unused (and, for K > N, rank-deficient) ones.
+// Upstream these loops refit the model once per fold (N refits for leave-one-out, num_trials for
+// leave-some-out, each through plsr on a freshly assembled matrix).  Here the folds of one call are
+// handed to the device together (pls_hip_cv_folds): XX = X^T X and XY = X^T Y are formed once, every
+// fold works on their downdates by its held-out rows, and the residuals come back in the layout of
+// Residual::errors().  Same numbers up to fp64 rounding (tests compare with one refit per fold).
+//
+// Deliberate difference kept from the first version: the reference builds its inner models with
+// A = X.cols() components (the 3-argument constructors, ref :334-337, :356-359, used at :477 and :531)
+// although only the outer model's A are ever read (:479, :540); components are computed strictly in
+// sequence, so the first A are identical either way, and only those are computed here.
 // ---------------------------------------------------------------------------------------------
-Residual Model::cv_LOO() const {
-    const Index N = _X.rows(), K = _X.cols(), M = _Y.cols();
-    Mat2D Xv(N - 1, K), Yv(N - 1, M);  // rows 1..N-1: row 0 is left out first
-    for (Index j = 0; j < K; ++j)
-        for (Index i = 1; i < N; ++i) Xv(i - 1, j) = _X(i, j);
-    for (Index j = 0; j < M; ++j)
-        for (Index i = 1; i < N; ++i) Yv(i - 1, j) = _Y(i, j);
-    std::vector<Mat2D> Ev(static_cast<size_t>(M), Mat2D::Zero(N, static_cast<Index>(A)));
+namespace {
 
-    Model fold(Xv, Yv, method, A);
-    for (Index out = 0; out < N; ++out) {
-        Mat2D x1(1, K), y1(1, M);
-        for (Index j = 0; j < K; ++j) x1(0, j) = _X(out, j);
-        for (Index j = 0; j < M; ++j) y1(0, j) = _Y(out, j);
-        for (size_t nc = 1; nc <= A; ++nc) {
-            const Mat2D res = fold.residuals(x1, y1, nc);
-            for (Index m = 0; m < M; ++m) Ev[static_cast<size_t>(m)](out, static_cast<Index>(nc - 1)) = res(0, m);
-        }
-        if (out < N - 1) {  // put this row back in place of the next one to be left out, refit
-            for (Index j = 0; j < K; ++j) Xv(out, j) = _X(out, j);
-            for (Index j = 0; j < M; ++j) Yv(out, j) = _Y(out, j);
-            fold.plsr(Xv, Yv, method);
-        }
+// residuals of `folds` (each `test_size` held-out rows, row-major index list) -> M matrices nobs x A
+std::vector<Mat2D> run_folds(const Mat2D &X, const Mat2D &Y, size_t A, const std::vector<int64_t> &test_idx,
+                             size_t test_size, size_t num_folds) {
+    const Index N = X.rows(), K = X.cols(), M = Y.cols();
+    const Index nobs = static_cast<Index>(num_folds * test_size), Ai = static_cast<Index>(A);
+    std::vector<float_type> e(static_cast<size_t>(nobs * Ai * M));
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        check(pls_hip_cv_folds(device(), X.data(), N, Y.data(), N, N, K, M, Ai, test_idx.data(),
+                               static_cast<int64_t>(test_size), static_cast<int64_t>(num_folds), PLS_HIP_F64,
+                               PLS_HIP_MEM_HOST, e.data()),
+              "pls_hip_cv_folds");
     }
-    return Residual(Ev, "LOO");
+    std::vector<Mat2D> Ev(static_cast<size_t>(M), Mat2D::Zero(nobs, Ai));
+    for (Index m = 0; m < M; ++m)
+        for (Index c = 0; c < Ai; ++c)
+            for (Index i = 0; i < nobs; ++i)
+                Ev[static_cast<size_t>(m)](i, c) = e[static_cast<size_t>(m * nobs * Ai + i + c * nobs)];
+    return Ev;
+}
+
+}  // namespace
+
+Residual Model::cv_LOO() const {
+    const size_t N = static_cast<size_t>(_X.rows());
+    if (N < 2) throw std::invalid_argument("PLS::Model::cv_LOO: need at least two observations");
+    std::vector<int64_t> idx(N);
+    std::iota(idx.begin(), idx.end(), int64_t(0));  // fold i leaves out row i (ref :478-488)
+    return Residual(run_folds(_X, _Y, A, idx, 1, N), "LOO");
 }
 
 Residual Model::cv_NEW_DATA(const Mat2D &X_new, const Mat2D &Y_new) const {
@@ -444,37 +455,17 @@ Residual Model::cv_LSO(const float_type test_fraction, const size_t num_trials, 
     const size_t test_size = static_cast<size_t>(test_fraction * N + 0.5);
     const size_t train_size = N - test_size;
     if (test_size == 0 || train_size == 0) throw std::invalid_argument("PLS::Model::cv_LSO: empty train or test split");
-    const Index K = _X.cols(), M = _Y.cols();
 
-    std::vector<Mat2D> Ev(static_cast<size_t>(M),
-                          Mat2D::Zero(static_cast<Index>(num_trials * test_size), static_cast<Index>(A)));
+    // the same shuffle stream as the reference (rand_nchoosek on one persistent index vector, ref :524-534):
+    // trial rep trains on `sample` and tests on `complement`
     std::vector<Eigen::Index> sample(train_size), complement(test_size), full(N);
     std::iota(full.begin(), full.end(), Eigen::Index(0));
-
-    Mat2D Xv(static_cast<Index>(train_size), K), Yv(static_cast<Index>(train_size), M);
-    Mat2D Xp(static_cast<Index>(test_size), K), Yp(static_cast<Index>(test_size), M);
-    Model fold(static_cast<size_t>(K), static_cast<size_t>(M), method, A);
-
+    std::vector<int64_t> idx(num_trials * test_size);
     for (size_t rep = 0; rep < num_trials; ++rep) {
         rand_nchoosek(rng, full, sample, complement);
-        for (Index j = 0; j < K; ++j) {
-            for (size_t i = 0; i < train_size; ++i) Xv(static_cast<Index>(i), j) = _X(sample[i], j);
-            for (size_t i = 0; i < test_size; ++i) Xp(static_cast<Index>(i), j) = _X(complement[i], j);
-        }
-        for (Index j = 0; j < M; ++j) {
-            for (size_t i = 0; i < train_size; ++i) Yv(static_cast<Index>(i), j) = _Y(sample[i], j);
-            for (size_t i = 0; i < test_size; ++i) Yp(static_cast<Index>(i), j) = _Y(complement[i], j);
-        }
-        fold.plsr(Xv, Yv, method);
-        for (size_t nc = 1; nc <= A; ++nc) {
-            const Mat2D res = fold.residuals(Xp, Yp, nc);
-            for (Index m = 0; m < M; ++m)
-                for (size_t i = 0; i < test_size; ++i)
-                    Ev[static_cast<size_t>(m)](static_cast<Index>(rep * test_size + i), static_cast<Index>(nc - 1)) +=
-                        res(static_cast<Index>(i), m);
-        }
+        for (size_t i = 0; i < test_size; ++i) idx[rep * test_size + i] = static_cast<int64_t>(complement[i]);
     }
-    return Residual(Ev, "LSO");
+    return Residual(run_folds(_X, _Y, A, idx, test_size, num_trials), "LSO");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -266,6 +266,33 @@ class Handle:
         self._last_inputs = (S, Y, Q)
         return out
 
+    def cv_folds(self, X, Y, A: int, test_idx):
+        """Residuals of batched cross-validation folds (cv_LOO / cv_LSO of the reference in one launch).
+        test_idx: (num_folds, test_size) integer array of held-out rows.  Returns E with shape (M, nobs, A),
+        nobs = num_folds * test_size: E[m] is what Residual.errors()[m] holds."""
+        idx = np.ascontiguousarray(np.asarray(test_idx, dtype=np.int64))
+        if idx.ndim == 1:
+            idx = idx[:, None]
+        nf, ts = idx.shape
+        if _is_torch(X):
+            X = as_colmajor(X); Y = as_colmajor(Y, X.dtype)
+            N, K = X.shape
+            M = Y.shape[1]
+            E = torch.empty((M, A, nf * ts), dtype=torch.float64, device=X.device)
+            rc = self._lib.pls_hip_cv_folds(self.h, X.data_ptr(), _ld(X), Y.data_ptr(), _ld(Y), N, K, M, A,
+                                            idx.ctypes.data_as(ctypes.c_void_p), ts, nf, self._dt(X), L.MEM_DEVICE,
+                                            E.data_ptr())
+            L.check(rc, self.h)
+            return E.permute(0, 2, 1)
+        X = _np_f(X, np.float64); Y = _np_f(Y, np.float64)
+        N, K = X.shape
+        M = Y.shape[1]
+        E = np.zeros((M, A, nf * ts))
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = self._lib.pls_hip_cv_folds(self.h, p(X), N, p(Y), N, N, K, M, A, p(idx), ts, nf, L.F64, L.MEM_HOST, p(E))
+        L.check(rc, self.h)
+        return E.transpose(0, 2, 1)
+
     def synth_x(self, row0: int, nrows: int, K: int, seed: int, dtype=None, device=None):
         dtype = dtype or torch.float64
         X = colmajor_empty(nrows, K, dtype, device or f"cuda:{self.device}")

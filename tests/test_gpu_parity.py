@@ -427,3 +427,32 @@ def test_full_size_config4_fp32(handle, po):
     assert np.abs(G - np.diag(np.diag(G))).max() < 1e-4 * np.diag(G).max()
     rows = slice(77777, 77777 + 512)
     assert po.rel_fro(T[rows, 0].cpu().numpy(), X[rows].cpu().numpy().astype(np.float64) @ R[:, 0]) < 1e-5
+
+
+@pytest.mark.parametrize("N,K,M,A,ts,nf", [(10, 15, 2, 2, 1, 10), (60, 401, 1, 10, 1, 60), (60, 401, 1, 6, 18, 25),
+                                           (200, 24, 3, 5, 60, 12)])
+def test_batched_cv_folds(handle, oracle, po, N, K, M, A, ts, nf):
+    """f4: all cross-validation folds in one launch (Gram downdates) against one oracle refit per fold."""
+    if K == 401:
+        Xh = oracle.z_scores(po.read_csv(os.path.join(DATA, "nir.csv")))
+        Yh = oracle.z_scores(po.read_csv(os.path.join(DATA, "octane.csv")))
+    elif K == 15:
+        Xh = oracle.z_scores(po.read_csv(os.path.join(DATA, "toyX.csv")))
+        Yh = oracle.z_scores(po.read_csv(os.path.join(DATA, "toyY.csv")))
+    else:
+        Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    rng = np.random.default_rng(7)
+    idx = np.arange(N)[:, None] if ts == 1 and nf == N else np.stack([rng.permutation(N)[:ts] for _ in range(nf)])
+    E = handle.cv_folds(to_dev(Xh), to_dev(Yh), A, idx).cpu().numpy()       # device path
+    Eh = handle.cv_folds(Xh, Yh, A, idx)                                      # host-memory path
+    ref = np.zeros_like(Eh)
+    for f in range(idx.shape[0]):
+        test = idx[f]
+        train = np.setdiff1d(np.arange(N), test)
+        c = oracle.plsr(Xh[train], Yh[train], A)
+        for nc in range(1, A + 1):
+            B = oracle.coefficients(c["R"], c["Q"], nc)
+            ref[:, f * ts:(f + 1) * ts, nc - 1] = (Yh[test] - Xh[test] @ B).T
+    scale = np.abs(ref).max()
+    assert np.abs(E - ref).max() < 1e-8 * max(scale, 1.0)
+    assert np.abs(Eh - ref).max() < 1e-8 * max(scale, 1.0)
