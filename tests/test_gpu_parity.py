@@ -353,6 +353,46 @@ def test_padded_leading_dimensions(handle, oracle, po, mode):
     assert bool((guard[:, N:] == 7.0).all()), "the padding between T columns must not be written"
 
 
+def test_bad_arguments_every_entry_point(handle):
+    """each C-ABI entry validates shapes / pointers / enums and reports PLS_HIP_ERR_INVALID (1) or
+    UNSUPPORTED (4) without touching the device state"""
+    import ctypes
+    import pls_amd
+    from pls_amd import _lib as L
+    torch = _torch()
+    lib = L.lib()
+    h = handle.h
+    X = handle.synth_x(0, 64, 6, 1); Y = handle.synth_y(0, 64, 2, 1)
+    out = handle.fit_device(X, Y, 3); handle.synchronize()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    nul = ctypes.c_void_p(0)
+    W, P, Q, R, T, B = (out[k] for k in "WPQRTB")
+    fit = lambda **kw: lib.pls_hip_fit(h, kw.get("X", p(X)), kw.get("ldx", 64), p(Y), 64, kw.get("N", 64), kw.get("K", 6),
+                                        kw.get("M", 2), kw.get("A", 3), kw.get("method", 0), kw.get("dtype", 0),
+                                        kw.get("mem", 1), p(W), p(P), p(Q), p(R), p(T), 64, p(B))
+    assert fit() == 0
+    assert fit(X=nul) == 1 and fit(ldx=10) == 1 and fit(N=0) == 1 and fit(K=0) == 1 and fit(A=0) == 1 and fit(A=7) == 1
+    assert fit(method=5) == 1 and fit(dtype=9) == 1 and fit(mem=3) == 1 and fit(M=33) == 4
+    assert b"" != lib.pls_hip_last_error(h)
+    assert lib.pls_hip_xb(h, p(X), 64, 64, 6, nul, 6, 2, 0, 1, p(T), 64) == 1
+    assert lib.pls_hip_xb(h, p(X), 10, 64, 6, p(R), 6, 2, 0, 1, p(T), 64) == 1
+    assert lib.pls_hip_xty(h, p(X), 64, p(Y), 64, 0, 6, 2, 0, p(B)) == 1
+    assert lib.pls_hip_deflate(h, p(X), 64, p(X), 64, 64, 6, nul, p(P), 0) == 1
+    assert lib.pls_hip_coefficients(h, p(R), p(Q), 6, 2, 3, 4, 1, p(B)) == 1          # comp > A (src/pls.cpp:445)
+    assert lib.pls_hip_colwise_z_scores(h, p(X), 64, 64, 10, 6, 0, nul, 64, p(W), p(P)) == 1   # n_total < N
+    assert lib.pls_hip_sse_by_components(h, p(T), 64, p(Y), 64, 64, 3, 2, nul, 0, p(B)) == 1
+    assert lib.pls_hip_model_sse(h, p(X), 64, p(Y), 64, 64, 6, 2, 3, p(R), p(Q), 0, 7, p(B)) == 1
+    idx = (ctypes.c_int64 * 2)(0, 99)
+    assert lib.pls_hip_cv_folds(h, p(X), 64, p(Y), 64, 64, 6, 2, 3, idx, 1, 2, 0, 1, p(B)) == 1   # index out of range
+    assert lib.pls_hip_cv_folds(h, p(X), 64, p(Y), 64, 64, 6, 2, 3, idx, 1, 2, 1, 1, p(B)) == 4   # fp32 folds: unsupported
+    assert lib.pls_hip_set_option(h, 42, 1) == 1 and lib.pls_hip_set_option(h, L.OPT_ALGO, 9) == 1
+    assert lib.pls_hip_set_reducer(h, L.ALLREDUCE_FN(0), None, 1, 1) == 1            # rank >= nranks
+    assert lib.pls_hip_synth_x(h, p(X), 3, 0, 64, 6, 1, 0) == 1                        # ld < rows
+    # the handle is still healthy
+    out2 = handle.fit_device(X, Y, 3); handle.synchronize()
+    assert torch.equal(out2["B"], out["B"])
+
+
 def test_rank_deficient_leading_components(handle, oracle, po):
     """A > rank(X): the surplus columns are inf/NaN/garbage in the reference too (division by
     tt ~ 0, src/pls.cpp:427-428); the leading rank(X) components are unaffected."""
@@ -456,3 +496,33 @@ def test_batched_cv_folds(handle, oracle, po, N, K, M, A, ts, nf):
     scale = np.abs(ref).max()
     assert np.abs(E - ref).max() < 1e-8 * max(scale, 1.0)
     assert np.abs(Eh - ref).max() < 1e-8 * max(scale, 1.0)
+
+
+def test_very_tall_64bit_indexing(handle, po):
+    """N = 2^24 rows x 64 columns (8.6 GB): element and byte offsets beyond 2^31 / 2^32 on every path; the
+    resident-tile kernels decline this shape (column-group span > 2 GiB) and the one-product kernels
+    take over.  Size-independent checks: the plans agree, scores orthogonal, a row block of T against
+    the host product."""
+    import pls_amd
+    torch = _torch()
+    N, K, M, A = 1 << 24, 64, 2, 4
+    X = handle.synth_x(0, N, K, 3); Y = handle.synth_y(0, N, M, 3)
+    outs = {}
+    for algo in (0, 1, 2):
+        handle.set_option(pls_amd.OPT_ALGO, algo)
+        outs[algo] = handle.fit_device(X, Y, A)
+        handle.synchronize()
+    handle.set_option(pls_amd.OPT_ALGO, 0)
+    Bb = outs[0]["B"].cpu().numpy()
+    assert np.isfinite(Bb).all()
+    for algo, o in outs.items():
+        assert po.rel_fro(o["B"].cpu().numpy(), Bb) < TOL_B, algo
+    T = outs[0]["T"]
+    G = (T.t() @ T).cpu().numpy()
+    assert np.abs(G - np.diag(np.diag(G))).max() < 1e-9 * np.diag(G).max()
+    R = outs[0]["R"].cpu().numpy()
+    for r0 in (0, (1 << 23) + 12345, N - 1000):       # first rows, beyond 2^32 bytes into a column set, last rows
+        rows = slice(r0, r0 + 1000)
+        assert po.rel_fro(T[rows, 1].cpu().numpy(), X[rows].cpu().numpy() @ R[:, 1]) < 1e-11
+    # the last column of X sits beyond 8 GB: its generator values must match the host twin
+    assert np.array_equal(X[N - 4:, K - 1].cpu().numpy(), po.synth_x(N - 4, 4, K, 3)[:, K - 1])
