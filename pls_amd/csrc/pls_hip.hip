@@ -201,36 +201,43 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
     if (wide && N / ((i64)FV * plsk::WG) < 4 * (i64)c->num_cu) wide = false;
     int c0 = 0;
     while (c0 < C) {
-        // widest column tile first: X is read once per tile of up to 32 output columns
         const int rem = C - c0;
-        // smallest tile >= rem, capped at 16 columns (32 fp64 accumulators per lane): the 32-column tile is
-        // VALU/occupancy-bound (measured 4.0 ms for 20 columns at C3 vs 1.5 ms as 16 + 4)
-        int mt = rem > 8 ? 16 : rem > 4 ? 8 : rem > 2 ? 4 : rem > 1 ? 2 : 1;
-        if (wide && FV * mt > 32) mt = 32 / FV;
-        const int use = std::min(mt, rem);  // a tile wider than what is left: the kernel masks columns >= use
-        const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
-        Scope s(c, PLS_HIP_FAM_XB, bytes);
         const double *b = Bm + (i64)c0 * ldb;
         T *o = out + (i64)c0 * ldo;
+        const int cap = wide ? (FV == 2 ? 32 : 8) : 32;  // fp32 x 4 rows per lane: 8 columns = 32 fp64 accumulators
+        if (rem > 4) {
+            // many columns: Bm through LDS, up to `cap` columns per pass over X
+            const int mt = rem > 16 ? 32 : rem > 8 ? 16 : 8;
+            const int mtc = std::min(mt, cap);
+            const int use = std::min(mtc, rem);
+            const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
+            Scope s(c, PLS_HIP_FAM_XB, bytes);
+            const i64 per = (i64)plsk::WG * (wide ? FV : 1);
+            const dim3 grid((unsigned)((N + per - 1) / per)), blk(plsk::WG);
+#define XW_CASE(V, M_) hipLaunchKernelGGL((plsk::xb_wide_kernel<T, V, M_>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo)
+            if (wide) {
+                if constexpr (FV == 2) {
+                    if (mtc == 32) XW_CASE(FV, 32); else if (mtc == 16) XW_CASE(FV, 16); else XW_CASE(FV, 8);
+                } else {
+                    XW_CASE(FV, 8);
+                }
+            } else {
+                if (mtc == 32) XW_CASE(1, 32); else if (mtc == 16) XW_CASE(1, 16); else XW_CASE(1, 8);
+            }
+#undef XW_CASE
+            LAUNCH_CHECK(c);
+            c0 += use;
+            continue;
+        }
+        const int mt = rem > 2 ? 4 : rem > 1 ? 2 : 1;
+        const int use = std::min(mt, rem);
+        const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
+        Scope s(c, PLS_HIP_FAM_XB, bytes);
 #define XB_CASE(V, M_) launch_xb_t<T, V, M_>(c, X, ldx, N, K, b, ldb, use, o, ldo, sspart, nss)
         if (wide) {
-            switch (mt) {
-                case 32: XB_CASE(FV, 32); break;
-                case 16: XB_CASE(FV, 16); break;
-                case 8: XB_CASE(FV, 8); break;
-                case 4: XB_CASE(FV, 4); break;
-                case 2: XB_CASE(FV, 2); break;
-                default: XB_CASE(FV, 1); break;
-            }
+            if (mt == 4) XB_CASE(FV, 4); else if (mt == 2) XB_CASE(FV, 2); else XB_CASE(FV, 1);
         } else {
-            switch (mt) {
-                case 32: XB_CASE(1, 32); break;
-                case 16: XB_CASE(1, 16); break;
-                case 8: XB_CASE(1, 8); break;
-                case 4: XB_CASE(1, 4); break;
-                case 2: XB_CASE(1, 2); break;
-                default: XB_CASE(1, 1); break;
-            }
+            if (mt == 4) XB_CASE(1, 4); else if (mt == 2) XB_CASE(1, 2); else XB_CASE(1, 1);
         }
 #undef XB_CASE
         LAUNCH_CHECK(c);

@@ -104,6 +104,79 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
 }
 
 // ------------------------------------------------------------------------------------
+// out(N x ncols) = X * Bm for 4 < ncols <= MT columns in ONE pass over X (scores T = X R with A columns,
+// src/pls.cpp:439-442; fitted values X B :449-451).  With many columns the per-column scalar loads of the
+// narrow kernel above expose their latency (SGPRs cannot hold K x ncols operands), so Bm is staged
+// through LDS in chunks of KB rows, stored [k][MT] so that one k's columns are contiguous and every
+// lane reads the same address (LDS broadcast, conflict-free), two columns per ds_read_b128.
+// ------------------------------------------------------------------------------------
+template <typename T, int VEC, int MT>
+__global__ __launch_bounds__(WG) void xb_wide_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K,
+                                                     const double *__restrict__ Bm, i64 ldb, int ncols,
+                                                     T *__restrict__ out, i64 ldo) {
+    constexpr int KB = 64;
+    __shared__ __attribute__((aligned(16))) double bs[2][KB * MT];
+    const i64 i0 = ((i64)blockIdx.x * WG + threadIdx.x) * VEC;
+    const bool full = (i0 + VEC <= N);
+    double acc[VEC][MT];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[v][m] = 0.0;
+
+    auto stage = [&](int buf, int k0) {  // Bm[k0 .. k0+KB) x ncols -> bs[buf][k][m], zero padded
+        for (int j = threadIdx.x; j < KB * MT; j += WG) {
+            const int kk = j % KB, m = j / KB;  // consecutive threads: consecutive k of one column (coalesced)
+            bs[buf][kk * MT + m] = (k0 + kk < K && m < ncols) ? Bm[(k0 + kk) + (i64)m * ldb] : 0.0;
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += KB, buf ^= 1) {
+        if (k0 + KB < K) stage(buf ^ 1, k0 + KB);
+        const int kn = min(KB, K - k0);
+        constexpr int U = 8;
+        for (int kb = 0; kb < kn; kb += U) {
+            Pack<T, VEC> x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (full && kb + u < kn) x[u] = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + kb + u) * ldx);
+                else
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        x[u].v[v] = (kb + u < kn && i0 + v < N) ? X[i0 + v + (i64)(k0 + kb + u) * ldx] : (T)0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double *brow = &bs[buf][(kb + u) * MT];  // rows beyond kn hold zeros or stale data x 0
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const double b = brow[m];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v][m] = fma((double)x[u].v[v], b, acc[v][m]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        if (m < ncols) {
+            if (full) {
+                Pack<T, VEC> o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o.v[v] = (T)acc[v][m];
+                st_pack<T, VEC>(out + i0 + (i64)m * ldo, o);
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (i0 + v < N) out[i0 + v + (i64)m * ldo] = (T)acc[v][m];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------
 // part[blockIdx.x][(k0+kc) + (m0+m)*K] = sum over this workgroup's rows of X[i,k0+kc]*Y[i,m0+m]
 // grid = (row groups G, column groups ceil(K/KC)); a workgroup walks row chunks
 // blockIdx.x, blockIdx.x+G, ... of WG*VEC rows and keeps KC*MT fp64 accumulators per lane.
