@@ -110,6 +110,7 @@ def roofline_of(tm):
     ach = bytes_per / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac_of_measured_copy_ceiling": round(ach / 6290.0, 4),  # 6.29 TB/s float4 copy, MI355X_MICROARCH.md:36
             "launches": n, "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(bytes_per),
             "families_ms_per_fit": {f: round(tm["ms"][f] / max(tm["fits"], 1), 4) for f in tm["ms"]}}
 
