@@ -191,7 +191,7 @@ def main():
         "effective_gbs": round(2 * A * N * K * es / (el / a.steps) / 1e9, 1),
     }
 
-    if line["roofline"] is not None:
+    if line["roofline"] is not None and world == 1:  # the PMC summary was taken on the single-GPU shape
         tr, src = pmc_traffic(a.workload, a.algo, a.fuse, line["roofline"]["kernel"])
         line["roofline"]["traffic"] = tr
         line["roofline"]["traffic_source"] = src
