@@ -206,24 +206,35 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
         T *o = out + (i64)c0 * ldo;
         const int cap = wide ? (FV == 2 ? 32 : 8) : 32;  // fp32 x 4 rows per lane: 8 columns = 32 fp64 accumulators
         if (rem > 4) {
-            // many columns: Bm through LDS, up to `cap` columns per pass over X
-            const int mt = rem > 16 ? 32 : rem > 8 ? 16 : 8;
-            const int mtc = std::min(mt, cap);
-            const int use = std::min(mtc, rem);
+            // many columns: Bm through LDS, up to `cap` columns per pass over X; the tile is the column
+            // count rounded up to a multiple of 4 (every extra column costs VEC fp64 FMAs per element)
+            const int use = std::min(rem, cap);
+            const int mtc = (use + 3) & ~3;
             const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
             Scope s(c, PLS_HIP_FAM_XB, bytes);
             const i64 per = (i64)plsk::WG * (wide ? FV : 1);
             const dim3 grid((unsigned)((N + per - 1) / per)), blk(plsk::WG);
 #define XW_CASE(V, M_) hipLaunchKernelGGL((plsk::xb_wide_kernel<T, V, M_>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo)
+#define XW_SWITCH(V)                                   \
+    switch (mtc) {                                     \
+        case 8: XW_CASE(V, 8); break;                  \
+        case 12: XW_CASE(V, 12); break;                \
+        case 16: XW_CASE(V, 16); break;                \
+        case 20: XW_CASE(V, 20); break;                \
+        case 24: XW_CASE(V, 24); break;                \
+        case 28: XW_CASE(V, 28); break;                \
+        default: XW_CASE(V, 32); break;                \
+    }
             if (wide) {
                 if constexpr (FV == 2) {
-                    if (mtc == 32) XW_CASE(FV, 32); else if (mtc == 16) XW_CASE(FV, 16); else XW_CASE(FV, 8);
+                    XW_SWITCH(FV)
                 } else {
                     XW_CASE(FV, 8);
                 }
             } else {
-                if (mtc == 32) XW_CASE(1, 32); else if (mtc == 16) XW_CASE(1, 16); else XW_CASE(1, 8);
+                XW_SWITCH(1)
             }
+#undef XW_SWITCH
 #undef XW_CASE
             LAUNCH_CHECK(c);
             c0 += use;
