@@ -116,7 +116,44 @@ __device__ inline void component_update_body(const double *__restrict__ red, int
     double *sred = sh.sred, *qs = sh.qs, *Gs = sh.Gs, *Bs = sh.Bs, *Cs = sh.Cs;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    if (a < 0) {
+    // Single response (the headline configurations) with K <= 4096: every thread keeps its <= 4 entries
+    // of XY in registers from the Y-loading update through to the next weight vector; the q dot product
+    // is one workgroup reduction instead of one wave walking K, and XY is not re-read.
+    const bool fast = (M == 1 && K <= 4 * UPD_THREADS && a >= 0);
+    if (fast) {
+        const double tt = red_sum_n(red, nsl, K + 1, K);
+        const double *ra = R + (i64)a * K;
+        double xv[4], pv[4];
+        double part = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = tid + i * UPD_THREADS;
+            xv[i] = (k < K) ? XY[k] : 0.0;
+            pv[i] = (k < K) ? red_sum_n(red, nsl, K + 1, k) / tt : 0.0;
+            part = fma((k < K) ? ra[k] : 0.0, xv[i], part);
+        }
+        const double q = block_sum<UPD_WAVES>(part, sred) / tt;  // q = (r^T XY)/tt  (:428)
+        if (tid == 0) Q[(i64)a] = q;
+        double ssn = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = tid + i * UPD_THREADS;
+            if (k < K) {
+                P[k + (i64)a * K] = pv[i];
+                xv[i] -= (pv[i] * q) * tt;  // XY -= (p q^T) tt  (:429)
+                XY[k] = xv[i];
+                ssn = fma(xv[i], xv[i], ssn);
+            }
+        }
+        if (a + 1 >= A) return;
+        const double nrm = sqrt(block_sum<UPD_WAVES>(ssn, sred));  // w = XY / |XY|  (:404, :411)
+        double *w1 = W + (i64)(a + 1) * K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = tid + i * UPD_THREADS;
+            if (k < K) w1[k] = xv[i] / nrm;
+        }
+    } else if (a < 0) {
         if (red)
             for (int j = tid; j < K * M; j += UPD_THREADS) XY[j] = red_sum_n(red, nsl, K * M, j);
     } else {
@@ -143,7 +180,9 @@ __device__ inline void component_update_body(const double *__restrict__ red, int
     __syncthreads();  // XY complete (same workgroup: its own global stores are visible)
 
     double *wn = W + (i64)n * K;
-    if (M == 1) {
+    if (fast) {
+        // w_n already written above
+    } else if (M == 1) {
         double ss = 0.0;
         for (int k = tid; k < K; k += UPD_THREADS) ss = fma(XY[k], XY[k], ss);
         ss = block_sum<UPD_WAVES>(ss, sred);
