@@ -78,8 +78,15 @@ typedef enum { PLS_HIP_MEM_HOST = 0, PLS_HIP_MEM_DEVICE = 1 } pls_hip_mem;
  *           X_{a+1} = X_a - t p^T on a library-owned working copy.
  *  GRAM   : XX = X^T X once on the matrix cores (v_mfma_f64_16x16x4_f64 SYRK), the component loop on
  *           K x K data as KERNEL_TYPE2 does (tt = r^T XX r, p = XX r / tt, src/pls.cpp:422-425), then
- *           T = X R in one pass.  2 + A*0 passes over X; pays off when A exceeds ~K/50. */
-typedef enum { PLS_HIP_ALGO_KERNEL = 0, PLS_HIP_ALGO_NIPALS = 1, PLS_HIP_ALGO_GRAM = 2 } pls_hip_algo;
+ *           T = X R in one pass.  2 + A*0 passes over X; pays off when A exceeds ~K/50.
+ *  AUTO   : KERNEL or GRAM, whichever a bandwidth / matrix-core cost model predicts to be faster for
+ *           the shape of the call (GRAM only for fp64 storage, K <= 2048). */
+typedef enum {
+    PLS_HIP_ALGO_KERNEL = 0,
+    PLS_HIP_ALGO_NIPALS = 1,
+    PLS_HIP_ALGO_GRAM = 2,
+    PLS_HIP_ALGO_AUTO = 3
+} pls_hip_algo;
 
 typedef enum {
     PLS_HIP_OPT_ALGO = 1,       /* pls_hip_algo; default PLS_HIP_ALGO_KERNEL */

@@ -17,7 +17,7 @@ OK, ERR_INVALID, ERR_DEVICE, ERR_ALLOC, ERR_UNSUPPORTED, ERR_REDUCER = range(6)
 KERNEL_TYPE1, KERNEL_TYPE2 = 0, 1          # PLS::METHOD, reference include/PLS/pls.h:131
 F64, F32 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
-ALGO_KERNEL, ALGO_NIPALS, ALGO_GRAM = 0, 1, 2
+ALGO_KERNEL, ALGO_NIPALS, ALGO_GRAM, ALGO_AUTO = 0, 1, 2, 3
 OPT_ALGO, OPT_FUSE, OPT_PROFILE, OPT_POWER_ITERS, OPT_FUSED_GRID = 1, 2, 3, 4, 5
 REDUCE_SLICES = 8
 FAM_XTY, FAM_XB, FAM_DEFLATE, FAM_FUSED, FAM_SMALL, FAM_COUNT = 0, 1, 2, 3, 4, 5

@@ -421,9 +421,22 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                int A, int method, double *W, double *P, double *Q, double *R, T *Tm, i64 ldt, double *B) {
     // GRAM plan for a KERNEL_TYPE1 request: the K-sized loop runs on XX = X^T X exactly as KERNEL_TYPE2
     // does (no pass over X per component), then the scores are formed in one pass, T = X R.
-    const bool gram = (method == PLS_HIP_KERNEL_TYPE1) && (c->opt_algo == PLS_HIP_ALGO_GRAM);
+    // AUTO: pick between the read-only pass plan and the Gram plan from a bandwidth / matrix-core cost
+    // model (measured rates on MI355X: ~6 TB/s streaming reads, ~50 TFLOP/s executed in the fp64 SYRK of
+    // which the symmetric half is computed).  GRAM needs fp64 storage and pays off for A >~ K/50.
+    i64 algo = c->opt_algo;
+    if (algo == PLS_HIP_ALGO_AUTO) {
+        const double pass_s = (double)N * K * sizeof(T) / 6.0e12;
+        const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
+        const double syrk_s = 2.0 * N * (double)K * K * (nbk + 1) / (2.0 * nbk) / 50.0e12;
+        // ranks of a sharded fit see different N: they must not disagree on the plan -> KERNEL there
+        const bool gram_ok = std::is_same<T, double>::value && K <= 2048 && N >= 4096 && !c->reducer;
+        algo = (gram_ok && (1 + A) * pass_s > syrk_s + 2.5 * pass_s + A * 25e-6) ? PLS_HIP_ALGO_GRAM
+                                                                               : PLS_HIP_ALGO_KERNEL;
+    }
+    const bool gram = (method == PLS_HIP_KERNEL_TYPE1) && (algo == PLS_HIP_ALGO_GRAM);
     const bool type2 = (method == PLS_HIP_KERNEL_TYPE2) || gram;
-    const bool nipals = !type2 && (c->opt_algo == PLS_HIP_ALGO_NIPALS);
+    const bool nipals = !type2 && (algo == PLS_HIP_ALGO_NIPALS);
     const i64 L0 = (i64)K * M;
     const i64 redn = (i64)plsk::RED_SLICES * std::max<i64>(L0, K + 1);
     const i64 prow = max_partial_rows(c, N, K);
@@ -656,7 +669,8 @@ int pls_hip_set_option(pls_hip_handle h, int option, int64_t value) {
     CHK(check_handle(h));
     switch (option) {
         case PLS_HIP_OPT_ALGO:
-            if (value != PLS_HIP_ALGO_KERNEL && value != PLS_HIP_ALGO_NIPALS && value != PLS_HIP_ALGO_GRAM)
+            if (value != PLS_HIP_ALGO_KERNEL && value != PLS_HIP_ALGO_NIPALS && value != PLS_HIP_ALGO_GRAM &&
+                value != PLS_HIP_ALGO_AUTO)
                 return fail(h, PLS_HIP_ERR_INVALID, "unknown algo");
             h->opt_algo = value;
             return PLS_HIP_OK;
@@ -755,7 +769,7 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
         return fail(h, PLS_HIP_ERR_UNSUPPORTED, "M > 32 responses (or K > 2^30) not supported on the device");
     if (N > 0 && (!X || !Y || (!T && method == PLS_HIP_KERNEL_TYPE1))) return fail(h, PLS_HIP_ERR_INVALID, "null X/Y/T");
     if (A > 6144) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "more than 6144 components not supported");
-    if ((method == PLS_HIP_KERNEL_TYPE2 || h->opt_algo == PLS_HIP_ALGO_GRAM) && K > 16384)
+    if ((method == PLS_HIP_KERNEL_TYPE2 || h->opt_algo == PLS_HIP_ALGO_GRAM) && K > 16384)  // (AUTO never picks GRAM there)
         return fail(h, PLS_HIP_ERR_UNSUPPORTED, "KERNEL_TYPE2 keeps a K x K matrix: K <= 16384");
     if (!W || !P || !Q || !R) return fail(h, PLS_HIP_ERR_INVALID, "null W/P/Q/R");
     if (ldx < std::max<i64>(N, 1) || ldy < std::max<i64>(N, 1) || (T && ldt < std::max<i64>(N, 1)))

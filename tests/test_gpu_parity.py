@@ -62,8 +62,8 @@ def golden_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "s_*.npz")))
 
 
-@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1), (2, 1)],
-                ids=["kernel-unfused", "kernel-fused", "nipals-unfused", "nipals-fused", "gram"])
+@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1), (2, 1), (3, 1)],
+                ids=["kernel-unfused", "kernel-fused", "nipals-unfused", "nipals-fused", "gram", "auto"])
 def mode(request, handle):
     import pls_amd
     algo, fuse = request.param
@@ -496,6 +496,27 @@ def test_batched_cv_folds(handle, oracle, po, N, K, M, A, ts, nf):
     scale = np.abs(ref).max()
     assert np.abs(E - ref).max() < 1e-8 * max(scale, 1.0)
     assert np.abs(Eh - ref).max() < 1e-8 * max(scale, 1.0)
+
+
+def test_auto_plan_choice(handle):
+    """AUTO = GRAM where the cost model says so (tall fp64, many components), KERNEL otherwise; checked
+    through which kernel families ran."""
+    import pls_amd
+    handle.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_AUTO)
+    handle.set_option(pls_amd.OPT_PROFILE, 1)
+    try:
+        X = handle.synth_x(0, 1 << 18, 256, 5); Y = handle.synth_y(0, 1 << 18, 1, 5)
+        handle.timing()
+        handle.fit_device(X, Y, 20); tm = handle.timing()
+        assert tm["launches"]["fused"] == 0 and tm["launches"]["xty"] >= 2     # SYRK + X^T Y, no per-component pass
+        handle.fit_device(X, Y, 2); tm = handle.timing()
+        assert tm["launches"]["fused"] == 2                                      # two components: passes are cheaper
+        Xs = handle.synth_x(0, 500, 64, 5); Ys = handle.synth_y(0, 500, 1, 5)
+        handle.fit_device(Xs, Ys, 20); tm = handle.timing()
+        assert tm["launches"]["fused"] == 20                                     # small N: KERNEL
+    finally:
+        handle.set_option(pls_amd.OPT_ALGO, 0)
+        handle.set_option(pls_amd.OPT_PROFILE, 0)
 
 
 def test_very_tall_64bit_indexing(handle, po):
