@@ -35,9 +35,14 @@ pls_hip_handle device() {
         if (rc != PLS_HIP_OK)
             throw std::runtime_error("PLS: no usable MI355X (gfx950) device (pls_hip_create status " +
                                      std::to_string(rc) + "); this library has no CPU path");
-        if (const char *e = std::getenv("PLS_HIP_ALGO"))  // "nipals": explicit X deflation
+        if (const char *e = std::getenv("PLS_HIP_ALGO")) {  // kernel (default) | nipals | gram | auto
+            const std::string a(e);
             pls_hip_set_option(g_handle, PLS_HIP_OPT_ALGO,
-                               std::string(e) == "nipals" ? PLS_HIP_ALGO_NIPALS : PLS_HIP_ALGO_KERNEL);
+                               a == "nipals" ? PLS_HIP_ALGO_NIPALS
+                               : a == "gram" ? PLS_HIP_ALGO_GRAM
+                               : a == "auto" ? PLS_HIP_ALGO_AUTO
+                                             : PLS_HIP_ALGO_KERNEL);
+        }
     }
     return g_handle;
 }
