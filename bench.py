@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--fuse", type=int, default=1)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (gloo: rehearsal with ranks sharing one GPU)")
+    ap.add_argument("--reducer", default="torch", choices=["torch", "rccl"],
+                    help="N > 1: torch.distributed all_reduce from a callback (default) or the library's own RCCL "
+                         "communicator issued on the launch stream (include/pls_hip_rccl.h)")
     ap.add_argument("--no-alt", action="store_true", help="skip the alternative execution plans")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=1 << 20, help="rows of the CPU baseline sample (default: the whole workload, ~10 s on one core)")
@@ -168,7 +171,11 @@ def main():
     X = h.synth_x(row0, nrows, K, pls_amd.SEED_DEFAULT, dtype=tdt)
     Y = h.synth_y(row0, nrows, M, pls_amd.SEED_DEFAULT, dtype=tdt)
     if world > 1:
-        attach_reducer(h, K, M)
+        if a.reducer == "rccl" and a.backend == "nccl":
+            from pls_amd.distributed import attach_rccl_reducer
+            attach_rccl_reducer(h)
+        else:
+            attach_reducer(h, K, M)
     algo = {"nipals": pls_amd.ALGO_NIPALS, "kernel": pls_amd.ALGO_KERNEL, "gram": pls_amd.ALGO_GRAM}[a.algo]
     h.set_option(pls_amd.OPT_ALGO, algo)
     h.set_option(pls_amd.OPT_FUSE, a.fuse)

@@ -89,3 +89,39 @@ def make_host_allreduce(group=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
     return _allreduce
+
+
+def attach_rccl_reducer(handle, group=None):
+    """Alternative to attach_reducer: the library's own RCCL communicator (libpls_hip_rccl.so,
+    include/pls_hip_rccl.h) -- ncclAllReduce is issued directly on the handle's stream, no Python in the
+    A-loop.  torch.distributed is used once, to hand the ncclUniqueId of rank 0 to the other ranks.
+    Returns the communicator (keep it; detach_rccl_reducer releases it)."""
+    import os
+
+    import torch.distributed as dist
+
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(L.LIB_PATH), "libpls_hip_rccl.so"), mode=ctypes.RTLD_GLOBAL)
+    lib.pls_hip_rccl_unique_id.argtypes = [ctypes.c_void_p]
+    lib.pls_hip_rccl_attach.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_void_p)]
+    lib.pls_hip_rccl_detach.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    ident = ctypes.create_string_buffer(128)
+    if rank == 0:
+        L.check(lib.pls_hip_rccl_unique_id(ident))
+    if world > 1:
+        box = [bytes(ident.raw)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        ident = ctypes.create_string_buffer(box[0], 128)
+    comm = ctypes.c_void_p()
+    L.check(lib.pls_hip_rccl_attach(handle.h, handle.device, ident, rank, world, ctypes.byref(comm)), handle.h)
+    handle._keep += [lib]
+    handle._rccl = (lib, comm)
+    return comm
+
+
+def detach_rccl_reducer(handle):
+    lib, comm = handle._rccl
+    L.check(lib.pls_hip_rccl_detach(handle.h, comm), handle.h)
+    handle._rccl = None

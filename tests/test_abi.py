@@ -32,9 +32,19 @@ def test_library_exports_every_declared_symbol():
     assert L.pls_hip_abi_version() == 1
 
 
+def test_rccl_helper_exports():
+    from pls_amd import _lib
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libpls_hip_rccl.so")
+    assert os.path.exists(path), "optional RCCL reducer helper not built"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    src = open(os.path.join(ROOT, "include", "pls_hip_rccl.h")).read()
+    declared = sorted(set(re.findall(r"PLS_HIP_API\s+int\s+(pls_hip_rccl_\w+)\s*\(", src)))
+    assert sorted(set(re.findall(r" T (pls_hip_rccl_\w+)", out))) == declared and len(declared) == 3
+
+
 def test_header_is_plain_c():
     """the boundary must compile as C (no C++/torch types in the signatures)"""
-    src = '#include "pls_hip.h"\nint main(void){return pls_hip_abi_version()==PLS_HIP_ABI_VERSION?0:1;}\n'
+    src = '#include "pls_hip.h"\n#include "pls_hip_rccl.h"\nint main(void){return pls_hip_abi_version()==PLS_HIP_ABI_VERSION?0:1;}\n'
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                         "-x", "c", "-"], input=src, text=True, capture_output=True)
     assert r.returncode == 0, r.stderr

@@ -153,3 +153,40 @@ def test_nccl_reducer_single_rank():
     p.join(timeout=120)
     assert p.exitcode == 0
     assert all(same.values()), same
+
+
+def _rccl_direct_worker(q):
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    sys.path.insert(0, ROOT)
+    import torch
+    import pls_amd
+    from pls_amd.distributed import attach_rccl_reducer, detach_rccl_reducer
+    try:
+        torch.cuda.set_device(0)
+        N, K, M, A = 8192, 128, 2, 5
+        h = pls_amd.Handle()
+        X = h.synth_x(0, N, K, 1); Y = h.synth_y(0, N, M, 1)
+        plain = h.fit_device(X, Y, A); h.synchronize()
+        attach_rccl_reducer(h)            # ncclCommInitRank(nranks = 1) + ncclAllReduce on the launch stream
+        red = h.fit_device(X, Y, A); h.synchronize()
+        detach_rccl_reducer(h)
+        again = h.fit_device(X, Y, A); h.synchronize()
+        q.put({k: bool(torch.equal(plain[k], red[k]) and torch.equal(plain[k], again[k])) for k in "WPQRTB"})
+        h.close()
+    except BaseException:
+        import traceback
+        q.put({"error": traceback.format_exc()})
+        raise
+
+
+def test_library_rccl_reducer_single_rank():
+    """include/pls_hip_rccl.h: the library-owned RCCL communicator as reducer (the C++ host route)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_direct_worker, args=(q,))
+    p.start()
+    same = q.get(timeout=120)
+    p.join(timeout=60)
+    assert "error" not in same, same.get("error")
+    assert p.exitcode == 0 and all(same.values()), same
