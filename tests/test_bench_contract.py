@@ -1,0 +1,50 @@
+"""bench.py's one-JSON-line contract (the driver parses it): helper logic on CPU, a real tiny run on the GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def test_roofline_helper_and_traffic_lookup():
+    sys.path.insert(0, ROOT)
+    import bench
+    tm = {"fit_ms": 70.0, "fits": 2,
+          "ms": {"xty": 1.4, "xb": 0.0, "deflate": 0.0, "fused": 66.0, "small": 0.8},
+          "launches": {"xty": 2, "xb": 0, "deflate": 0, "fused": 40, "small": 80},
+          "bytes": {"xty": 2 * 4303360000, "xb": 0, "deflate": 0, "fused": 40 * 8391556096, "small": 0}}
+    r = bench.roofline_of(tm)
+    assert r["kernel"] == "fused" and r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["achieved"] - 8391556096 / (66.0 / 40 * 1e-3) / 1e9) < 0.1
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4 and r["traffic"] is None
+    tr, src = bench.pmc_traffic("C3", "nipals", 1, "fused")
+    assert src and src.startswith("profiles/") and 8.0e9 < tr < 9.0e9       # committed PMC summary of the headline plan
+    assert bench.pmc_traffic("C3", "nipals", 0, "deflate") == (None, None)  # no summary for that plan
+    assert bench.roofline_of({"ms": {k: 0 for k in tm["ms"]}, "launches": {k: 0 for k in tm["ms"]},
+                              "bytes": {k: 0 for k in tm["ms"]}, "fits": 0, "fit_ms": 0}) is None
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "3", "--warmup", "1",
+                        "--cpu-rows", "4096"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["metric"] == "NIPALS components/sec" and d["unit"] == "components/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1

@@ -230,6 +230,18 @@ def test_kernel_type2(handle, oracle, po, N, K, M, A):
     check_against(po, out, ref, oracle.coefficients(ref["R"], ref["Q"]), None, col_err=cerr)
 
 
+def test_kernel_type2_fp32_storage(handle, oracle, po):
+    """KERNEL_TYPE2 on fp32 storage: X^T X through the column-reduction kernel (the MFMA SYRK is fp64 only)."""
+    import pls_amd
+    torch = _torch()
+    N, K, M, A = 1500, 70, 2, 5
+    X = handle.synth_x(0, N, K, 21, dtype=torch.float32); Y = handle.synth_y(0, N, M, 21, dtype=torch.float32)
+    Xh = X.cpu().numpy().astype(np.float64); Yh = Y.cpu().numpy().astype(np.float64)
+    ref = oracle.plsr(Xh, Yh, A, method=1)
+    out = handle.fit_device(X, Y, A, method=pls_amd.KERNEL_TYPE2); handle.synchronize()
+    check_against(po, out, ref, oracle.coefficients(ref["R"], ref["Q"]), None, tol_b=1e-9, tol_col=1e-8, tol_inv=1e-7)
+
+
 def test_fp32_storage(handle, oracle, po, mode):
     """BASELINE config 4 is fp32 (no reference counterpart: float_type is double, pls.h:22).
     fp32 storage of X, Y, T with fp64 accumulation, checked against the fp64 oracle run on the
