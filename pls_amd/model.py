@@ -329,6 +329,7 @@ class Model:
         self.A = int(K if max_components is None else max_components)  # src/pls.cpp:356-359
         self.method = algorithm
         self.W = self.P = self.R = self.Q = self.T = None
+        self._X, self._Y = X, Y  # the reference keeps _X, _Y for its cross-validation methods (pls.h:250)
         self.plsr(X, Y, algorithm)
 
     # void plsr(const Mat2D&, const Mat2D&, const METHOD&)  include/PLS/pls.h:199
@@ -379,6 +380,36 @@ class Model:
     def SSE(self, X, Y, comp: int | None = None):
         r = self.residuals(X, Y, comp)
         return (r * r).sum(0)
+
+    # ---- cross-validation (reference include/PLS/pls.h:235-241, src/pls.cpp:469-549) -------------------
+    # Each returns the residual tensor E of shape (M, nobs, A): E[m] is Residual.errors()[m].
+    def cv_LOO(self):
+        """leave-one-out: fold i refits on all rows but i (all folds in one batched device call)"""
+        n = self._X.shape[0]
+        return self.handle.cv_folds(self._X, self._Y, self.A, np.arange(n)[:, None])
+
+    def cv_LSO(self, test_fraction: float, num_trials: int, rng=None):
+        """leave-some-out: num_trials random splits with round(test_fraction*N) held-out rows each.
+        The reference draws its splits from std::shuffle on a std::mt19937 (src/pls.cpp:218-227);
+        here they come from a numpy Generator (pass one for reproducibility)."""
+        n = self._X.shape[0]
+        ts = int(test_fraction * n + 0.5)
+        if ts == 0 or ts == n:
+            raise L.PlsHipError(L.ERR_INVALID, "empty train or test split")
+        rng = np.random.default_rng() if rng is None else rng
+        idx = np.stack([rng.permutation(n)[:ts] for _ in range(num_trials)])
+        return self.handle.cv_folds(self._X, self._Y, self.A, idx)
+
+    def cv_NEW_DATA(self, X_new, Y_new):
+        """residuals on data outside the fit for 1..A components (src/pls.cpp:494-509); no refit"""
+        S = self.scores(X_new)
+        if _is_torch(S):
+            Y2 = (Y_new if Y_new.dim() == 2 else Y_new[:, None]).to(torch.float64)
+            fit = torch.cumsum(S.to(torch.float64)[:, :, None] * self.Q.t()[None, :, :], dim=1)  # (N, A, M)
+            return (Y2[:, None, :] - fit).permute(2, 0, 1)
+        Y2 = _np_f(Y_new, np.float64)
+        fit = np.cumsum(np.asarray(S, dtype=np.float64)[:, :, None] * np.asarray(self.Q).T[None, :, :], axis=1)
+        return (Y2[:, None, :] - fit).transpose(2, 0, 1)
 
     def explained_variance_by_components(self, X, Y):
         """(EV, SSE), each M x A: what print_explained_variance (src/pls.cpp:551-562) reports for

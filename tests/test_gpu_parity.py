@@ -559,3 +559,31 @@ def test_very_tall_64bit_indexing(handle, po):
         assert po.rel_fro(T[rows, 1].cpu().numpy(), X[rows].cpu().numpy() @ R[:, 1]) < 1e-11
     # the last column of X sits beyond 8 GB: its generator values must match the host twin
     assert np.array_equal(X[N - 4:, K - 1].cpu().numpy(), po.synth_x(N - 4, 4, K, 3)[:, K - 1])
+
+
+def test_model_api_cross_validation(handle, oracle, po):
+    """the Python mirror's cv_LOO / cv_LSO / cv_NEW_DATA (reference pls.h:235-241) on the nir example"""
+    import pls_amd
+    Xh = oracle.z_scores(po.read_csv(os.path.join(DATA, "nir.csv")))
+    Yh = oracle.z_scores(po.read_csv(os.path.join(DATA, "octane.csv")))
+    A = 5
+    m = pls_amd.Model(to_dev(Xh), to_dev(Yh), pls_amd.KERNEL_TYPE1, A, handle=handle)
+    E = m.cv_LOO().cpu().numpy()
+    assert E.shape == (1, 60, A)
+    i = 17
+    keep = np.arange(60) != i
+    c = oracle.plsr(Xh[keep], Yh[keep], A)
+    for nc in range(1, A + 1):
+        assert abs(E[0, i, nc - 1] - (Yh[i] - Xh[i] @ oracle.coefficients(c["R"], c["Q"], nc))[0]) < 1e-9
+    rmse = np.sqrt((E ** 2).mean(axis=1))
+    assert np.allclose(rmse[0, :3], [0.849836, 0.501343, 0.160829], atol=2e-6)     # the CLI's printed LOO RMSE
+    Es = m.cv_LSO(0.3, 7, np.random.default_rng(1)).cpu().numpy()
+    assert Es.shape == (1, 7 * 18, A) and np.isfinite(Es).all()
+    ref = oracle.plsr(Xh, Yh, A)
+    En = m.cv_NEW_DATA(to_dev(Xh[:9]), to_dev(Yh[:9])).cpu().numpy()
+    for nc in range(1, A + 1):
+        want = Yh[:9] - Xh[:9] @ oracle.coefficients(ref["R"], ref["Q"], nc)
+        assert np.abs(En[:, :, nc - 1].T - want).max() < 1e-9
+    # host-memory model
+    mh = pls_amd.Model(Xh, Yh, pls_amd.KERNEL_TYPE1, A, handle=handle)
+    assert np.abs(mh.cv_LOO() - E).max() < 1e-9
