@@ -441,7 +441,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     const i64 redn = (i64)plsk::RED_SLICES * std::max<i64>(L0, K + 1);
     const i64 prow = max_partial_rows(c, N, K);
     CHK(ensure(c, c->part, (size_t)prow * (size_t)std::max<i64>(L0, K) * 8));
-    const i64 ssmax = std::max<i64>(std::max<i64>((N + plsk::WG - 1) / plsk::WG, 1), 2 * (i64)c->num_cu);
+    // t^T t partials: one per workgroup of whichever kernel forms the scores (narrow X*v: N/256; tile kernels: their grid)
+    const i64 ssmax = std::max<i64>(std::max<i64>((N + plsk::WG - 1) / plsk::WG, 1), max_partial_rows(c, N, K));
     CHK(ensure(c, c->sspart, (size_t)ssmax * 8));
     CHK(ensure(c, c->xy, (size_t)L0 * 8));
     CHK(ensure(c, c->v, (size_t)K * 8));
