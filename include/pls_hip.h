@@ -197,7 +197,7 @@ PLS_HIP_API int pls_hip_colwise_z_scores(pls_hip_handle h, const void *X, int64_
                                          double *mean, double *sd);
 /* SSE(M x A, ld M)[m, c-1] = sum_i (Y[i,m] - (S[:, :c] Q[:, :c]^T)[i,m])^2 for c = 1..A in one sweep
  * over the scores S = X R (N x A): Model::SSE for every component count (src/pls.cpp:457-459) without the
- * A separate X*B passes of print_explained_variance (:551-562). */
+ * A separate X*B passes of print_explained_variance (:551-562).  A*M <= 1024. */
 PLS_HIP_API int pls_hip_sse_by_components(pls_hip_handle h, const void *S, int64_t lds, const void *Y,
                                           int64_t ldy, int64_t N, int64_t A, int64_t M, const double *Q,
                                           int dtype, double *SSE);

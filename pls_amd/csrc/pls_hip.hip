@@ -1012,7 +1012,7 @@ int pls_hip_sse_by_components(pls_hip_handle h, const void *S, int64_t lds, cons
                               int64_t N, int64_t A, int64_t M, const double *Q, int dtype, double *SSE) {
     CHK(check_handle(h));
     if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
-    if (N < 1 || A < 1 || M < 1 || A * M > 4096 || !S || !Y || !Q || !SSE || lds < N || ldy < N)
+    if (N < 1 || A < 1 || M < 1 || A * M > 1024 || !S || !Y || !Q || !SSE || lds < N || ldy < N)
         return fail(h, PLS_HIP_ERR_INVALID, "bad sse arguments");
     CHK(set_device(h));
     if (dtype == PLS_HIP_F64)
@@ -1094,7 +1094,7 @@ int pls_hip_model_sse(pls_hip_handle h, const void *X, int64_t ldx, const void *
     CHK(check_handle(h));
     if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
     if (mem != PLS_HIP_MEM_HOST && mem != PLS_HIP_MEM_DEVICE) return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
-    if (N < 1 || K < 1 || M < 1 || A < 1 || A * M > 4096 || K > (1 << 30) || !X || !Y || !R || !Q || !SSE ||
+    if (N < 1 || K < 1 || M < 1 || A < 1 || A * M > 1024 || K > (1 << 30) || !X || !Y || !R || !Q || !SSE ||
         ldx < N || ldy < N)
         return fail(h, PLS_HIP_ERR_INVALID, "bad model_sse arguments");
     CHK(set_device(h));
