@@ -769,7 +769,7 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
     if (K > (1 << 30) || M > (1 << 20) || (M > 1 && M > plsk::MMAX))
         return fail(h, PLS_HIP_ERR_UNSUPPORTED, "M > 32 responses (or K > 2^30) not supported on the device");
     if (N > 0 && (!X || !Y || (!T && method == PLS_HIP_KERNEL_TYPE1))) return fail(h, PLS_HIP_ERR_INVALID, "null X/Y/T");
-    if (A > 6144) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "more than 6144 components not supported");
+    if (A > 4096) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "more than 4096 components not supported");
     if ((method == PLS_HIP_KERNEL_TYPE2 || h->opt_algo == PLS_HIP_ALGO_GRAM) && K > 16384)  // (AUTO never picks GRAM there)
         return fail(h, PLS_HIP_ERR_UNSUPPORTED, "KERNEL_TYPE2 keeps a K x K matrix: K <= 16384");
     if (!W || !P || !Q || !R) return fail(h, PLS_HIP_ERR_INVALID, "null W/P/Q/R");
@@ -1027,7 +1027,7 @@ int pls_hip_cv_folds(pls_hip_handle h, const void *X, int64_t ldx, const void *Y
     if (dtype != PLS_HIP_F64) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "cv_folds: fp64 only");
     if (mem != PLS_HIP_MEM_HOST && mem != PLS_HIP_MEM_DEVICE) return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
     if (h->reducer) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "cv_folds: not available on a sharded handle");
-    if (N < 2 || K < 1 || M < 1 || A < 1 || A > K || A > 6144 || K > 16384 || (M > 1 && M > plsk::MMAX) || !X || !Y ||
+    if (N < 2 || K < 1 || M < 1 || A < 1 || A > K || A > 4096 || K > 16384 || (M > 1 && M > plsk::MMAX) || !X || !Y ||
         !test_idx || !E || test_size < 1 || test_size >= N || num_folds < 1 || ldx < N || ldy < N ||
         num_folds > (1 << 22) || test_size > (1 << 20))
         return fail(h, PLS_HIP_ERR_INVALID, "bad cv_folds arguments");
