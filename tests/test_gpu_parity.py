@@ -587,3 +587,19 @@ def test_model_api_cross_validation(handle, oracle, po):
     # host-memory model
     mh = pls_amd.Model(Xh, Yh, pls_amd.KERNEL_TYPE1, A, handle=handle)
     assert np.abs(mh.cv_LOO() - E).max() < 1e-9
+
+
+def test_many_components_equals_least_squares(handle, oracle, po, mode):
+    """A = K = 200 components (the reference's CV inner models fit K components, src/pls.cpp:356-359):
+    the full-rank fit reproduces ordinary least squares, and the run exercises the multi-workgroup r update."""
+    N, K, M = 3000, 200, 2
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    out = handle.fit_device(to_dev(Xh), to_dev(Yh), K); handle.synchronize()
+    B = out["B"].cpu().numpy()
+    Bls = np.linalg.lstsq(Xh, Yh, rcond=None)[0]
+    assert np.isfinite(B).all() and po.rel_fro(B, Bls) < 1e-7
+    # the leading scores are mutually orthogonal (the trailing ones carry ~1e-13 of the variance: rounding noise)
+    T = out["T"].cpu().numpy()[:, :20]
+    G = T.T @ T
+    d = np.sqrt(np.diag(G))
+    assert np.abs(G / np.outer(d, d) - np.eye(20)).max() < 1e-8
