@@ -206,7 +206,7 @@ def main():
         alt = {}
         if not a.no_alt and world == 1:
             plans = {"kernel_fused": (0, 1), "kernel_unfused": (0, 0), "nipals_fused": (1, 1), "nipals_unfused": (1, 0)}
-            if dt == "f64" and K <= 2048:
+            if K <= 2048:
                 plans["gram_mfma_syrk"] = (2, 1)  # XX on the matrix cores + component loop on K x K + T = X R
             for name, (al, fu) in plans.items():
                 if (al, fu) == (algo, a.fuse):
@@ -218,7 +218,7 @@ def main():
                 alt[name] = {"components_per_s": round(A * st / e2, 2), "ms_per_fit": round(e2 / st * 1e3, 3),
                              "roofline": roofline_of(t2)}
             # METHOD::KERNEL_TYPE2 (XX = X^T X on the matrix cores, then no pass over X; T not computed)
-            if dt == "f64":
+            if K <= 2048:
                 h.set_option(pls_amd.OPT_ALGO, 0)
                 st = max(2, a.steps // 2)
                 for _ in range(2):

@@ -80,7 +80,7 @@ typedef enum { PLS_HIP_MEM_HOST = 0, PLS_HIP_MEM_DEVICE = 1 } pls_hip_mem;
  *           K x K data as KERNEL_TYPE2 does (tt = r^T XX r, p = XX r / tt, src/pls.cpp:422-425), then
  *           T = X R in one pass.  2 + A*0 passes over X; pays off when A exceeds ~K/50.
  *  AUTO   : KERNEL or GRAM, whichever a bandwidth / matrix-core cost model predicts to be faster for
- *           the shape of the call (GRAM only for fp64 storage, K <= 2048). */
+ *           the shape of the call (GRAM only for K <= 2048, single rank). */
 typedef enum {
     PLS_HIP_ALGO_KERNEL = 0,
     PLS_HIP_ALGO_NIPALS = 1,

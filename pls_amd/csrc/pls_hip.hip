@@ -368,7 +368,7 @@ int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX
     double *part = nullptr, *red2 = nullptr;
     const i64 prow = max_partial_rows(c, N, K);
     bool have_xx = false;
-    if constexpr (std::is_same<T, double>::value) {
+    {
         // matrix-core path: 128 x 128 blocks on v_mfma_f64_16x16x4_f64, row-split partial blocks
         const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
         const i64 S = std::max<i64>(1, (16 * (i64)c->num_cu + nbk * (nbk + 1) / 2 - 1) / (nbk * (nbk + 1) / 2));  // capacity bound
@@ -380,7 +380,7 @@ int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX
             int rc;
             {
                 Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) * ((nbk + 1)) + (i64)K * K * 8);
-                rc = plsk::launch_syrk_f64(c->stream, c->num_cu, X, ldx, N, K, part, S * (i64)K * K, &nb);
+                rc = plsk::launch_syrk<T>(c->stream, c->num_cu, X, ldx, N, K, part, S * (i64)K * K, &nb);
                 if (rc != 0) s.on = false;
             }
             if (rc == 0) {
@@ -423,14 +423,14 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // does (no pass over X per component), then the scores are formed in one pass, T = X R.
     // AUTO: pick between the read-only pass plan and the Gram plan from a bandwidth / matrix-core cost
     // model (measured rates on MI355X: ~6 TB/s streaming reads, ~50 TFLOP/s executed in the fp64 SYRK of
-    // which the symmetric half is computed).  GRAM needs fp64 storage and pays off for A >~ K/50.
+    // which the symmetric half is computed).  GRAM pays off for A >~ K/50.
     i64 algo = c->opt_algo;
     if (algo == PLS_HIP_ALGO_AUTO) {
         const double pass_s = (double)N * K * sizeof(T) / 6.0e12;
         const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
         const double syrk_s = 2.0 * N * (double)K * K * (nbk + 1) / (2.0 * nbk) / 50.0e12;
         // ranks of a sharded fit see different N: they must not disagree on the plan -> KERNEL there
-        const bool gram_ok = std::is_same<T, double>::value && K <= 2048 && N >= 4096 && !c->reducer;
+        const bool gram_ok = K <= 2048 && N >= 4096 && !c->reducer;
         algo = (gram_ok && (1 + A) * pass_s > syrk_s + 2.5 * pass_s + A * 25e-6) ? PLS_HIP_ALGO_GRAM
                                                                                : PLS_HIP_ALGO_KERNEL;
     }

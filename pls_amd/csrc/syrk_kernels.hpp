@@ -22,15 +22,25 @@ namespace plsk {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SYRK_TB = 128;  // block tile (columns of X per panel)
-constexpr int SYRK_RB = 32;   // rows per slab
-constexpr int SYRK_LDP = 34;  // padded slab rows in LDS (doubles)
-constexpr size_t SYRK_LDS_BYTES = 2 * (size_t)SYRK_TB * SYRK_LDP * sizeof(double);
+// per storage type: V rows per 16-byte access, slab of RB = 16*V rows (256-byte column segments), LDS row
+// count padded by 2 elements: conflict-free operand reads for 8-byte (fp64: stride 34 doubles) and 4-byte
+// (fp32: stride 66 floats) elements alike.  fp32 panels are converted to fp64 at the operand read, so
+// the accumulation policy (fp64) is the same as everywhere else in the library.
+template <typename T>
+struct SyrkCfg {
+    static constexpr int V = 16 / sizeof(T);
+    static constexpr int RB = 16 * V;
+    static constexpr int LDP = RB + 2;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)SYRK_TB * LDP * sizeof(T);
+};
 
 // blockIdx.x enumerates the nbk*(nbk+1)/2 blocks (bi <= bj); blockIdx.y = row split.
-__global__ __launch_bounds__(256, 2) void syrk_f64_kernel(const double *__restrict__ X, i64 ldx, i64 N,
-                                                          int K, int nbk, double *__restrict__ part) {
-    extern __shared__ double slab[];  // As[TB][LDP], Bs[TB][LDP]
-    double *As = slab, *Bs = slab + SYRK_TB * SYRK_LDP;
+template <typename T>
+__global__ __launch_bounds__(256, 2) void syrk_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
+                                                      double *__restrict__ part) {
+    constexpr int V = SyrkCfg<T>::V, SYRK_RB = SyrkCfg<T>::RB, SYRK_LDP = SyrkCfg<T>::LDP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];  // As[TB][LDP], Bs[TB][LDP]
+    T *As = reinterpret_cast<T *>(slab_raw), *Bs = As + SYRK_TB * SYRK_LDP;
 
     int bi = 0, rem = blockIdx.x;
     while (rem >= nbk - bi) { rem -= nbk - bi; ++bi; }
@@ -39,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void syrk_f64_kernel(const double *__restri
     if (diag) Bs = As;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // staging map: row pair rp (16 of them), column group cgi (16 of them); 8 columns per thread
+    // staging map: row group rp (16 of them, V rows each), column group cgi (16 of them); 8 columns per thread
     const int rp = tid & 15, cgi = tid >> 4;
     // compute map
     const int a0 = (wv >> 1) * 64, b0 = (wv & 1) * 64;
@@ -52,30 +62,38 @@ __global__ __launch_bounds__(256, 2) void syrk_f64_kernel(const double *__restri
         for (int n = 0; n < 4; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     const i64 nslabs = (N + SYRK_RB - 1) / SYRK_RB;
-    Pack<double, 2> ga[8], gb[8];
+    Pack<T, V> ga[8], gb[8];
 
     auto load_slab = [&](i64 s) {
-        const i64 r0 = s * SYRK_RB + 2 * rp;
+        const i64 r0 = s * SYRK_RB + V * rp;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int ca = bi * SYRK_TB + cgi + 16 * j, cb = bj * SYRK_TB + cgi + 16 * j;
-            ga[j].v[0] = ga[j].v[1] = 0.0;
-            gb[j].v[0] = gb[j].v[1] = 0.0;
-            if (r0 + 1 < N) {
-                if (ca < K) ga[j] = ld_pack_nt<double, 2>(X + r0 + (i64)ca * ldx);
-                if (!diag && cb < K) gb[j] = ld_pack_nt<double, 2>(X + r0 + (i64)cb * ldx);
-            } else if (r0 < N) {  // odd N: the last row has no partner, its slot stays zero
-                if (ca < K) ga[j].v[0] = X[r0 + (i64)ca * ldx];
-                if (!diag && cb < K) gb[j].v[0] = X[r0 + (i64)cb * ldx];
+#pragma unroll
+            for (int e = 0; e < V; ++e) ga[j].v[e] = gb[j].v[e] = (T)0;
+            if (r0 + V <= N) {
+                if (ca < K) ga[j] = ld_pack_nt<T, V>(X + r0 + (i64)ca * ldx);
+                if (!diag && cb < K) gb[j] = ld_pack_nt<T, V>(X + r0 + (i64)cb * ldx);
+            } else if (r0 < N) {  // ragged last rows: element-wise, the missing slots stay zero
+                for (int e = 0; e < V; ++e)
+                    if (r0 + e < N) {
+                        if (ca < K) ga[j].v[e] = X[r0 + e + (i64)ca * ldx];
+                        if (!diag && cb < K) gb[j].v[e] = X[r0 + e + (i64)cb * ldx];
+                    }
             }
         }
     };
-    auto store_slab = [&]() {
+    auto store_slab = [&]() {  // 8-byte pieces: (col*LDP + V*rp)*sizeof(T) is 8-byte aligned for both types
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = cgi + 16 * j;
-            *reinterpret_cast<Pack<double, 2> *>(As + c * SYRK_LDP + 2 * rp) = ga[j];
-            if (!diag) *reinterpret_cast<Pack<double, 2> *>(Bs + c * SYRK_LDP + 2 * rp) = gb[j];
+            constexpr int H = 8 / sizeof(T);  // elements per 8-byte piece
+#pragma unroll
+            for (int e = 0; e < V; e += H) {
+                *reinterpret_cast<Pack<T, H> *>(As + c * SYRK_LDP + V * rp + e) = *reinterpret_cast<const Pack<T, H> *>(&ga[j].v[e]);
+                if (!diag)
+                    *reinterpret_cast<Pack<T, H> *>(Bs + c * SYRK_LDP + V * rp + e) = *reinterpret_cast<const Pack<T, H> *>(&gb[j].v[e]);
+            }
         }
     };
 
@@ -91,9 +109,9 @@ __global__ __launch_bounds__(256, 2) void syrk_f64_kernel(const double *__restri
         for (int kk = 0; kk < SYRK_RB; kk += 4) {
             double a[4], b[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = As[(a0 + 16 * m + li) * SYRK_LDP + kk + lq];
+            for (int m = 0; m < 4; ++m) a[m] = (double)As[(a0 + 16 * m + li) * SYRK_LDP + kk + lq];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = Bs[(b0 + 16 * n + li) * SYRK_LDP + kk + lq];
+            for (int n = 0; n < 4; ++n) b[n] = (double)Bs[(b0 + 16 * n + li) * SYRK_LDP + kk + lq];
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -121,9 +139,12 @@ __global__ __launch_bounds__(256, 2) void syrk_f64_kernel(const double *__restri
 }
 
 // rc: 0 launched (part holds *nb partial K x K matrices), 1 shape not covered
-inline int launch_syrk_f64(hipStream_t stream, int num_cu, const double *X, i64 ldx, i64 N, int K,
-                           double *part, i64 part_capacity_doubles, int *nb) {
-    if (((uintptr_t)X % 16) != 0 || (ldx % 2) != 0 || N < 1) return 1;
+template <typename T>
+int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int K, double *part,
+                i64 part_capacity_doubles, int *nb) {
+    constexpr int SYRK_RB = SyrkCfg<T>::RB;
+    const size_t SYRK_LDS_BYTES = SyrkCfg<T>::LDS_BYTES;
+    if (((uintptr_t)X % 16) != 0 || (ldx % SyrkCfg<T>::V) != 0 || N < 1) return 1;
     const int nbk = (K + SYRK_TB - 1) / SYRK_TB;
     const int nblocks = nbk * (nbk + 1) / 2;
     const i64 nslabs = (N + SYRK_RB - 1) / SYRK_RB;
@@ -137,15 +158,15 @@ inline int launch_syrk_f64(hipStream_t stream, int num_cu, const double *X, i64 
     if (S < 1) return 1;
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_f64_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_kernel<T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYRK_LDS_BYTES) != hipSuccess) {
             (void)hipGetLastError();
             return 1;
         }
         raised = true;
     }
-    hipLaunchKernelGGL(syrk_f64_kernel, dim3(nblocks, (unsigned)S), dim3(256), SYRK_LDS_BYTES, stream, X, ldx, N, K,
-                       nbk, part);
+    hipLaunchKernelGGL(syrk_kernel<T>, dim3(nblocks, (unsigned)S), dim3(256), SYRK_LDS_BYTES, stream, X, ldx, N, K, nbk,
+                       part);
     *nb = (int)S;
     return 0;
 }

@@ -231,7 +231,7 @@ def test_kernel_type2(handle, oracle, po, N, K, M, A):
 
 
 def test_kernel_type2_fp32_storage(handle, oracle, po):
-    """KERNEL_TYPE2 on fp32 storage: X^T X through the column-reduction kernel (the MFMA SYRK is fp64 only)."""
+    """KERNEL_TYPE2 on fp32 storage: fp32 panels through LDS, converted to fp64 at the MFMA operand read."""
     import pls_amd
     torch = _torch()
     N, K, M, A = 1500, 70, 2, 5
@@ -240,6 +240,22 @@ def test_kernel_type2_fp32_storage(handle, oracle, po):
     ref = oracle.plsr(Xh, Yh, A, method=1)
     out = handle.fit_device(X, Y, A, method=pls_amd.KERNEL_TYPE2); handle.synchronize()
     check_against(po, out, ref, oracle.coefficients(ref["R"], ref["Q"]), None, tol_b=1e-9, tol_col=1e-8, tol_inv=1e-7)
+
+
+def test_gram_fp32_tall(handle, oracle, po):
+    """GRAM plan on fp32 storage at a size where the SYRK grid is fully populated, ragged row count"""
+    import pls_amd
+    torch = _torch()
+    N, K, M, A = 70001 * 4 // 4 + 3, 300, 2, 6          # N % 4 != 0: the last slab is ragged
+    X = handle.synth_x(0, N, K, 31, dtype=torch.float32); Y = handle.synth_y(0, N, M, 31, dtype=torch.float32)
+    handle.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_KERNEL)
+    ref = handle.fit_device(X, Y, A); handle.synchronize()
+    handle.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_GRAM)
+    out = handle.fit_device(X, Y, A); handle.synchronize()
+    handle.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_KERNEL)
+    assert po.rel_fro(out["B"].cpu().numpy(), ref["B"].cpu().numpy()) < 2e-5
+    Xh = X[:2000].cpu().numpy().astype(np.float64)
+    assert po.rel_fro(out["T"][:2000, 0].cpu().numpy().astype(np.float64), Xh @ out["R"][:, 0].cpu().numpy()) < 1e-5
 
 
 def test_fp32_storage(handle, oracle, po, mode):
