@@ -14,13 +14,14 @@
 namespace plsk {
 
 // Xt[f][i*K + k] = X[idx[f*ts + i] + k*ldx],  Yt[f][i*M + m] likewise.  grid = folds*ts workgroups.
-__global__ __launch_bounds__(WG) void cv_gather_kernel(const double *__restrict__ X, i64 ldx,
-                                                       const double *__restrict__ Y, i64 ldy, int K,
-                                                       int M, const i64 *__restrict__ idx,
+template <typename T>
+__global__ __launch_bounds__(WG) void cv_gather_kernel(const T *__restrict__ X, i64 ldx,
+                                                       const T *__restrict__ Y, i64 ldy, int K, int M,
+                                                       const i64 *__restrict__ idx,
                                                        double *__restrict__ Xt, double *__restrict__ Yt) {
     const i64 row = idx[blockIdx.x];
-    for (int k = threadIdx.x; k < K; k += WG) Xt[(i64)blockIdx.x * K + k] = X[row + (i64)k * ldx];
-    for (int m = threadIdx.x; m < M; m += WG) Yt[(i64)blockIdx.x * M + m] = Y[row + (i64)m * ldy];
+    for (int k = threadIdx.x; k < K; k += WG) Xt[(i64)blockIdx.x * K + k] = (double)X[row + (i64)k * ldx];
+    for (int m = threadIdx.x; m < M; m += WG) Yt[(i64)blockIdx.x * M + m] = (double)Y[row + (i64)m * ldy];
 }
 
 // per-fold workspace layout (doubles)

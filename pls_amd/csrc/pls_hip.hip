@@ -1020,11 +1020,59 @@ int pls_hip_sse_by_components(pls_hip_handle h, const void *S, int64_t lds, cons
     return sse_device<float>(h, (const float *)S, lds, (const float *)Y, ldy, N, (int)A, (int)M, Q, SSE);
 }
 
+}  // extern "C"
+
+namespace {
+
+// device part of pls_hip_cv_folds on storage type T (X, Y device pointers; E device pointer)
+template <typename T>
+int cv_folds_device(pls_hip_context *h, const T *dX, i64 dldx, const T *dY, i64 dldy, i64 N, int Ki, int Mi, int Ai,
+                    const int64_t *test_idx, int ts, i64 num_folds, double *dE) {
+    const i64 nobs = num_folds * ts;
+    const i64 K = Ki, M = Mi, A = Ai;
+    const plsk::CvLayout L(Ki, Mi, Ai, ts);
+    CHK(ensure(h, h->xx, (size_t)K * K * 8));
+    CHK(ensure(h, h->xy, (size_t)K * M * 8));
+    CHK(ensure(h, h->cvidx, (size_t)nobs * 8));
+    CHK(ensure(h, h->cvx, (size_t)nobs * K * 8));
+    CHK(ensure(h, h->cvy, (size_t)nobs * M * 8));
+    CHK(ensure(h, h->cvws, (size_t)num_folds * (size_t)L.total * 8));
+    double *XX = (double *)h->xx.p, *XYd = (double *)h->xy.p;
+    // XX and XY of the whole matrix, once
+    CHK(compute_xx<T>(h, dX, dldx, N, Ki, XX));
+    {
+        CHK(ensure(h, h->part, (size_t)max_partial_rows(h, N, Ki) * (size_t)(K * M) * 8));
+        CHK(ensure(h, h->red, (size_t)plsk::RED_SLICES * std::max<i64>(K * M, K + 1) * 8));
+        int nb = 0;
+        CHK(launch_xty<T>(h, dX, dldx, dY, dldy, N, Ki, Mi, (double *)h->part.p, &nb));
+        CHK(launch_reduce(h, (const double *)h->part.p, nb, Ki * Mi, nullptr, 0, (double *)h->red.p));
+        hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((Ki * Mi + plsk::WG - 1) / plsk::WG), dim3(plsk::WG), 0,
+                           h->stream, (const double *)h->red.p, Ki * Mi, XYd);
+        LAUNCH_CHECK(h);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->cvidx.p, test_idx, (size_t)nobs * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL((plsk::cv_gather_kernel<T>), dim3((unsigned)nobs), dim3(plsk::WG), 0, h->stream, dX, dldx, dY,
+                       dldy, Ki, Mi, (const i64 *)h->cvidx.p, (double *)h->cvx.p, (double *)h->cvy.p);
+    LAUNCH_CHECK(h);
+    {
+        Scope s(h, PLS_HIP_FAM_SMALL, (i64)num_folds * A * ((i64)K * K + 4 * K) * 8);
+        hipLaunchKernelGGL(plsk::cv_folds_kernel, dim3((unsigned)num_folds), dim3(plsk::UPD_THREADS), (size_t)A * 8,
+                           h->stream, (const double *)XX, (const double *)XYd, (const double *)h->cvx.p,
+                           (const double *)h->cvy.p, Ki, Mi, Ai, ts, (double *)h->cvws.p, dE, (int)h->opt_power_iters);
+        LAUNCH_CHECK(h);
+    }
+    return PLS_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int pls_hip_cv_folds(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy, int64_t N,
                      int64_t K, int64_t M, int64_t A, const int64_t *test_idx, int64_t test_size,
                      int64_t num_folds, int dtype, int mem, double *E) {
     CHK(check_handle(h));
-    if (dtype != PLS_HIP_F64) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "cv_folds: fp64 only");
+    if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
     if (mem != PLS_HIP_MEM_HOST && mem != PLS_HIP_MEM_DEVICE) return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
     if (h->reducer) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "cv_folds: not available on a sharded handle");
     if (N < 2 || K < 1 || M < 1 || A < 1 || A > K || A > 4096 || K > 16384 || (M > 1 && M > plsk::MMAX) || !X || !Y ||
@@ -1035,54 +1083,30 @@ int pls_hip_cv_folds(pls_hip_handle h, const void *X, int64_t ldx, const void *Y
     for (i64 j = 0; j < nobs; ++j)
         if (test_idx[j] < 0 || test_idx[j] >= N) return fail(h, PLS_HIP_ERR_INVALID, "cv_folds: test index out of range");
     CHK(set_device(h));
-    const int Ki = (int)K, Mi = (int)M, Ai = (int)A, ts = (int)test_size;
-    const double *dX = (const double *)X, *dY = (const double *)Y;
+    const size_t es = esize(dtype);
+    const void *dX = X, *dY = Y;
     i64 dldx = ldx, dldy = ldy;
     if (mem == PLS_HIP_MEM_HOST) {
-        const i64 ldn = N + (N & 1);
-        CHK(ensure(h, h->hX, (size_t)ldn * K * 8));
-        CHK(ensure(h, h->hY, (size_t)ldn * M * 8));
-        CHK(h2d(h, h->hX.p, ldn, X, ldx, N, K, 8));
-        CHK(h2d(h, h->hY.p, ldn, Y, ldy, N, M, 8));
-        dX = (const double *)h->hX.p; dY = (const double *)h->hY.p;
+        const i64 ldn = N + ((-N) & 3);  // 16-byte columns for either type
+        CHK(ensure(h, h->hX, (size_t)ldn * K * es));
+        CHK(ensure(h, h->hY, (size_t)ldn * M * es));
+        CHK(h2d(h, h->hX.p, ldn, X, ldx, N, K, es));
+        CHK(h2d(h, h->hY.p, ldn, Y, ldy, N, M, es));
+        dX = h->hX.p; dY = h->hY.p;
         dldx = dldy = ldn;
     }
-    const plsk::CvLayout L(Ki, Mi, Ai, ts);
-    CHK(ensure(h, h->xx, (size_t)K * K * 8));
-    CHK(ensure(h, h->xy, (size_t)K * M * 8));
-    CHK(ensure(h, h->cvidx, (size_t)nobs * 8));
-    CHK(ensure(h, h->cvx, (size_t)nobs * K * 8));
-    CHK(ensure(h, h->cvy, (size_t)nobs * M * 8));
-    CHK(ensure(h, h->cvws, (size_t)num_folds * (size_t)L.total * 8));
     CHK(ensure(h, h->cve, (size_t)nobs * A * M * 8));
-    double *XX = (double *)h->xx.p, *XYd = (double *)h->xy.p;
-    // XX and XY of the whole matrix, once
-    CHK(compute_xx<double>(h, dX, dldx, N, Ki, XX));
-    {
-        CHK(ensure(h, h->part, (size_t)max_partial_rows(h, N, Ki) * (size_t)(K * M) * 8));
-        CHK(ensure(h, h->red, (size_t)plsk::RED_SLICES * std::max<i64>(K * M, K + 1) * 8));
-        int nb = 0;
-        CHK(launch_xty<double>(h, dX, dldx, dY, dldy, N, Ki, Mi, (double *)h->part.p, &nb));
-        CHK(launch_reduce(h, (const double *)h->part.p, nb, Ki * Mi, nullptr, 0, (double *)h->red.p));
-        hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((Ki * Mi + plsk::WG - 1) / plsk::WG), dim3(plsk::WG), 0,
-                           h->stream, (const double *)h->red.p, Ki * Mi, XYd);
-        LAUNCH_CHECK(h);
-    }
-    HIPCHK(h, hipMemcpyAsync(h->cvidx.p, test_idx, (size_t)nobs * 8, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(plsk::cv_gather_kernel, dim3((unsigned)nobs), dim3(plsk::WG), 0, h->stream, dX, dldx, dY, dldy,
-                       Ki, Mi, (const i64 *)h->cvidx.p, (double *)h->cvx.p, (double *)h->cvy.p);
-    LAUNCH_CHECK(h);
     double *dE = (mem == PLS_HIP_MEM_HOST) ? (double *)h->cve.p : E;
-    {
-        Scope s(h, PLS_HIP_FAM_SMALL, (i64)num_folds * A * ((i64)K * K + 4 * K) * 8);
-        hipLaunchKernelGGL(plsk::cv_folds_kernel, dim3((unsigned)num_folds), dim3(plsk::UPD_THREADS), (size_t)A * 8,
-                           h->stream, (const double *)XX, (const double *)XYd, (const double *)h->cvx.p,
-                           (const double *)h->cvy.p, Ki, Mi, Ai, ts, (double *)h->cvws.p, dE, (int)h->opt_power_iters);
-        LAUNCH_CHECK(h);
-    }
-    if (mem == PLS_HIP_MEM_HOST) {
+    int rc;
+    if (dtype == PLS_HIP_F64)
+        rc = cv_folds_device<double>(h, (const double *)dX, dldx, (const double *)dY, dldy, N, (int)K, (int)M, (int)A,
+                                     test_idx, (int)test_size, num_folds, dE);
+    else
+        rc = cv_folds_device<float>(h, (const float *)dX, dldx, (const float *)dY, dldy, N, (int)K, (int)M, (int)A,
+                                    test_idx, (int)test_size, num_folds, dE);
+    if (rc != PLS_HIP_OK) return rc;
+    if (mem == PLS_HIP_MEM_HOST)
         HIPCHK(h, hipMemcpyAsync(E, dE, (size_t)nobs * A * M * 8, hipMemcpyDeviceToHost, h->stream));
-    }
     // the index list is host memory of the caller: the copy above must have consumed it before we return
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PLS_HIP_OK;

@@ -284,12 +284,14 @@ class Handle:
                                             E.data_ptr())
             L.check(rc, self.h)
             return E.permute(0, 2, 1)
-        X = _np_f(X, np.float64); Y = _np_f(Y, np.float64)
+        dt = np.float32 if np.asarray(X).dtype == np.float32 else np.float64
+        X = _np_f(X, dt); Y = _np_f(Y, dt)
         N, K = X.shape
         M = Y.shape[1]
         E = np.zeros((M, A, nf * ts))
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        rc = self._lib.pls_hip_cv_folds(self.h, p(X), N, p(Y), N, N, K, M, A, p(idx), ts, nf, L.F64, L.MEM_HOST, p(E))
+        rc = self._lib.pls_hip_cv_folds(self.h, p(X), N, p(Y), N, N, K, M, A, p(idx), ts, nf,
+                                        L.F64 if dt == np.float64 else L.F32, L.MEM_HOST, p(E))
         L.check(rc, self.h)
         return E.transpose(0, 2, 1)
 

@@ -412,7 +412,7 @@ def test_bad_arguments_every_entry_point(handle):
     assert lib.pls_hip_model_sse(h, p(X), 64, p(Y), 64, 64, 6, 2, 3, p(R), p(Q), 0, 7, p(B)) == 1
     idx = (ctypes.c_int64 * 2)(0, 99)
     assert lib.pls_hip_cv_folds(h, p(X), 64, p(Y), 64, 64, 6, 2, 3, idx, 1, 2, 0, 1, p(B)) == 1   # index out of range
-    assert lib.pls_hip_cv_folds(h, p(X), 64, p(Y), 64, 64, 6, 2, 3, idx, 1, 2, 1, 1, p(B)) == 4   # fp32 folds: unsupported
+    assert lib.pls_hip_cv_folds(h, p(X), 64, p(Y), 64, 64, 6, 2, 3, idx, 1, 2, 5, 1, p(B)) == 1   # bad dtype
     assert lib.pls_hip_set_option(h, 42, 1) == 1 and lib.pls_hip_set_option(h, L.OPT_ALGO, 9) == 1
     assert lib.pls_hip_set_reducer(h, L.ALLREDUCE_FN(0), None, 1, 1) == 1            # rank >= nranks
     assert lib.pls_hip_synth_x(h, p(X), 3, 0, 64, 6, 1, 0) == 1                        # ld < rows
@@ -619,3 +619,21 @@ def test_many_components_equals_least_squares(handle, oracle, po, mode):
     G = T.T @ T
     d = np.sqrt(np.diag(G))
     assert np.abs(G / np.outer(d, d) - np.eye(20)).max() < 1e-8
+
+
+def test_batched_cv_folds_fp32_storage(handle, oracle, po):
+    torch = _torch()
+    N, K, M, A, ts, nf = 400, 40, 2, 4, 25, 9
+    X = handle.synth_x(0, N, K, 5, dtype=torch.float32); Y = handle.synth_y(0, N, M, 5, dtype=torch.float32)
+    Xh = X.cpu().numpy().astype(np.float64); Yh = Y.cpu().numpy().astype(np.float64)
+    rng = np.random.default_rng(3)
+    idx = np.stack([rng.permutation(N)[:ts] for _ in range(nf)])
+    E = handle.cv_folds(X, Y, A, idx).cpu().numpy()
+    Eh = handle.cv_folds(X.cpu().numpy(), Y.cpu().numpy(), A, idx)
+    for f in (0, nf - 1):
+        train = np.setdiff1d(np.arange(N), idx[f])
+        c = oracle.plsr(Xh[train], Yh[train], A)
+        for nc in range(1, A + 1):
+            want = (Yh[idx[f]] - Xh[idx[f]] @ oracle.coefficients(c["R"], c["Q"], nc)).T
+            assert np.abs(E[:, f * ts:(f + 1) * ts, nc - 1] - want).max() < 1e-8     # fp64 accumulation throughout
+    assert np.abs(E - Eh).max() < 1e-12
