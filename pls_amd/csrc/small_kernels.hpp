@@ -63,7 +63,9 @@ __device__ inline void dominant_eigvec_lds(double *G, double *Bm, double *Cm, do
         int same = 1;
         if (act) {
             const double nb = Cm[a + b * M] / t2, ob = Bm[a + b * M];
-            same = fabs(nb - ob) <= 4.0e-16 * fabs(nb) + 1.0e-300;  // fixed point: B has become v1 v1^T
+            // fixed point: B has become v1 v1^T.  B is trace-normalised (entries <= 1), so entries that are
+            // still shrinking towards zero count as converged once they are below 1e-18 in absolute terms
+            same = fabs(nb - ob) <= 4.0e-16 * fabs(nb) + 1.0e-18;
             Bm[a + b * M] = nb;
         }
         if (__syncthreads_and(same)) break;  // uniform exit; also the barrier that publishes Bm
@@ -160,9 +162,17 @@ __device__ inline void component_update_body(const double *__restrict__ red, int
         const double tt = red_sum_n(red, nsl, K + 1, K);
         const double *ra = R + (i64)a * K;
         for (int m = wv; m < M; m += UPD_WAVES) {  // q_m = (r^T XY[:,m]) / tt
-            double s = 0.0;
-            for (int k = lane; k < K; k += WAVE) s = fma(ra[k], XY[k + (i64)m * K], s);
-            s = wave_sum(s);
+            const double *xm = XY + (i64)m * K;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // 4 independent chains: 8 loads in flight per lane
+            int k = lane;
+            for (; k + 3 * WAVE < K; k += 4 * WAVE) {
+                s0 = fma(ra[k], xm[k], s0);
+                s1 = fma(ra[k + WAVE], xm[k + WAVE], s1);
+                s2 = fma(ra[k + 2 * WAVE], xm[k + 2 * WAVE], s2);
+                s3 = fma(ra[k + 3 * WAVE], xm[k + 3 * WAVE], s3);
+            }
+            for (; k < K; k += WAVE) s0 = fma(ra[k], xm[k], s0);
+            double s = wave_sum((s0 + s1) + (s2 + s3));
             if (lane == 0) {
                 qs[m] = s / tt;
                 Q[m + (i64)a * M] = s / tt;
@@ -194,9 +204,17 @@ __device__ inline void component_update_body(const double *__restrict__ red, int
             int i = 0, rem = pr;
             while (rem >= M - i) { rem -= M - i; ++i; }
             const int j = i + rem;
-            double s = 0.0;
-            for (int k = lane; k < K; k += WAVE) s = fma(XY[k + (i64)i * K], XY[k + (i64)j * K], s);
-            s = wave_sum(s);
+            const double *xi = XY + (i64)i * K, *xj = XY + (i64)j * K;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int k = lane;
+            for (; k + 3 * WAVE < K; k += 4 * WAVE) {
+                s0 = fma(xi[k], xj[k], s0);
+                s1 = fma(xi[k + WAVE], xj[k + WAVE], s1);
+                s2 = fma(xi[k + 2 * WAVE], xj[k + 2 * WAVE], s2);
+                s3 = fma(xi[k + 3 * WAVE], xj[k + 3 * WAVE], s3);
+            }
+            for (; k < K; k += WAVE) s0 = fma(xi[k], xj[k], s0);
+            const double s = wave_sum((s0 + s1) + (s2 + s3));
             if (lane == 0) { Gs[i + j * M] = s; Gs[j + i * M] = s; }
         }
         __syncthreads();
