@@ -68,7 +68,7 @@ __global__ __launch_bounds__(UPD_THREADS) void cv_folds_kernel(
     }
     for (int j = tid; j < ts * M; j += UPD_THREADS) yh[j] = 0.0;
     __syncthreads();
-    component_update_body(nullptr, 1, XYf, Wf, Pf, Qf, Rf, v, K, M, A, -1, 0, power_iters, 0, cs, sh);
+    component_update_call(nullptr, 1, XYf, Wf, Pf, Qf, Rf, v, K, M, A, -1, 0, power_iters, 0, cs, sh);
 
     for (int a = 0; a < A; ++a) {
         __syncthreads();  // r_a (in v) is complete
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(UPD_THREADS) void cv_folds_kernel(
         const double tt = block_sum<UPD_WAVES>(part, ttred);  // tt = r^T XX_train r
         if (tid == 0) red1[K] = tt;
         __syncthreads();
-        component_update_body(red1, 1, XYf, Wf, Pf, Qf, Rf, v, K, M, A, a, 0, power_iters, 0, cs, sh);
+        component_update_call(red1, 1, XYf, Wf, Pf, Qf, Rf, v, K, M, A, a, 0, power_iters, 0, cs, sh);
         __syncthreads();
         for (int j = tid; j < ts * M; j += UPD_THREADS) {  // residuals of the test rows with a+1 components
             const int i = j / M, m = j % M;

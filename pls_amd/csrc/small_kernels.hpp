@@ -100,6 +100,272 @@ __device__ inline void dominant_eigvec_lds(double *G, double *Bm, double *Cm, do
     __syncthreads();
 }
 
+// ---- few responses (2 <= M <= 8): thread-per-k form of the component update ----------------------
+// A wave that walks a K-vector on its own is latency-bound (K/64 dependent round trips to L2: 31 us
+// for the 36 pair products of M = 8, K = 4096).  Here every thread owns the entries k = tid + i*1024
+// of all M columns of XY instead, so the M loads of an entry are independent, the deflation of XY
+// (:429) and the Gram matrix XY^T XY (:405) come out of the same registers, and the sums over k are
+// one butterfly per value plus a fixed-order sum over the 16 waves.
+
+__device__ __forceinline__ void wave_lds_sync() {  // LDS hand-over between the lanes of ONE wave
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// dominant_eigvec_lds for MM*MM <= 64, run by ONE wave without workgroup barriers.  G, Bm, Cm: MM x MM
+// (stride MM, zero-padded beyond the M used rows/columns -- the zeros are exact under every step).
+template <int MM>
+__device__ __forceinline__ void dominant_eigvec_wave(const double *G, double *Bm, double *Cm, double *qv, int iters) {
+    static_assert(MM * MM <= WAVE, "one matrix entry per lane");
+    const int lane = threadIdx.x & 63;
+    const int a = lane % MM, b = lane / MM;
+    const bool act = lane < MM * MM;
+    double tr = 0.0;
+#pragma unroll
+    for (int c = 0; c < MM; ++c) tr += G[c + c * MM];
+    double cur = act ? G[a + b * MM] / tr : 0.0;
+    if (act) Bm[a + b * MM] = cur;
+    wave_lds_sync();
+    for (int it = 0; it < iters; ++it) {
+        double s = 0.0;
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < MM; ++c) s = fma(Bm[a + c * MM], Bm[c + b * MM], s);
+            Cm[a + b * MM] = s;
+        }
+        wave_lds_sync();
+        double t2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < MM; ++c) t2 += Cm[c + c * MM];
+        const double nb = s / t2;
+        const bool moved = act && !(fabs(nb - cur) <= 4.0e-16 * fabs(nb) + 1.0e-18);  // see dominant_eigvec_lds
+        cur = nb;
+        if (act) Bm[a + b * MM] = nb;
+        wave_lds_sync();
+        if (__builtin_amdgcn_ballot_w64(moved) == 0) break;
+    }
+    int best = 0;
+    double bd = Bm[0];
+#pragma unroll
+    for (int c = 1; c < MM; ++c)
+        if (Bm[c + c * MM] > bd) { bd = Bm[c + c * MM]; best = c; }
+    if (lane < MM) qv[lane] = Bm[lane + best * MM];
+    wave_lds_sync();
+    for (int pol = 0; pol < 2; ++pol) {
+        double s = 0.0;
+        if (lane < MM) {
+#pragma unroll
+            for (int c = 0; c < MM; ++c) s = fma(G[lane + c * MM], qv[c], s);
+        }
+        wave_lds_sync();
+        if (lane < MM) qv[lane] = s;
+        wave_lds_sync();
+        double n2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < MM; ++c) n2 = fma(qv[c], qv[c], n2);
+        const double inv = 1.0 / sqrt(n2);
+        wave_lds_sync();
+        if (lane < MM) qv[lane] = s * inv;
+        wave_lds_sync();
+    }
+    int big = 0;
+#pragma unroll
+    for (int c = 1; c < MM; ++c)
+        if (fabs(qv[c]) > fabs(qv[big])) big = c;
+    const double sgn = (qv[big] < 0.0) ? -1.0 : 1.0;
+    wave_lds_sync();
+    if (lane < MM) qv[lane] *= sgn;
+    wave_lds_sync();
+}
+
+// Sums of N per-lane values over the 64 lanes of a wave in N-1 + (levels left) exchanges instead of 6 N:
+// at every level the two partner lanes split the remaining values between them, each keeping the sum of
+// its half.  Returns the index of the value whose total ends in g[0] of this lane (valid == false: none).
+// Every total is a fixed butterfly tree over the lanes, so equal inputs give equal bits.
+template <int N, int MASK>
+__device__ __forceinline__ int wave_multi_sum(double *g, int lane, bool &valid) {
+    if constexpr (MASK == 0) {
+        return 0;
+    } else if constexpr (N == 1) {
+        g[0] += shfl_xor_f64(g[0], MASK);
+        return wave_multi_sum<1, MASK / 2>(g, lane, valid);
+    } else {
+        constexpr int H = (N + 1) / 2;
+        const bool up = (lane & MASK) != 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const double lo = g[i], hi = (i + H < N) ? g[i + H] : 0.0;
+            const double keep = up ? hi : lo, send = up ? lo : hi;
+            g[i] = keep + shfl_xor_f64(send, MASK);
+        }
+        const int idx = wave_multi_sum<H, MASK / 2>(g, lane, valid) + (up ? H : 0);
+        valid = valid && (idx < N);
+        return idx;
+    }
+}
+
+// g[pair(i,j)] += x[i] x[j] for i <= j, pairs numbered row by row (compile-time indices: g stays in registers)
+template <int MM>
+__device__ __forceinline__ void gram_add(const double (&x)[MM], double (&g)[MM * (MM + 1) / 2]) {
+#pragma unroll
+    for (int i = 0; i < MM; ++i)
+#pragma unroll
+        for (int j = i; j < MM; ++j) {
+            const int idx = i * MM - (i * (i - 1)) / 2 + (j - i);
+            g[idx] = fma(x[i], x[j], g[idx]);
+        }
+}
+
+// Everything of component_update_body up to and including w_n for 2 <= M <= MM.  Returns after the
+// workgroup barrier that publishes w_n.
+template <int MM>
+__device__ __forceinline__ void narrow_update(const double *__restrict__ red, int nsl, double *__restrict__ XY,
+                                     double *__restrict__ P, double *__restrict__ Q,
+                                     const double *__restrict__ R, double *__restrict__ W, int K, int M, int A,
+                                     int a, int power_iters, UpdShared &sh) {
+    constexpr int NP = MM * (MM + 1) / 2;
+    static_assert(UPD_WAVES * NP <= 32 * 32, "wave partials live in UpdShared::Bs");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool last = (a + 1 >= A);
+    // columns m >= M alias column M-1 (loaded unconditionally, value replaced by 0): a conditional load
+    // would put a wait on the join of every branch and serialise the M loads of an entry
+    i64 co[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) co[m] = (i64)(m < M ? m : M - 1) * K;
+    double g[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) g[i] = 0.0;
+
+    if (a >= 0) {
+        const double tt = red_sum_n(red, nsl, K + 1, K);
+        const double *ra = R + (i64)a * K;
+        double qa[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) qa[m] = 0.0;
+        double *pa = P + (i64)a * K;
+#pragma unroll 2
+        for (int k = tid; k < K; k += UPD_THREADS) {  // p = X^T t / tt (:427);  q = XY^T r / tt (:428)
+            pa[k] = red_sum_n(red, nsl, K + 1, k) / tt;
+            const double rk = ra[k];
+            double x[MM];
+#pragma unroll
+            for (int m = 0; m < MM; ++m) x[m] = XY[k + co[m]];
+#pragma unroll
+            for (int m = 0; m < MM; ++m) qa[m] = fma(rk, (m < M) ? x[m] : 0.0, qa[m]);
+        }
+        {
+            bool valid = true;
+            const int idx = wave_multi_sum<MM, 32>(qa, lane, valid);
+            if (valid) sh.Cs[wv * MM + idx] = qa[0];
+        }
+        __syncthreads();
+        if (tid < MM) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < UPD_WAVES; ++w) s += sh.Cs[w * MM + tid];
+            s /= tt;
+            sh.qs[tid] = s;
+            if (tid < M) Q[tid + (i64)a * M] = s;
+        }
+        __syncthreads();
+        double qv[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) qv[m] = sh.qs[m];
+        // p is re-read from P (this thread's own store) rather than kept: with the 36 Gram accumulators live the
+        // loop has no registers to spare, and short of them the compiler issues its loads one at a time
+        for (int k = tid; k < K; k += UPD_THREADS) {  // XY -= (p q^T) tt (:429), Gram of the new XY
+            const double p = pa[k];
+            double x[MM];
+#pragma unroll
+            for (int m = 0; m < MM; ++m) x[m] = XY[k + co[m]];
+#pragma unroll
+            for (int m = 0; m < MM; ++m) x[m] = (m < M) ? x[m] - (p * qv[m]) * tt : 0.0;
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+                if (m < M) XY[k + (i64)m * K] = x[m];
+            if (!last) gram_add<MM>(x, g);
+        }
+    } else {
+        for (int k = tid; k < K; k += UPD_THREADS) {  // prologue: XY = reduced X^T Y (or already in place)
+            double x[MM];
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                x[m] = 0.0;
+                if (m < M) {
+                    if (red) {
+                        x[m] = red_sum_n(red, nsl, K * M, k + m * K);
+                        XY[k + (i64)m * K] = x[m];
+                    } else {
+                        x[m] = XY[k + (i64)m * K];
+                    }
+                }
+            }
+            gram_add<MM>(x, g);
+        }
+    }
+    if (last) return;
+
+    double *part = sh.Bs;  // [wave][pair]
+    {
+        bool valid = true;
+        const int idx = wave_multi_sum<NP, 32>(g, lane, valid);
+        if (valid) part[wv * NP + idx] = g[0];
+    }
+    __syncthreads();
+    if (tid < NP) {
+        int i = 0, rem = tid;
+        while (rem >= MM - i) { rem -= MM - i; ++i; }
+        const int j = i + rem;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < UPD_WAVES; ++w) s += part[w * NP + tid];
+        sh.Gs[i + j * MM] = s;
+        sh.Gs[j + i * MM] = s;
+    }
+    __syncthreads();
+    if (wv == 0) dominant_eigvec_wave<MM>(sh.Gs, sh.Bs, sh.Cs, sh.qs, power_iters);
+    __syncthreads();
+    double qv[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) qv[m] = sh.qs[m];
+    double *wn = W + (i64)(a + 1) * K;
+    // this thread's first 4 entries of w stay in registers between the product and the normalisation
+    // (all of them when K <= 4096); their loads are unconditional on a clamped index so that all 4 x M
+    // are in flight together
+    double ss = 0.0;
+    double wl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + i * UPD_THREADS, kc = k < K ? k : K - 1;
+        double x[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) x[m] = XY[kc + co[m]];
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) s = fma((m < M) ? x[m] : 0.0, qv[m], s);
+        wl[i] = (k < K) ? s : 0.0;
+        ss = fma(wl[i], wl[i], ss);
+    }
+    for (int k = tid + 4 * UPD_THREADS; k < K; k += UPD_THREADS) {  // w = XY q (:408)
+        double x[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) x[m] = XY[k + co[m]];
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) s = fma((m < M) ? x[m] : 0.0, qv[m], s);
+        wn[k] = s;
+        ss = fma(s, s, ss);
+    }
+    ss = block_sum<UPD_WAVES>(ss, sh.sred);
+    const double nrm = sqrt(ss);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + i * UPD_THREADS;
+        if (k < K) wn[k] = wl[i] / nrm;
+    }
+    for (int k = tid + 4 * UPD_THREADS; k < K; k += UPD_THREADS) wn[k] = wn[k] / nrm;  // own element: no hazard
+}
+
 // a = index of the component whose pass just finished (-1: prologue, red holds X^T Y).
 // red is the RED_SLICES-sliced output of reduce_partials_kernel (summed over ranks when sharded).
 //   a >= 0 : red = [X^T t (K), t^T t];  p = red/tt (:427) -> P[:,a];  q = XY^T r_a / tt (:428)
@@ -109,7 +375,7 @@ __device__ inline void dominant_eigvec_lds(double *G, double *Bm, double *Cm, do
 // Dynamic LDS: A doubles (the p_j^T w inner products).
 // Body shared by component_update_kernel (one fit) and cv_folds_kernel (one fold per workgroup).
 // red == nullptr with a < 0: XY already holds the covariance.  nsl: slices in red.
-__device__ inline void component_update_body(const double *__restrict__ red, int nsl,
+__device__ __forceinline__ void component_update_body(const double *__restrict__ red, int nsl,
                                              double *__restrict__ XY, double *__restrict__ W,
                                              double *__restrict__ P, double *__restrict__ Q,
                                              double *__restrict__ R, double *__restrict__ vnext, int K,
@@ -122,7 +388,15 @@ __device__ inline void component_update_body(const double *__restrict__ red, int
     // of XY in registers from the Y-loading update through to the next weight vector; the q dot product
     // is one workgroup reduction instead of one wave walking K, and XY is not re-read.
     const bool fast = (M == 1 && K <= 4 * UPD_THREADS && a >= 0);
-    if (fast) {
+    const bool narrow = (M >= 2 && M <= 8);
+    if (narrow) {
+        if (M <= 2)
+            narrow_update<2>(red, nsl, XY, P, Q, R, W, K, M, A, a, power_iters, sh);
+        else if (M <= 4)
+            narrow_update<4>(red, nsl, XY, P, Q, R, W, K, M, A, a, power_iters, sh);
+        else
+            narrow_update<8>(red, nsl, XY, P, Q, R, W, K, M, A, a, power_iters, sh);
+    } else if (fast) {
         const double tt = red_sum_n(red, nsl, K + 1, K);
         const double *ra = R + (i64)a * K;
         double xv[4], pv[4];
@@ -190,7 +464,7 @@ __device__ inline void component_update_body(const double *__restrict__ red, int
     __syncthreads();  // XY complete (same workgroup: its own global stores are visible)
 
     double *wn = W + (i64)n * K;
-    if (fast) {
+    if (fast || narrow) {
         // w_n already written above
     } else if (M == 1) {
         double ss = 0.0;
@@ -267,6 +541,15 @@ __device__ inline void component_update_body(const double *__restrict__ red, int
         rn[k] = r;
         vnext[k] = nipals ? w : r;
     }
+}
+
+// Out-of-line copy for callers that need the body more than once (cv_folds_kernel): inlining it twice next
+// to their own loops overflows the 128 registers a 1024-thread workgroup leaves per lane.
+__device__ __noinline__ void component_update_call(const double *red, int nsl, double *XY, double *W, double *P,
+                                                   double *Q, double *R, double *vnext, int K, int M, int A,
+                                                   int a, int nipals, int power_iters, int split_rotate,
+                                                   double *cs, UpdShared &sh) {
+    component_update_body(red, nsl, XY, W, P, Q, R, vnext, K, M, A, a, nipals, power_iters, split_rotate, cs, sh);
 }
 
 __global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
