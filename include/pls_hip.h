@@ -93,7 +93,8 @@ typedef enum {
     PLS_HIP_OPT_FUSE = 2,       /* 0: one kernel per product (Xv, X^T t, deflate); 1 (default): row-tile-resident fused pass when the shape allows */
     PLS_HIP_OPT_PROFILE = 3,    /* HIP events on the launch stream: 1 = around the streaming kernels over X, 2 = around every kernel */
     PLS_HIP_OPT_POWER_ITERS = 4, /* squarings of the S^T S power iteration (m > 1); default 48 */
-    PLS_HIP_OPT_FUSED_GRID = 5   /* workgroups of the fused pass; 0 (default) = 8 per CU */
+    PLS_HIP_OPT_FUSED_GRID = 5,  /* workgroups of the fused pass; 0 (default) = 2 per CU */
+    PLS_HIP_OPT_WORK_LAYOUT = 6  /* NIPALS work buffer (the deflated copy of X) of a fused fit: 1 (default) row-tile-major, 0 column-major */
 } pls_hip_option;
 
 /*

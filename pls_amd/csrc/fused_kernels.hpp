@@ -49,6 +49,15 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
     __builtin_amdgcn_raw_buffer_store_b128(raw, r, voff, 0, AUX);
 }
 
+// Matrix layouts: element (i, k) of a matrix with column stride ld and tile stride ts lives at
+//   (i / R) * ts + (i % R) + k * ld.
+// The caller's column-major matrices are (ld, ts = R): a tile is K separate 256-byte segments.  The
+// library's own deflated copy of X (the NIPALS work buffer, never seen by the caller) is stored
+// ROW-TILE-MAJOR, (ld = R, ts = R*K): the R x K tile is one contiguous R*K*s-byte block, column-major
+// inside.  Same kernel, same arithmetic; only the two strides differ.  Why: a read+write sweep that
+// touches memory in 256-byte pieces stops at ~5.0 TB/s on MI355X, in >= 4 KB contiguous pieces it
+// reaches 5.9-6.3 TB/s (profiles/r1/rw_probe.txt) -- reads alone do not care (5.9 TB/s either way).
+//
 // Addressing: every access of a tile is (wave-uniform descriptor for the column group) +
 // (per-lane 32-bit byte offset that never changes): the descriptor base X + tile*R + j*CG*ld
 // lives in SGPRs, the lane offset (rp*V + cg*ld)*s in ONE VGPR, so the CPT loads in flight cost
@@ -61,7 +70,7 @@ constexpr int AUX_NT = 2;
 
 template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX = AUX_NT, int STAUX = AUX_NT>
 __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pass_kernel(
-    const T *X, i64 ldx, T *dst, i64 ldd, i64 N, int K,  // dst may alias X (in-place deflation)
+    const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd, i64 N, int K,  // dst may alias X (in-place deflation)
     const double *__restrict__ v, const T *__restrict__ tprev, const double *__restrict__ pprev,
     T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart) {
     constexpr int RP = R / V;    // lanes along the rows of a tile
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
             const int cols = min(CG, K - CG * j);  // columns of this group that exist (may be <= 0)
             const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldx * (i64)sizeof(T)) : 0u;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<T *>(X + tile * R + (i64)j * CG * ldx), (short)0, (int)nrec, BUF_WORD3);
+                const_cast<T *>(X + tile * tsx + (i64)j * CG * ldx), (short)0, (int)nrec, BUF_WORD3);
             x[j] = buf_ld<T, V, LDAUX>(rs, xo);
             __builtin_amdgcn_sched_barrier(0);  // build one descriptor, issue its load, repeat
         }
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
                 const int cols = min(CG, K - CG * j);
                 const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldd * (i64)sizeof(T)) : 0u;
                 const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-                    dst + tile * R + (i64)j * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
+                    dst + tile * tsd + (i64)j * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
                 buf_st<T, V, STAUX>(rd, dof, x[j]);
             }
         }
@@ -384,11 +393,26 @@ int launch_deflate_tile(hipStream_t stream, int num_cu, const T *src, i64 lds_, 
     return 0;
 }
 
-// rc: 0 = launched, 1 = shape/alignment not covered (caller falls back to the one-product
-// kernels), <0 = launch error.  grid_hint: 0 = auto.
+// Rows per tile of the tile-resident kernels: 256-byte column segments (32 fp64 / 64 fp32 rows).
 template <typename T>
-int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, T *dst, i64 ldd, i64 N,
-                      int K, const double *v, const T *tprev, const double *pprev, T *tout,
+constexpr int tile_rows() { return 256 / (int)sizeof(T); }
+
+// Will launch_fused_pass accept every pass of a fit on (X, ldx) with score columns Tm + a*ldt?  (Decided once
+// per fit: the work buffer's layout depends on it.)
+template <typename T>
+bool fused_pass_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
+    constexpr int V = 16 / sizeof(T);
+    constexpr int CG = 512 / (tile_rows<T>() / V);
+    auto al = [](const void *p, i64 ld) { return ((uintptr_t)p % 16 == 0) && (ld % V == 0); };
+    return al(X, ldx) && al(Tm, ldt) && K <= CG * 32 && N >= 1 && N % V == 0 &&
+           (i64)CG * ldx * (i64)sizeof(T) < (1ll << 31);
+}
+
+// rc: 0 = launched, 1 = shape/alignment not covered (caller falls back to the one-product
+// kernels), <0 = launch error.  grid_hint: 0 = auto.  (ldx, tsx) / (ldd, tsd): column and tile strides.
+template <typename T>
+int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd,
+                      i64 N, int K, const double *v, const T *tprev, const double *pprev, T *tout,
                       double *part, int max_rows, double *sspart, int *nb, int *nss, int grid_hint) {
     constexpr int V = 16 / sizeof(T);
     constexpr int R = 256 / sizeof(T), NT = 512;  // 256-byte column segments: 32 fp64 / 64 fp32 rows
@@ -396,6 +420,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, T *ds
     const bool defl = (tprev != nullptr);
     auto al = [](const void *p, i64 ld) { return ((uintptr_t)p % 16 == 0) && (ld % V == 0); };
     if (!al(X, ldx) || !al(tout, V) || (defl && (!al(dst, ldd) || !al(tprev, V)))) return 1;
+    if (tsx % V != 0 || (defl && tsd % V != 0)) return 1;
     if (K > CG * 32 || N < 1 || N % V != 0) return 1;
     // a column group's byte span (its num_records, and every lane offset) must stay below 2^31
     if ((i64)CG * ldx * (i64)sizeof(T) >= (1ll << 31)) return 1;
@@ -409,10 +434,10 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, T *ds
     do {                                                                                          \
         if (defl)                                                                                 \
             hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, true>), g, b, 0, stream, X,  \
-                               ldx, dst, ldd, N, K, v, tprev, pprev, tout, part, sspart);         \
+                               ldx, tsx, dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart); \
         else                                                                                      \
             hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, false>), g, b, 0, stream, X, \
-                               ldx, dst, ldd, N, K, v, tprev, pprev, tout, part, sspart);         \
+                               ldx, tsx, dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart); \
     } while (0)
     if (K <= CG * 4) FUSED_CASE(4);
     else if (K <= CG * 8) FUSED_CASE(8);

@@ -46,7 +46,7 @@ struct pls_hip_context {
     double *user_red = nullptr;
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
-    i64 opt_fused_grid = 0;
+    i64 opt_fused_grid = 0, opt_work_layout = 1;
     DevBuf part, sspart, red, red2, xx, praw, xy, v, cs, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
@@ -455,7 +455,14 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         CHK(ensure(c, c->red, (size_t)redn * 8));
         red = (double *)c->red.p;
     }
-    if (nipals && A > 1 && N > 0) CHK(ensure(c, c->work, (size_t)N * K * sizeof(T)));
+    // NIPALS keeps the deflated matrix in a library-owned buffer.  When the tile-resident pass covers the fit it
+    // is stored row-tile-major (every R x K tile one contiguous block: fused_kernels.hpp), otherwise column-major
+    // with ld = N for the one-product kernels.
+    constexpr i64 TR = plsk::tile_rows<T>();
+    const bool fused_fit = c->opt_fuse && N > 0 && plsk::fused_pass_covers<T>(X, ldx, N, K, Tm, ldt);
+    const bool tiled_work = nipals && fused_fit && c->opt_work_layout != 0;
+    if (nipals && A > 1 && N > 0)
+        CHK(ensure(c, c->work, tiled_work ? (size_t)((N + TR - 1) / TR) * TR * K * sizeof(T) : (size_t)N * K * sizeof(T)));
     double *part = (double *)c->part.p, *sspart = (double *)c->sspart.p;
     double *XY = (double *)c->xy.p, *v = (double *)c->v.p;
     T *work = (T *)c->work.p;
@@ -504,11 +511,12 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     }
 
     const T *Xc = X;
-    i64 ldc = ldx;
+    i64 ldc = ldx, tsc = TR;  // column stride and tile stride of the current matrix
+    const i64 ldw = tiled_work ? TR : N, tsw = tiled_work ? TR * (i64)K : TR;
     for (int a = 0; a < A; ++a) {
         if (N > 0) {
             bool done = false;
-            if (c->opt_fuse) {
+            if (fused_fit) {
                 // tile-resident pass: [deflate with (t_{a-1}, p_{a-1}) +] t_a = X v, X^T t_a partials
                 int nb = 0, nss = 0;
                 const T *tprev = (nipals && a > 0) ? Tm + (i64)(a - 1) * ldt : nullptr;
@@ -518,17 +526,17 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     const i64 bytes = (tprev ? 2 : 1) * (i64)N * K * sizeof(T) +
                                       (tprev ? 2 : 1) * (i64)N * sizeof(T) + (tprev ? 3 : 2) * (i64)K * 8;
                     Scope s(c, PLS_HIP_FAM_FUSED, bytes);
-                    rc = plsk::launch_fused_pass<T>(c->stream, c->num_cu, Xc, ldc, tprev ? work : nullptr,
-                                                    N, N, K, v, tprev, pprev, Tm + (i64)a * ldt, part,
+                    rc = plsk::launch_fused_pass<T>(c->stream, c->num_cu, Xc, ldc, tsc, tprev ? work : nullptr, ldw, tsw,
+                                                    N, K, v, tprev, pprev, Tm + (i64)a * ldt, part,
                                                     (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid);
                     if (rc != 0) s.on = false;  // nothing was launched: drop the event pair
                 }
                 if (rc == 0) {
                     LAUNCH_CHECK(c);
                     done = true;
-                    if (tprev) { Xc = work; ldc = N; }
+                    if (tprev) { Xc = work; ldc = ldw; tsc = tsw; }
                     CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
-                } else if (rc < 0) {
+                } else {
                     return fail(c, PLS_HIP_ERR_DEVICE, "fused pass launch failed");
                 }
             }
@@ -685,6 +693,7 @@ int pls_hip_set_option(pls_hip_handle h, int option, int64_t value) {
             if (value < 0 || value > (1 << 20)) return fail(h, PLS_HIP_ERR_INVALID, "fused grid out of range");
             h->opt_fused_grid = value;
             return PLS_HIP_OK;
+        case PLS_HIP_OPT_WORK_LAYOUT: h->opt_work_layout = value ? 1 : 0; return PLS_HIP_OK;
         default: return fail(h, PLS_HIP_ERR_INVALID, "unknown option");
     }
 }
@@ -698,6 +707,7 @@ int pls_hip_get_option(pls_hip_handle h, int option, int64_t *value) {
         case PLS_HIP_OPT_PROFILE: *value = h->opt_profile; return PLS_HIP_OK;
         case PLS_HIP_OPT_POWER_ITERS: *value = h->opt_power_iters; return PLS_HIP_OK;
         case PLS_HIP_OPT_FUSED_GRID: *value = h->opt_fused_grid; return PLS_HIP_OK;
+        case PLS_HIP_OPT_WORK_LAYOUT: *value = h->opt_work_layout; return PLS_HIP_OK;
         default: return fail(h, PLS_HIP_ERR_INVALID, "unknown option");
     }
 }

@@ -193,6 +193,31 @@ def test_x_not_modified_and_deterministic(handle, oracle, po, mode):
         assert _torch().equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("N,K,M,A,dt", [(3000, 96, 3, 7, "f64"), (4098, 513, 1, 5, "f64"), (32 * 700 + 2, 40, 2, 4, "f64"),
+                                        (5000, 200, 2, 6, "f32"), (64 * 33 + 4, 1025, 1, 3, "f32")])
+def test_work_layouts_bit_identical(handle, N, K, M, A, dt):
+    """The NIPALS work buffer (the deflated copy of X) is row-tile-major by default and column-major with
+    OPT_WORK_LAYOUT = 0: a storage choice only -- every output must agree bit for bit (ragged last tile,
+    K not a multiple of the 32 column groups, both storage types)."""
+    import pls_amd
+    torch = _torch()
+    dtype = torch.float64 if dt == "f64" else torch.float32
+    X = handle.synth_x(0, N, K, 99, dtype=dtype); Y = handle.synth_y(0, N, M, 99, dtype=dtype)
+    handle.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_NIPALS)
+    try:
+        outs = []
+        for layout in (1, 0):
+            handle.set_option(pls_amd.OPT_WORK_LAYOUT, layout)
+            o = handle.fit_device(X, Y, A); handle.synchronize()
+            outs.append({k: v.clone() for k, v in o.items()})
+        for k in "WPQRTB":
+            assert torch.equal(outs[0][k], outs[1][k]), k
+            assert torch.isfinite(outs[0][k]).all(), k
+    finally:
+        handle.set_option(pls_amd.OPT_WORK_LAYOUT, 1)
+        handle.set_option(pls_amd.OPT_ALGO, 0)
+
+
 def test_t_orthogonal_full_rank_components(handle, po):
     """A = K components on a small matrix: scores mutually orthogonal, P^T R = I, and the
     regression reproduces least squares (B_A=K == lstsq) -- a size-independent property."""
