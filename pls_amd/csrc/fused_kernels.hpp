@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_tile_kernel(
 // Dynamic LDS: 2*K doubles (w and p_prev).
 template <typename T, int V, int R, int NT, int CPT>
 __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
-    const T *src, i64 lds_, T *dst, i64 ldd, i64 N, int K, const T *__restrict__ tprev,
+    const T *src, i64 lds_, i64 tss, T *dst, i64 ldd, i64 tsd, i64 N, int K, const T *__restrict__ tprev,
     const double *__restrict__ pprev, const double *__restrict__ w, T *__restrict__ tout,
     double *__restrict__ sspart) {
     constexpr int RP = R / V, CG = NT / RP, NW = NT / WAVE;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
                 const int cols = min(CG, K - CG * (g0 + j));
                 const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * lds_ * (i64)sizeof(T)) : 0u;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<T *>(src + tile * R + (i64)(g0 + j) * CG * lds_), (short)0, (int)nrec, BUF_WORD3);
+                    const_cast<T *>(src + tile * tss + (i64)(g0 + j) * CG * lds_), (short)0, (int)nrec, BUF_WORD3);
                 x[j] = buf_ld<T, V, AUX_NT>(rs, so);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
                 const int cols = min(CG, K - CG * (g0 + j));
                 const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldd * (i64)sizeof(T)) : 0u;
                 const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-                    dst + tile * R + (i64)(g0 + j) * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
+                    dst + tile * tsd + (i64)(g0 + j) * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
                 buf_st<T, V, AUX_NT>(rd, dof, x[j]);
             }
         }
@@ -346,14 +346,15 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
 
 // rc as launch_fused_pass; *nss = number of t^T t partials written
 template <typename T>
-int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_, T *dst, i64 ldd, i64 N,
-                         int K, const T *tprev, const double *pprev, const double *w, T *tout,
+int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_, i64 tss, T *dst, i64 ldd, i64 tsd,
+                         i64 N, int K, const T *tprev, const double *pprev, const double *w, T *tout,
                          double *sspart, int max_rows, int *nss) {
     constexpr int V = 16 / sizeof(T);
     constexpr int R = 256 / sizeof(T), NT = 512, CPT = 8;
     constexpr int CG = NT / (R / V);
     auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
     if (!al(src, lds_) || !al(dst, ldd) || !al(tprev, V) || !al(tout, V) || N < 1 || N % V != 0) return 1;
+    if (tss % V != 0 || tsd % V != 0) return 1;
     if ((i64)CG * lds_ * (i64)sizeof(T) >= (1ll << 31) || (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     const size_t dyn = (size_t)K * 16;  // w and p_prev
     if (dyn > 72 * 1024) return 1;      // two workgroups per CU must fit the 160 KiB LDS
@@ -371,8 +372,96 @@ int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_,
     const i64 ntiles = (N + R - 1) / R;
     const i64 grid = std::min<i64>(std::min<i64>(ntiles, 2 * (i64)num_cu), max_rows);
     hipLaunchKernelGGL((deflate_score_kernel<T, V, R, NT, CPT>), dim3((unsigned)grid), dim3(NT), (size_t)K * 16,
-                       stream, src, lds_, dst, ldd, N, K, tprev, pprev, w, tout, sspart);
+                       stream, src, lds_, tss, dst, ldd, tsd, N, K, tprev, pprev, w, tout, sspart);
     *nss = (int)grid;
+    return 0;
+}
+
+// Will launch_deflate_score accept every deflating pass of a fit (decided once per fit, like fused_pass_covers)?
+template <typename T>
+bool deflate_score_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
+    constexpr int V = 16 / sizeof(T);
+    constexpr int CG = 512 / ((256 / (int)sizeof(T)) / V);
+    auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
+    return al(X, ldx) && al(Tm, ldt) && N >= 1 && N % V == 0 && (size_t)K * 16 <= 72 * 1024 &&
+           (i64)CG * ldx * (i64)sizeof(T) < (1ll << 31);
+}
+
+// Loading partials p_raw = X^T t for a matrix in (ld, ts) tile addressing -- the row-tile-major work buffer of
+// the semi-fused plan:   part[blockIdx.x*K + k] = sum over the workgroup's tiles and rows of X[i,k] * t[i].
+// grid = (row chunks of tpw tiles, column blocks of CG*CPT columns); one-shot workgroups, 16-byte accesses,
+// a tile's column block is one contiguous CG*CPT*256-byte piece.
+template <typename T, int V, int R, int NT, int CPT>
+__global__ __launch_bounds__(NT, (NT / 256) * 2) void xty_tiled_kernel(const T *X, i64 ldx, i64 tsx, i64 N, int K,
+                                                                       const T *__restrict__ t,
+                                                                       double *__restrict__ part, int tpw) {
+    constexpr int RP = R / V, CG = NT / RP;
+    const int rp = threadIdx.x % RP, cg = threadIdx.x / RP;
+    const int g0 = blockIdx.y * CPT;  // first column group of this block
+    const i64 ntiles = (N + R - 1) / R;
+    const i64 tile0 = (i64)blockIdx.x * tpw, tile1 = min(ntiles, tile0 + (i64)tpw);
+    const uint32_t xoff = (uint32_t)(((i64)rp * V + (i64)cg * ldx) * (i64)sizeof(T));
+    constexpr uint32_t OOR = 0x80000000u;
+    double pacc[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) pacc[j] = 0.0;
+    for (i64 tile = tile0; tile < tile1; ++tile) {
+        const i64 i0 = tile * R + (i64)rp * V;
+        const bool rowok = (i0 < N);
+        const uint32_t xo = rowok ? xoff : OOR;
+        Pack<T, V> x[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int cols = min(CG, K - CG * (g0 + j));
+            const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldx * (i64)sizeof(T)) : 0u;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<T *>(X + tile * tsx + (i64)(g0 + j) * CG * ldx), (short)0, (int)nrec, BUF_WORD3);
+            x[j] = buf_ld<T, V, AUX_NT>(rs, xo);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        double tv[V];
+        if (rowok) {
+            const Pack<T, V> tpk = ld_pack<T, V>(t + i0);
+#pragma unroll
+            for (int e = 0; e < V; ++e) tv[e] = (double)tpk.v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) tv[e] = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+#pragma unroll
+            for (int e = 0; e < V; ++e) pacc[j] = fma((double)x[j].v[e], tv[e], pacc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        double s = pacc[j];
+#pragma unroll
+        for (int m = 1; m < RP; m <<= 1) s += shfl_xor_f64(s, m);
+        const int k = cg + CG * (g0 + j);
+        if (rp == 0 && k < K) part[(i64)blockIdx.x * K + k] = s;
+    }
+}
+
+// rc as launch_fused_pass; *nb = partial rows written (<= max_rows)
+template <typename T>
+int launch_xty_tiled(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 tsx, i64 N, int K, const T *t,
+                     double *part, int max_rows, int *nb) {
+    constexpr int V = 16 / sizeof(T);
+    constexpr int R = 256 / sizeof(T), NT = 512, CPT = 16;
+    constexpr int CG = NT / (R / V);
+    auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
+    if (!al(X, ldx) || !al(t, V) || tsx % V != 0 || N < 1 || N % V != 0 || max_rows < 1) return 1;
+    if ((i64)CG * ldx * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    const i64 ntiles = (N + R - 1) / R;
+    const int nkb = (K + CG * CPT - 1) / (CG * CPT);
+    // ~8 workgroups per CU in total, at most max_rows row chunks
+    const i64 want = std::max<i64>(1, std::min<i64>((8 * (i64)num_cu + nkb - 1) / nkb, max_rows));
+    const i64 tpw = (ntiles + want - 1) / want;
+    const i64 gx = (ntiles + tpw - 1) / tpw;
+    hipLaunchKernelGGL((xty_tiled_kernel<T, V, R, NT, CPT>), dim3((unsigned)gx, (unsigned)nkb), dim3(NT), 0, stream, X,
+                       ldx, tsx, N, K, t, part, (int)tpw);
+    *nb = (int)gx;
     return 0;
 }
 

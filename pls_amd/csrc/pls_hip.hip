@@ -460,7 +460,10 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // with ld = N for the one-product kernels.
     constexpr i64 TR = plsk::tile_rows<T>();
     const bool fused_fit = c->opt_fuse && N > 0 && plsk::fused_pass_covers<T>(X, ldx, N, K, Tm, ldt);
-    const bool tiled_work = nipals && fused_fit && c->opt_work_layout != 0;
+    // wide matrices (no resident tile): deflation + score in one sweep, loading in a second read
+    const bool semi_fit = nipals && c->opt_fuse && !fused_fit && N > 0 &&
+                          plsk::deflate_score_covers<T>(X, ldx, N, K, Tm, ldt);
+    const bool tiled_work = nipals && (fused_fit || semi_fit) && c->opt_work_layout != 0;
     if (nipals && A > 1 && N > 0)
         CHK(ensure(c, c->work, tiled_work ? (size_t)((N + TR - 1) / TR) * TR * K * sizeof(T) : (size_t)N * K * sizeof(T)));
     double *part = (double *)c->part.p, *sspart = (double *)c->sspart.p;
@@ -546,26 +549,37 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 if (nipals && a > 0) {  // X_a = X_{a-1} - t_{a-1} p_{a-1}^T (first one out of place)
                     const T *tprev = Tm + (i64)(a - 1) * ldt;
                     const double *pprev = P + (i64)(a - 1) * K;
-                    if (c->opt_fuse) {  // wide matrices: deflation and score in one sweep (3NK instead of 4NK)
+                    if (semi_fit) {  // wide matrices: deflation and score in one sweep (3NK instead of 4NK)
                         const i64 bytes = 2 * (i64)N * K * sizeof(T) + 2 * (i64)N * sizeof(T) + 2 * (i64)K * 8;
                         Scope s(c, PLS_HIP_FAM_DEFLATE, bytes);
-                        const int rc = plsk::launch_deflate_score<T>(c->stream, c->num_cu, Xc, ldc, work, N, N, K, tprev,
-                                                                     pprev, v, Tm + (i64)a * ldt, sspart,
+                        const int rc = plsk::launch_deflate_score<T>(c->stream, c->num_cu, Xc, ldc, tsc, work, ldw, tsw, N, K,
+                                                                     tprev, pprev, v, Tm + (i64)a * ldt, sspart,
                                                                      (int)ssmax, &nss);
-                        if (rc == 0) {
-                            LAUNCH_CHECK(c);
-                            have_t = true;
-                        } else {
+                        if (rc != 0) {
                             s.on = false;
+                            return fail(c, PLS_HIP_ERR_DEVICE, "deflate+score launch failed");
                         }
+                        LAUNCH_CHECK(c);
+                        have_t = true;
                     }
                     if (!have_t) CHK(launch_deflate<T>(c, Xc, ldc, work, N, N, K, tprev, pprev));
                     Xc = work;
-                    ldc = N;
+                    ldc = ldw;
+                    tsc = tsw;
                 }
                 if (!have_t)
                     CHK(launch_xb<T>(c, Xc, ldc, N, K, v, K, 1, Tm + (i64)a * ldt, ldt, sspart, &nss));  // :419-420
-                CHK(launch_xty<T>(c, Xc, ldc, Tm + (i64)a * ldt, ldt, N, K, 1, part, &nb));           // :421
+                if (tsc != TR) {  // row-tile-major work buffer: the loading in tile addressing (:421)
+                    Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) + (i64)N * sizeof(T) + (i64)K * 8);
+                    if (plsk::launch_xty_tiled<T>(c->stream, c->num_cu, Xc, ldc, tsc, N, K, Tm + (i64)a * ldt, part,
+                                                  (int)prow, &nb) != 0) {
+                        s.on = false;
+                        return fail(c, PLS_HIP_ERR_DEVICE, "tiled loading launch failed");
+                    }
+                    LAUNCH_CHECK(c);
+                } else {
+                    CHK(launch_xty<T>(c, Xc, ldc, Tm + (i64)a * ldt, ldt, N, K, 1, part, &nb));  // :421
+                }
                 CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
             }
         } else {
