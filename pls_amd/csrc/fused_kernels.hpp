@@ -194,63 +194,10 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
     if (tid == 0) sspart[blockIdx.x] = ss;
 }
 
-// Stand-alone rank-1 deflation dst = src - t p^T in the same tile access pattern (256-byte column
-// segments, descriptor + one lane offset, nt policy), no reductions and no barriers.  Any K: a
-// workgroup walks the column groups of its tile CPT at a time.
-template <typename T, int V, int R, int NT, int CPT>
-__global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_tile_kernel(
-    const T *src, i64 lds_, T *dst, i64 ldd, i64 N, int K, const T *__restrict__ t,
-    const double *__restrict__ p) {
-    constexpr int RP = R / V, CG = NT / RP;
-    const int rp = threadIdx.x % RP, cg = threadIdx.x / RP;
-    const uint32_t soff = (uint32_t)(((i64)rp * V + (i64)cg * lds_) * (i64)sizeof(T));
-    const uint32_t doff = (uint32_t)(((i64)rp * V + (i64)cg * ldd) * (i64)sizeof(T));
-    constexpr uint32_t OOR = 0x80000000u;
-    const int ngroups = (K + CG - 1) / CG;
-    for (i64 tile = blockIdx.x; tile * R < N; tile += gridDim.x) {
-        const i64 i0 = tile * R + (i64)rp * V;
-        const bool rowok = (i0 < N);
-        const uint32_t so = rowok ? soff : OOR, dof = rowok ? doff : OOR;
-        double tp[V];
-        if (rowok) {
-            const Pack<T, V> tpk = ld_pack<T, V>(t + i0);
-#pragma unroll
-            for (int e = 0; e < V; ++e) tp[e] = -(double)tpk.v[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < V; ++e) tp[e] = 0.0;
-        }
-        for (int g0 = 0; g0 < ngroups; g0 += CPT) {
-            Pack<T, V> x[CPT];
-#pragma unroll
-            for (int j = 0; j < CPT; ++j) {
-                const int cols = min(CG, K - CG * (g0 + j));
-                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * lds_ * (i64)sizeof(T)) : 0u;
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<T *>(src + tile * R + (i64)(g0 + j) * CG * lds_), (short)0, (int)nrec, BUF_WORD3);
-                x[j] = buf_ld<T, V, AUX_NT>(rs, so);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int j = 0; j < CPT; ++j) {
-                const int k = cg + CG * (g0 + j);
-                const double pk = (k < K) ? p[k] : 0.0;
-#pragma unroll
-                for (int e = 0; e < V; ++e) x[j].v[e] = (T)fma(tp[e], pk, (double)x[j].v[e]);
-                const int cols = min(CG, K - CG * (g0 + j));
-                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldd * (i64)sizeof(T)) : 0u;
-                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-                    dst + tile * R + (i64)(g0 + j) * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
-                buf_st<T, V, AUX_NT>(rd, dof, x[j]);
-            }
-        }
-    }
-}
-
 // Semi-fused sweep for matrices too wide for the resident tile (K > 32 column groups' worth):
 //   X' = X - t_prev p_prev^T (written),  t = X' w,  t^T t partials      -- the loading p = X'^T t then
 // takes one more READ of X' (xty_kernel): 3 N K s of traffic per component instead of 4.
-// Same tile access pattern as deflate_tile_kernel; the column groups of a tile are streamed CPT at
+// Same tile access pattern as the fused pass; the column groups of a tile are streamed CPT at
 // a time (nothing stays resident), the per-lane partial scores are combined once per tile.
 // Dynamic LDS: 2*K doubles (w and p_prev).
 template <typename T, int V, int R, int NT, int CPT>
@@ -462,23 +409,6 @@ int launch_xty_tiled(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 ts
     hipLaunchKernelGGL((xty_tiled_kernel<T, V, R, NT, CPT>), dim3((unsigned)gx, (unsigned)nkb), dim3(NT), 0, stream, X,
                        ldx, tsx, N, K, t, part, (int)tpw);
     *nb = (int)gx;
-    return 0;
-}
-
-// rc as launch_fused_pass
-template <typename T>
-int launch_deflate_tile(hipStream_t stream, int num_cu, const T *src, i64 lds_, T *dst, i64 ldd, i64 N,
-                        int K, const T *t, const double *p) {
-    constexpr int V = 16 / sizeof(T);
-    constexpr int R = 256 / sizeof(T), NT = 512, CPT = 8;  // 256-byte column segments
-    constexpr int CG = NT / (R / V);
-    auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
-    if (!al(src, lds_) || !al(dst, ldd) || !al(t, V) || N < 1 || N % V != 0) return 1;
-    if ((i64)CG * lds_ * (i64)sizeof(T) >= (1ll << 31) || (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
-    const i64 ntiles = (N + R - 1) / R;
-    const i64 grid = std::min<i64>(ntiles, 2 * (i64)num_cu);
-    hipLaunchKernelGGL((deflate_tile_kernel<T, V, R, NT, CPT>), dim3((unsigned)grid), dim3(NT), 0, stream, src,
-                       lds_, dst, ldd, N, K, t, p);
     return 0;
 }
 

@@ -305,8 +305,10 @@ int launch_deflate(pls_hip_context *c, const T *src, i64 lds, T *dst, i64 ldd, i
     const i64 G = std::min<i64>(std::max<i64>(nch, 1), std::max<i64>(1, (16 * c->num_cu) / nkg));
     const i64 bytes = 2 * (i64)N * K * sizeof(T) + (i64)N * sizeof(T) + (i64)K * 8;
     Scope s(c, PLS_HIP_FAM_DEFLATE, bytes);
-    const int trc = plsk::launch_deflate_tile<T>(c->stream, c->num_cu, src, lds, dst, ldd, N, K, t, p);
-    if (trc == 0) {
+    const i64 nrb = (N + (i64)plsk::WG * FV - 1) / ((i64)plsk::WG * FV);
+    if (wide && K <= 65535 && nrb >= 1 && nrb < (1ll << 31)) {  // one 4 KB column piece per workgroup
+        hipLaunchKernelGGL((plsk::deflate_piece_kernel<T, FV>), dim3((unsigned)nrb, (unsigned)K), dim3(plsk::WG), 0,
+                           c->stream, src, lds, dst, ldd, N, t, p);
         LAUNCH_CHECK(c);
         return PLS_HIP_OK;
     }

@@ -270,6 +270,34 @@ __global__ __launch_bounds__(WG) void xty_kernel(const T *__restrict__ X, i64 ld
 }
 
 // ------------------------------------------------------------------------------------
+// dst[i,k] = src[i,k] - t[i] * p[k] on column-major matrices, one-shot workgroups: a workgroup is ONE
+// contiguous 4 KB piece of one column (256 lanes x 16 bytes), one load and one store per lane.
+// grid = (row blocks, K), row blocks fastest.  This is the fastest read+write form on MI355X
+// (pls_amd/csrc/tune/rw_probe.hip, profiles/r1/rw_probe.txt: 6.15 TB/s out of place, 5.96 in place;
+// two columns per workgroup 5.7, the 256-byte tile pattern 5.0): the t piece is re-read once per
+// column, but from L2 / Infinity Cache, not from HBM.
+// ------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(WG) void deflate_piece_kernel(const T *__restrict__ src, i64 lds, T *dst, i64 ldd,
+                                                           i64 N, const T *__restrict__ t,
+                                                           const double *__restrict__ p) {
+    const i64 i0 = ((i64)blockIdx.x * WG + threadIdx.x) * VEC;
+    const int k = blockIdx.y;
+    const double pk = p[k];
+    const T *s = src + (i64)k * lds;
+    T *d = dst + (i64)k * ldd;
+    if (i0 + VEC <= N) {
+        const Pack<T, VEC> tv = ld_pack<T, VEC>(t + i0);
+        Pack<T, VEC> x = ld_pack_nt<T, VEC>(s + i0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x.v[v] = (T)fma(-(double)tv.v[v], pk, (double)x.v[v]);
+        st_pack_nt<T, VEC>(d + i0, x);
+    } else {
+        for (i64 i = i0; i < N; ++i) d[i] = (T)fma(-(double)t[i], pk, (double)s[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // dst[i,k] = src[i,k] - t[i] * p[k].   grid = (row groups, column groups of KC).
 // Algorithmic bytes: 2*N*K*s + N*s + K*8.
 // ------------------------------------------------------------------------------------

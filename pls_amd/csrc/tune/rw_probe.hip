@@ -116,6 +116,26 @@ __global__ __launch_bounds__(NTH) void tile_colblock(const double* __restrict__ 
     }
 }
 
+// rank-1 deflation dst = src - t p^T with one-shot workgroups: NTH threads = NTH/256 columns x 512 rows (2 rows
+// per thread), CPT column sets per thread.  blockIdx.x = row block (fastest), blockIdx.y = column block.
+template <int NTH, int CPT>
+__global__ __launch_bounds__(NTH) void defl_oneshot(const double* __restrict__ X, double* Xo, i64 N, const double* __restrict__ t,
+                                                    const double* __restrict__ p) {
+    constexpr int CW = NTH / 256;  // columns side by side in the workgroup
+    const int rp = threadIdx.x % 256, cw = threadIdx.x / 256;
+    const i64 i0 = (i64)blockIdx.x * 512 + 2 * rp;
+    const P2 tv = *reinterpret_cast<const P2*>(t + i0);
+    P2 x[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) x[j] = *reinterpret_cast<const P2*>(X + i0 + (i64)((blockIdx.y * CPT + j) * CW + cw) * N);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const double pk = p[(blockIdx.y * CPT + j) * CW + cw];
+        x[j].v[0] = fma(-tv.v[0], pk, x[j].v[0]); x[j].v[1] = fma(-tv.v[1], pk, x[j].v[1]);
+        *reinterpret_cast<P2*>(Xo + i0 + (i64)((blockIdx.y * CPT + j) * CW + cw) * N) = x[j];
+    }
+}
+
 template <typename F>
 double time_ms(F&& launch, int reps = 7) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -164,6 +184,18 @@ int main() {
         printf("persistent tile R=%d NT=%d %s grid 512: out-of-place %.0f | in-place %.0f GB/s\n", R, NTH, tag, bytes / a / 1e6, bytes / b / 1e6); \
     }
     TILE(32, 512, false, "plain")
+    {
+        double *tvec, *pvec;
+        CK(hipMalloc(&tvec, N * 8)); CK(hipMalloc(&pvec, K * 8)); CK(hipMemset(tvec, 0, N * 8)); CK(hipMemset(pvec, 0, K * 8));
+#define DEFL(NTH, CPT)                                                                                                    \
+        {                                                                                                                 \
+            const dim3 g((unsigned)(N / 512), K / ((NTH / 256) * CPT));                                                   \
+            double a = time_ms([&] { hipLaunchKernelGGL((defl_oneshot<NTH, CPT>), g, dim3(NTH), 0, 0, X, Xo, N, tvec, pvec); }); \
+            double b = time_ms([&] { hipLaunchKernelGGL((defl_oneshot<NTH, CPT>), g, dim3(NTH), 0, 0, X, X, N, tvec, pvec); });  \
+            printf("defl_oneshot NT=%d CPT=%d (%d KB/WG): out-of-place %.0f | in-place %.0f GB/s\n", NTH, CPT, 4 * (NTH / 256) * CPT, bytes / a / 1e6, bytes / b / 1e6); \
+        }
+        DEFL(256, 1) DEFL(256, 2) DEFL(256, 4) DEFL(512, 1) DEFL(512, 2) DEFL(1024, 1) DEFL(1024, 2)
+    }
 #define CB(R, NTH, CPT)                                                                                                   \
     {                                                                                                                     \
         constexpr int CGc = NTH / (R / 2);                                                                                \
