@@ -1,4 +1,7 @@
-"""Why is the fused pass slower per byte at N = 131072 (C3 / 8) than at N >= 262144?  Placement and grid sweeps."""
+"""Fused-pass launch time against the row count (tile counts around 4096 and 8192), with the column-major
+working copy this showed a 10-30 % spread between neighbouring N (DRAM channel effects of 256-byte pieces at
+particular column strides); the row-tile-major working copy removed it.  Earlier variants of this script swept the
+placement inside a large buffer, the leading dimensions of X and T and the grid size (none of them mattered)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pls_amd

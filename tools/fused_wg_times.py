@@ -1,4 +1,9 @@
-"""Per-workgroup start/end times of the last fused pass of a fit (debug build with PLS_HIP_TSBUF)."""
+"""Per-workgroup start/end times of the last fused pass of a fit.
+
+Needs a TEMPORARY instrumented build that is not in the tree: fused_pass_kernel takes one more pointer argument and
+thread 0 of every workgroup writes {wall_clock64() at entry, at exit, chunks, tiles} to it; the launcher reads the
+device address from the environment variable PLS_HIP_TSBUF.  The numbers this produced are recorded in
+profiles/r1/fused_wg_times.txt (static tile map vs device work queue)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
