@@ -174,6 +174,15 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
             for (int e = 0; e < V; ++e) ss = fma(t[e], t[e], ss);
         }
         // loading: p_raw[k] += sum over the lane's rows of x[i,k] * t[i]   (rows >= N hold x = 0)
+        // fp32 storage: the tile is converted to fp64 again here -- the empty asm hides the stored values from
+        // common-subexpression elimination, which would otherwise keep the fp64 copies of the whole tile made for
+        // the score alive across the barrier (2x the registers of the tile: 135-217 spilled VGPRs, 2.3 TB/s)
+        if (sizeof(T) < sizeof(double)) {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j)
+#pragma unroll
+                for (int e = 0; e < V; ++e) asm volatile("" : "+v"(x[j].v[e]));
+        }
 #pragma unroll
         for (int j = 0; j < CPT; ++j)
 #pragma unroll
