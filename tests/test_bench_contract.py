@@ -48,3 +48,23 @@ def test_bench_prints_one_contract_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_as_the_driver_launches_it():
+    """The driver's N > 1 launch line (torch.distributed.run, one process per rank) with the gloo rehearsal backend
+    and both ranks on the one GPU of the test box: rank 0 prints exactly one line with n_gpus = 2."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "tiny", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["parallelism"] == "row-shard x2"
+    assert d["roofline"]["measured_over"].startswith("separate profiled steps")
