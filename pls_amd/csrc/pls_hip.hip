@@ -47,7 +47,7 @@ struct pls_hip_context {
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
     i64 opt_fused_grid = 0, opt_work_layout = 1;
-    DevBuf part, sspart, red, red2, xx, praw, xy, v, cs, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
+    DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
     std::vector<hipEvent_t> ev_pool;  // grows until pls_hip_get_timing harvests and recycles it
@@ -382,7 +382,13 @@ int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX
             int rc;
             {
                 Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) * ((nbk + 1)) + (i64)K * K * 8);
-                rc = plsk::launch_syrk<T>(c->stream, c->num_cu, X, ldx, N, K, part, S * (i64)K * K, &nb);
+                if (!c->zeros.p) {  // source of out-of-range rows for the LDS-DMA panels
+                    CHK(ensure(c, c->zeros, 256));
+                    HIPCHK(c, hipMemsetAsync(c->zeros.p, 0, 256, c->stream));
+                }
+                static const bool glds = !(getenv("PLS_HIP_SYRK_GLDS") && atoi(getenv("PLS_HIP_SYRK_GLDS")) == 0);
+                rc = plsk::launch_syrk<T>(c->stream, c->num_cu, X, ldx, N, K, part, S * (i64)K * K, &nb,
+                                          glds ? c->zeros.p : nullptr);
                 if (rc != 0) s.on = false;
             }
             if (rc == 0) {
@@ -672,7 +678,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->tab,
+    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->tab,
                       &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)

@@ -138,10 +138,127 @@ __global__ __launch_bounds__(256, 2) void syrk_kernel(const T *__restrict__ X, i
             }
 }
 
+// 16 bytes per lane, global -> LDS without a register destination: lane l's bytes land at lds_base + 16 l
+// (lds_base wave-uniform).  The builtin exists in the device pass only.
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(gsrc, lds_base, 16, 0, 0);
+#else
+    (void)gsrc;
+    (void)lds_base;
+#endif
+}
+
+// ---- LDS-DMA variant ----------------------------------------------------------------------------------
+// The register-staged kernel above exposes the global-load latency of every slab (load -> barrier -> LDS
+// store -> barrier -> 128 MFMAs; only the second workgroup of the CU covers it): 67-68 % MFMA-busy.  Here
+// the panels go global -> LDS directly (global_load_lds_dwordx4: no staging registers, so the 128
+// accumulator registers leave room), into one of two LDS buffers, one slab ahead of the MFMAs, with ONE
+// barrier per slab:
+//     barrier (slab s landed, slab s-1 consumed) -> issue slab s+1 -> 16 MFMAs x RB/4 steps on slab s.
+// An LDS-DMA instruction writes 1 KB lane-linearly, so the LDS image of a panel is [column][8 positions of
+// 16 bytes] (V rows per position, RB = 8 V rows per slab, 128 bytes per column) and cannot be padded; bank
+// conflicts of the operand reads (16 lanes = 16 columns, stride 128 B) are removed by an XOR swizzle
+// instead: the row group q of column c is stored at position q ^ ((c >> 1) & 7) -- applied to the SOURCE
+// address of the DMA and to the READ address alike.
+// Columns >= K read column K-1 again (their products are never written); the launcher requires N % V == 0
+// and sends rows beyond N to a zero block.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void syrk_glds_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
+                                                           const T *__restrict__ zeros, double *__restrict__ part) {
+    constexpr int V = 16 / sizeof(T);   // rows per 16-byte position
+    constexpr int RB = 8 * V;           // rows per slab
+    constexpr int CS = 8 * V;           // elements per column in LDS (128 bytes)
+    constexpr int PANEL = SYRK_TB * CS; // elements per panel buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];  // [2 buffers][A panel, B panel]
+    T *lds = reinterpret_cast<T *>(slab_raw);
+
+    int bi = 0, rem = blockIdx.x;
+    while (rem >= nbk - bi) { rem -= nbk - bi; ++bi; }
+    const int bj = bi + rem;
+    const bool diag = (bi == bj);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int a0 = (wv >> 1) * 64, b0 = (wv & 1) * 64;
+    const int li = lane & 15, lq = lane >> 4;
+    const int fl = li >> 1;  // swizzle key of this lane's operand columns: ((a0 + 16 m + li) >> 1) & 7
+
+    // staging map of the DMA: wave-instruction i covers columns 8 i .. 8 i + 7; lane = (column, position)
+    const int scol = lane >> 3, spos = lane & 7;
+
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    const i64 nslabs = (N + RB - 1) / RB;
+    auto issue = [&](i64 s, int buf) {
+        T *Ab = lds + (size_t)buf * 2 * PANEL, *Bb = Ab + PANEL;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = wv + 4 * j;
+            const int col = 8 * i + scol;
+            const int q = spos ^ ((col >> 1) & 7);
+            const i64 row = s * RB + (i64)q * V;
+            const bool ok = row < N;  // N % V == 0: a position is all-valid or all-invalid
+            const int ca = min(bi * SYRK_TB + col, K - 1);
+            const T *ga = ok ? X + row + (i64)ca * ldx : zeros;
+            glds16(ga, Ab + i * (8 * CS));
+            if (!diag) {
+                const int cb = min(bj * SYRK_TB + col, K - 1);
+                const T *gb = ok ? X + row + (i64)cb * ldx : zeros;
+                glds16(gb, Bb + i * (8 * CS));
+            }
+        }
+    };
+
+    i64 s = blockIdx.y;
+    int buf = 0;
+    if (s < nslabs) issue(s, 0);
+    for (; s < nslabs; s += gridDim.y, buf ^= 1) {
+        __syncthreads();  // vmcnt(0) + barrier: slab s has landed for every wave; the other buffer is free again
+        if (s + gridDim.y < nslabs) issue(s + gridDim.y, buf ^ 1);
+        const T *As = lds + (size_t)buf * 2 * PANEL, *Bs = diag ? As : As + PANEL;
+#pragma unroll
+        for (int kk = 0; kk < RB; kk += 4) {
+            const int r = kk + lq;
+            const int off = (((r / V) ^ fl) * V) + (r % V);
+            double a[4], b[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = (double)As[(a0 + 16 * m + li) * CS + off];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[n] = (double)Bs[(b0 + 16 * n + li) * CS + off];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+    }
+
+    double *out = part + (i64)blockIdx.y * ((i64)K * K);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ga_ = bi * SYRK_TB + a0 + 16 * m + lq + 4 * r;
+                const int gb_ = bj * SYRK_TB + b0 + 16 * n + li;
+                if (ga_ < K && gb_ < K) {
+                    const double v = acc[m][n][r];
+                    out[ga_ + (i64)gb_ * K] = v;
+                    if (!diag) out[gb_ + (i64)ga_ * K] = v;
+                }
+            }
+}
+
 // rc: 0 launched (part holds *nb partial K x K matrices), 1 shape not covered
+// zeros: >= 16 bytes of device zeros (source of the rows beyond N in the LDS-DMA variant); nullptr = register-staged kernel
 template <typename T>
 int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int K, double *part,
-                i64 part_capacity_doubles, int *nb) {
+                i64 part_capacity_doubles, int *nb, const void *zeros = nullptr) {
     constexpr int SYRK_RB = SyrkCfg<T>::RB;
     const size_t SYRK_LDS_BYTES = SyrkCfg<T>::LDS_BYTES;
     if (((uintptr_t)X % 16) != 0 || (ldx % SyrkCfg<T>::V) != 0 || N < 1) return 1;
@@ -156,6 +273,29 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
     S = std::max<i64>(1, std::min<i64>(S, nslabs));
     S = std::min<i64>(S, part_capacity_doubles / ((i64)K * K));
     if (S < 1) return 1;
+    constexpr int V = SyrkCfg<T>::V;
+    if (zeros && N % V == 0 && K >= 1) {  // LDS-DMA variant: slabs of 8 V rows, two LDS buffers of two panels
+        constexpr int RBG = 8 * V;
+        constexpr size_t LDS_G = 2 * 2 * (size_t)SYRK_TB * 128;
+        const i64 nslabs_g = (N + RBG - 1) / RBG;
+        i64 Sg = nblocks <= slots ? slots / nblocks : (8 * slots + nblocks - 1) / nblocks;
+        Sg = std::max<i64>(1, std::min<i64>(Sg, nslabs_g));
+        Sg = std::min<i64>(Sg, part_capacity_doubles / ((i64)K * K));
+        if (Sg < 1) return 1;
+        static bool raised_g = false;
+        if (!raised_g) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_glds_kernel<T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_G) != hipSuccess) {
+                (void)hipGetLastError();
+                return 1;
+            }
+            raised_g = true;
+        }
+        hipLaunchKernelGGL(syrk_glds_kernel<T>, dim3(nblocks, (unsigned)Sg), dim3(256), LDS_G, stream, X, ldx, N, K, nbk,
+                           static_cast<const T *>(zeros), part);
+        *nb = (int)Sg;
+        return 0;
+    }
     static bool raised = false;
     if (!raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_kernel<T>),
