@@ -430,13 +430,13 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // GRAM plan for a KERNEL_TYPE1 request: the K-sized loop runs on XX = X^T X exactly as KERNEL_TYPE2
     // does (no pass over X per component), then the scores are formed in one pass, T = X R.
     // AUTO: pick between the read-only pass plan and the Gram plan from a bandwidth / matrix-core cost
-    // model (measured rates on MI355X: ~6 TB/s streaming reads, ~50 TFLOP/s executed in the fp64 SYRK of
+    // model (measured rates on MI355X: ~6 TB/s streaming reads, ~60 TFLOP/s executed in the fp64 SYRK of
     // which the symmetric half is computed).  GRAM pays off for A >~ K/50.
     i64 algo = c->opt_algo;
     if (algo == PLS_HIP_ALGO_AUTO) {
         const double pass_s = (double)N * K * sizeof(T) / 6.0e12;
         const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
-        const double syrk_s = 2.0 * N * (double)K * K * (nbk + 1) / (2.0 * nbk) / 50.0e12;
+        const double syrk_s = 2.0 * N * (double)K * K * (nbk + 1) / (2.0 * nbk) / 60.0e12;
         // ranks of a sharded fit see different N: they must not disagree on the plan -> KERNEL there
         const bool gram_ok = K <= 2048 && N >= 4096 && !c->reducer;
         algo = (gram_ok && (1 + A) * pass_s > syrk_s + 2.5 * pass_s + A * 25e-6) ? PLS_HIP_ALGO_GRAM
