@@ -77,10 +77,23 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
     constexpr int CG = NT / RP;  // column groups
     constexpr int NW = NT / WAVE;
     static_assert(RP <= WAVE && WAVE % RP == 0 && NT % RP == 0, "tile shape");
-    __shared__ double vs[CG * CPT];
-    __shared__ double ps[DEFL ? CG * CPT : 1];
-    __shared__ double tred[2][NW][R];
-    __shared__ double sred[NW];
+    // LDS: the operand vectors v [CG*CPT] and, when DEFL, p_prev [CG*CPT], the score exchange, the block-sum
+    // scratch.  One static block with a fixed layout (p_prev first): the instruction schedule of the headline
+    // kernel turned out to depend on these addresses (1.3 % slower with the vectors after the exchange buffer or
+    // in dynamic LDS).  Only the 128-column-group shape, whose vectors exceed a static allocation, takes them
+    // from dynamic LDS.
+    constexpr bool DYN = (size_t)2 * CG * CPT * sizeof(double) > 48 * 1024;
+    struct alignas(16) Lds {
+        alignas(16) double ps[(DEFL && !DYN) ? CG * CPT : 2];
+        alignas(16) double vs[DYN ? 2 : CG * CPT];
+        alignas(16) double tred[2][NW][R];
+        alignas(16) double sred[NW];
+    };
+    __shared__ Lds lds;
+    extern __shared__ double fused_dyn[];
+    double *vs = DYN ? fused_dyn : lds.vs, *ps = DYN ? fused_dyn + CG * CPT : lds.ps;
+    auto &tred = lds.tred;
+    double *sred = lds.sred;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int rp = tid % RP, cg = tid / RP;
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
 // Dynamic LDS: 2*K doubles (w and p_prev).
 template <typename T, int V, int R, int NT, int CPT>
 __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
-    const T *src, i64 lds_, i64 tss, T *dst, i64 ldd, i64 tsd, i64 N, int K, const T *__restrict__ tprev,
+    const T *src, i64 lds_, i64 tss, T *dst, i64 ldd, i64 tsd, int rdst, i64 N, int K, const T *__restrict__ tprev,
     const double *__restrict__ pprev, const double *__restrict__ w, T *__restrict__ tout,
     double *__restrict__ sspart) {
     constexpr int RP = R / V, CG = NT / RP, NW = NT / WAVE;
@@ -227,7 +240,10 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
     }
     __syncthreads();
     const uint32_t soff = (uint32_t)(((i64)rp * V + (i64)cg * lds_) * (i64)sizeof(T));
-    const uint32_t doff = (uint32_t)(((i64)rp * V + (i64)cg * ldd) * (i64)sizeof(T));
+    // destination tiles may be shorter than the R rows read at a time (rdst divides R; rdst == R otherwise): the
+    // lane's rows rp*V.. fall into sub-tile (rp*V)/rdst of the R/rdst destination tiles this source tile covers
+    const int dsub = (rp * V) / rdst, dwithin = (rp * V) % rdst, dtiles = R / rdst;
+    const uint32_t doff = (uint32_t)(((i64)dsub * tsd + dwithin + (i64)cg * ldd) * (i64)sizeof(T));
     constexpr uint32_t OOR = 0x80000000u;
     const int ngroups = (K + CG - 1) / CG;
     double ss = 0.0;
@@ -267,11 +283,11 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
                     x[j].v[e] = (T)fma(tp[e], pk, (double)x[j].v[e]);
                     tacc[e] = fma((double)x[j].v[e], wk, tacc[e]);
                 }
-                const int cols = min(CG, K - CG * (g0 + j));
-                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldd * (i64)sizeof(T)) : 0u;
+                // columns >= K are masked per lane (the lane offset may span several destination tiles, so the
+                // descriptor's range check cannot do it here)
                 const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-                    dst + tile * tsd + (i64)(g0 + j) * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
-                buf_st<T, V, AUX_NT>(rd, dof, x[j]);
+                    dst + tile * dtiles * tsd + (i64)(g0 + j) * CG * ldd, (short)0, 0x7fffffff, BUF_WORD3);
+                buf_st<T, V, AUX_NT>(rd, (k < K) ? dof : OOR, x[j]);
             }
         }
 #pragma unroll
@@ -303,14 +319,15 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
 // rc as launch_fused_pass; *nss = number of t^T t partials written
 template <typename T>
 int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_, i64 tss, T *dst, i64 ldd, i64 tsd,
-                         i64 N, int K, const T *tprev, const double *pprev, const double *w, T *tout,
+                         int rdst, i64 N, int K, const T *tprev, const double *pprev, const double *w, T *tout,
                          double *sspart, int max_rows, int *nss) {
     constexpr int V = 16 / sizeof(T);
     constexpr int R = 256 / sizeof(T), NT = 512, CPT = 8;
     constexpr int CG = NT / (R / V);
     auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
     if (!al(src, lds_) || !al(dst, ldd) || !al(tprev, V) || !al(tout, V) || N < 1 || N % V != 0) return 1;
-    if (tss % V != 0 || tsd % V != 0) return 1;
+    if (tss % V != 0 || tsd % V != 0 || rdst < V || R % rdst != 0) return 1;
+    if (((i64)(R / rdst) * tsd + (i64)CG * ldd) * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if ((i64)CG * lds_ * (i64)sizeof(T) >= (1ll << 31) || (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     const size_t dyn = (size_t)K * 16;  // w and p_prev
     if (dyn > 72 * 1024) return 1;      // two workgroups per CU must fit the 160 KiB LDS
@@ -328,7 +345,7 @@ int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_,
     const i64 ntiles = (N + R - 1) / R;
     const i64 grid = std::min<i64>(std::min<i64>(ntiles, 2 * (i64)num_cu), max_rows);
     hipLaunchKernelGGL((deflate_score_kernel<T, V, R, NT, CPT>), dim3((unsigned)grid), dim3(NT), (size_t)K * 16,
-                       stream, src, lds_, tss, dst, ldd, tsd, N, K, tprev, pprev, w, tout, sspart);
+                       stream, src, lds_, tss, dst, ldd, tsd, rdst, N, K, tprev, pprev, w, tout, sspart);
     *nss = (int)grid;
     return 0;
 }
@@ -400,11 +417,11 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void xty_tiled_kernel(const T *
 }
 
 // rc as launch_fused_pass; *nb = partial rows written (<= max_rows)
-template <typename T>
+template <typename T, int CGX = 32>
 int launch_xty_tiled(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 tsx, i64 N, int K, const T *t,
                      double *part, int max_rows, int *nb) {
     constexpr int V = 16 / sizeof(T);
-    constexpr int R = 256 / sizeof(T), NT = 512, CPT = 16;
+    constexpr int R = (512 / CGX) * V, NT = 512, CPT = 16;  // = tile_rows<T, CGX>()
     constexpr int CG = NT / (R / V);
     auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
     if (!al(X, ldx) || !al(t, V) || tsx % V != 0 || N < 1 || N % V != 0 || max_rows < 1) return 1;
@@ -421,16 +438,20 @@ int launch_xty_tiled(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 ts
     return 0;
 }
 
-// Rows per tile of the tile-resident kernels: 256-byte column segments (32 fp64 / 64 fp32 rows).
-template <typename T>
-constexpr int tile_rows() { return 256 / (int)sizeof(T); }
+// Rows per tile of the tile-resident kernels.  CGX = column groups of a 512-thread workgroup:
+//   32  -> 16 lanes along the rows: 256-byte column segments (32 fp64 / 64 fp32 rows), K <= 1024 -- the shape
+//          that can also read the caller's column-major matrices at full rate;
+//   64, 128 -> 8 / 4 lanes along the rows (16 / 8 fp64, 32 / 16 fp32 rows), K <= 2048 / 4096: only for the
+//          row-tile-major working copy, where a tile is contiguous whatever its height.
+template <typename T, int CGX = 32>
+constexpr int tile_rows() { return (512 / CGX) * (16 / (int)sizeof(T)); }
 
 // Will launch_fused_pass accept every pass of a fit on (X, ldx) with score columns Tm + a*ldt?  (Decided once
 // per fit: the work buffer's layout depends on it.)
 template <typename T>
 bool fused_pass_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
     constexpr int V = 16 / sizeof(T);
-    constexpr int CG = 512 / (tile_rows<T>() / V);
+    constexpr int CG = 32;
     auto al = [](const void *p, i64 ld) { return ((uintptr_t)p % 16 == 0) && (ld % V == 0); };
     return al(X, ldx) && al(Tm, ldt) && K <= CG * 32 && N >= 1 && N % V == 0 &&
            (i64)CG * ldx * (i64)sizeof(T) < (1ll << 31);
@@ -438,13 +459,14 @@ bool fused_pass_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) 
 
 // rc: 0 = launched, 1 = shape/alignment not covered (caller falls back to the one-product
 // kernels), <0 = launch error.  grid_hint: 0 = auto.  (ldx, tsx) / (ldd, tsd): column and tile strides.
-template <typename T>
+template <typename T, int CGX = 32>
 int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd,
                       i64 N, int K, const double *v, const T *tprev, const double *pprev, T *tout,
                       double *part, int max_rows, double *sspart, int *nb, int *nss, int grid_hint) {
     constexpr int V = 16 / sizeof(T);
-    constexpr int R = 256 / sizeof(T), NT = 512;  // 256-byte column segments: 32 fp64 / 64 fp32 rows
+    constexpr int R = tile_rows<T, CGX>(), NT = 512;
     constexpr int CG = NT / (R / V);
+    static_assert(CG == CGX, "tile shape");
     const bool defl = (tprev != nullptr);
     auto al = [](const void *p, i64 ld) { return ((uintptr_t)p % 16 == 0) && (ld % V == 0); };
     if (!al(X, ldx) || !al(tout, V) || (defl && (!al(dst, ldd) || !al(tprev, V)))) return 1;
@@ -454,23 +476,41 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     if ((i64)CG * ldx * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     const i64 ntiles = (N + R - 1) / R;
-    i64 grid = grid_hint > 0 ? grid_hint : 2 * (i64)num_cu;  // two resident 512-thread workgroups per CU
+    // CPT <= 16: two resident 512-thread workgroups per CU; CPT = 32 (256 VGPRs): one
+    const int per_cu = (CGX == 32 && K <= CG * 16) ? 2 : 1;
+    i64 grid = grid_hint > 0 ? grid_hint : per_cu * (i64)num_cu;
     grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows);
     if (grid < 1) return 1;
     const dim3 g((unsigned)grid), b(NT);
-#define FUSED_CASE(CPT_)                                                                          \
-    do {                                                                                          \
-        if (defl)                                                                                 \
-            hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, true>), g, b, 0, stream, X,  \
-                               ldx, tsx, dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart); \
-        else                                                                                      \
-            hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, false>), g, b, 0, stream, X, \
-                               ldx, tsx, dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart); \
+#define FUSED_CASE(CPT_)                                                                                      \
+    do {                                                                                                      \
+        const size_t dyn = ((size_t)2 * CG * CPT_ * sizeof(double) > 48 * 1024) ? (size_t)2 * CG * CPT_ * sizeof(double) : 0; \
+        if (dyn > 48 * 1024) {                                                                                \
+            static bool raised[2] = {false, false};                                                           \
+            const void *fn = defl ? reinterpret_cast<const void *>(&fused_pass_kernel<T, V, R, NT, CPT_, true>) \
+                                  : reinterpret_cast<const void *>(&fused_pass_kernel<T, V, R, NT, CPT_, false>); \
+            if (!raised[defl] &&                                                                              \
+                hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { \
+                (void)hipGetLastError();                                                                      \
+                return 1;                                                                                     \
+            }                                                                                                 \
+            raised[defl] = true;                                                                              \
+        }                                                                                                     \
+        if (defl)                                                                                             \
+            hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, true>), g, b, dyn, stream, X, ldx, tsx,  \
+                               dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart);                     \
+        else                                                                                                  \
+            hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, false>), g, b, dyn, stream, X, ldx, tsx, \
+                               dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart);                     \
     } while (0)
-    if (K <= CG * 4) FUSED_CASE(4);
-    else if (K <= CG * 8) FUSED_CASE(8);
-    else if (K <= CG * 16) FUSED_CASE(16);
-    else FUSED_CASE(32);
+    if constexpr (CGX == 32) {
+        if (K <= CG * 4) FUSED_CASE(4);
+        else if (K <= CG * 8) FUSED_CASE(8);
+        else if (K <= CG * 16) FUSED_CASE(16);
+        else FUSED_CASE(32);
+    } else {
+        FUSED_CASE(32);
+    }
 #undef FUSED_CASE
     *nb = (int)grid;
     *nss = (int)grid;

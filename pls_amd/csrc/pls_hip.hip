@@ -472,8 +472,14 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     const bool semi_fit = nipals && c->opt_fuse && !fused_fit && N > 0 &&
                           plsk::deflate_score_covers<T>(X, ldx, N, K, Tm, ldt);
     const bool tiled_work = nipals && (fused_fit || semi_fit) && c->opt_work_layout != 0;
+    // Row-tile-major tiles are contiguous whatever their height, so for 1024 < K <= 4096 the working copy uses
+    // SHORTER tiles (8-32 rows) that do fit the registers of a CU: from the third component on the fully fused
+    // pass runs again (2 N K s per component instead of the semi-fused 3 N K s).  Only the first deflation has
+    // to read the caller's column-major X in 256-byte pieces (deflate_score, writing the short tiles).
+    const int wide_cg = (semi_fit && tiled_work) ? (K <= 64 * 32 ? 64 : (K <= 128 * 32 ? 128 : 0)) : 0;
+    const i64 WR = wide_cg ? (512 / wide_cg) * (i64)(16 / sizeof(T)) : TR;  // rows per tile of the working copy
     if (nipals && A > 1 && N > 0)
-        CHK(ensure(c, c->work, tiled_work ? (size_t)((N + TR - 1) / TR) * TR * K * sizeof(T) : (size_t)N * K * sizeof(T)));
+        CHK(ensure(c, c->work, tiled_work ? (size_t)((N + WR - 1) / WR) * WR * K * sizeof(T) : (size_t)N * K * sizeof(T)));
     double *part = (double *)c->part.p, *sspart = (double *)c->sspart.p;
     double *XY = (double *)c->xy.p, *v = (double *)c->v.p;
     T *work = (T *)c->work.p;
@@ -523,7 +529,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
 
     const T *Xc = X;
     i64 ldc = ldx, tsc = TR;  // column stride and tile stride of the current matrix
-    const i64 ldw = tiled_work ? TR : N, tsw = tiled_work ? TR * (i64)K : TR;
+    const i64 ldw = tiled_work ? WR : N, tsw = tiled_work ? WR * (i64)K : TR;
+    bool cur_tiled = false;  // Xc is the row-tile-major working copy
     for (int a = 0; a < A; ++a) {
         if (N > 0) {
             bool done = false;
@@ -545,11 +552,32 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 if (rc == 0) {
                     LAUNCH_CHECK(c);
                     done = true;
-                    if (tprev) { Xc = work; ldc = ldw; tsc = tsw; }
+                    if (tprev) { Xc = work; ldc = ldw; tsc = tsw; cur_tiled = tiled_work; }
                     CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
                 } else {
                     return fail(c, PLS_HIP_ERR_DEVICE, "fused pass launch failed");
                 }
+            } else if (wide_cg && a >= 2) {
+                // short-tile fused pass on the working copy, in place
+                int nb = 0, nss = 0, rc;
+                const T *tprev = Tm + (i64)(a - 1) * ldt;
+                const double *pprev = P + (i64)(a - 1) * K;
+                {
+                    const i64 bytes = 2 * (i64)N * K * sizeof(T) + 2 * (i64)N * sizeof(T) + 3 * (i64)K * 8;
+                    Scope s(c, PLS_HIP_FAM_FUSED, bytes);
+                    rc = wide_cg == 64
+                             ? plsk::launch_fused_pass<T, 64>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v,
+                                                              tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
+                                                              &nb, &nss, (int)c->opt_fused_grid)
+                             : plsk::launch_fused_pass<T, 128>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v,
+                                                               tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
+                                                               &nb, &nss, (int)c->opt_fused_grid);
+                    if (rc != 0) s.on = false;
+                }
+                if (rc != 0) return fail(c, PLS_HIP_ERR_DEVICE, "short-tile fused pass launch failed");
+                LAUNCH_CHECK(c);
+                done = true;
+                CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
             }
             if (!done) {
                 int nss = 0, nb = 0;
@@ -560,9 +588,9 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     if (semi_fit) {  // wide matrices: deflation and score in one sweep (3NK instead of 4NK)
                         const i64 bytes = 2 * (i64)N * K * sizeof(T) + 2 * (i64)N * sizeof(T) + 2 * (i64)K * 8;
                         Scope s(c, PLS_HIP_FAM_DEFLATE, bytes);
-                        const int rc = plsk::launch_deflate_score<T>(c->stream, c->num_cu, Xc, ldc, tsc, work, ldw, tsw, N, K,
-                                                                     tprev, pprev, v, Tm + (i64)a * ldt, sspart,
-                                                                     (int)ssmax, &nss);
+                        const int rc = plsk::launch_deflate_score<T>(c->stream, c->num_cu, Xc, ldc, tsc, work, ldw, tsw,
+                                                                     (int)(tiled_work ? WR : TR), N, K, tprev, pprev, v,
+                                                                     Tm + (i64)a * ldt, sspart, (int)ssmax, &nss);
                         if (rc != 0) {
                             s.on = false;
                             return fail(c, PLS_HIP_ERR_DEVICE, "deflate+score launch failed");
@@ -574,13 +602,18 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     Xc = work;
                     ldc = ldw;
                     tsc = tsw;
+                    cur_tiled = tiled_work;
                 }
                 if (!have_t)
                     CHK(launch_xb<T>(c, Xc, ldc, N, K, v, K, 1, Tm + (i64)a * ldt, ldt, sspart, &nss));  // :419-420
-                if (tsc != TR) {  // row-tile-major work buffer: the loading in tile addressing (:421)
+                if (cur_tiled) {  // row-tile-major work buffer: the loading in tile addressing (:421)
                     Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) + (i64)N * sizeof(T) + (i64)K * 8);
-                    if (plsk::launch_xty_tiled<T>(c->stream, c->num_cu, Xc, ldc, tsc, N, K, Tm + (i64)a * ldt, part,
-                                                  (int)prow, &nb) != 0) {
+                    const T *ta = Tm + (i64)a * ldt;
+                    const int xrc =
+                        wide_cg == 64    ? plsk::launch_xty_tiled<T, 64>(c->stream, c->num_cu, Xc, ldc, tsc, N, K, ta, part, (int)prow, &nb)
+                        : wide_cg == 128 ? plsk::launch_xty_tiled<T, 128>(c->stream, c->num_cu, Xc, ldc, tsc, N, K, ta, part, (int)prow, &nb)
+                                         : plsk::launch_xty_tiled<T, 32>(c->stream, c->num_cu, Xc, ldc, tsc, N, K, ta, part, (int)prow, &nb);
+                    if (xrc != 0) {
                         s.on = false;
                         return fail(c, PLS_HIP_ERR_DEVICE, "tiled loading launch failed");
                     }
