@@ -402,19 +402,22 @@ def test_extreme_shapes(handle, oracle, po, mode, N, K, M, A):
     check_against(po, out, ref, Bref, ref["T"], col_err=cerr, tol_inv=1e-7)
 
 
-@pytest.mark.parametrize("N,K,M,A", [(600, 1100, 2, 5), (257, 1500, 1, 4)])
+@pytest.mark.parametrize("N,K,M,A", [(600, 1100, 2, 5), (257, 1500, 1, 4), (1030, 2048, 1, 6), (130, 2500, 2, 5),
+                                     (96, 4096, 1, 4), (66, 4100, 2, 4)])
 def test_wide_matrix(handle, oracle, po, mode, N, K, M, A):
-    """K beyond the resident-tile fused pass (fp64: K > 1024): the NIPALS plan takes the semi-fused
-    deflate+score sweep, the KERNEL plan the one-product kernels; same results."""
+    """K beyond the 256-byte-segment resident tile (K > 1024).  NIPALS plan: short-tile fused pass on the working
+    copy for K <= 2048 (16-row fp64 tiles) and K <= 4096 (8-row tiles) from component 2 on, the semi-fused
+    deflate+score sweep before that, for odd N (257: no 16-byte row packs) and beyond 4096 columns; KERNEL plan: the
+    one-product kernels.  Same results."""
     Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
     ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
     out = handle.fit_device(to_dev(Xh), to_dev(Yh), A); handle.synchronize()
     check_against(po, out, ref, Bref, ref["T"], col_err=cerr)
 
 
-def test_wide_matrix_fp32(handle, oracle, po, mode):
+@pytest.mark.parametrize("N,K,M,A", [(512, 2300, 3, 4), (516, 1536, 1, 5), (260, 4096, 2, 5)])
+def test_wide_matrix_fp32(handle, oracle, po, mode, N, K, M, A):
     torch = _torch()
-    N, K, M, A = 512, 2300, 3, 4
     X = handle.synth_x(0, N, K, 11, dtype=torch.float32); Y = handle.synth_y(0, N, M, 11, dtype=torch.float32)
     Xh = X.cpu().numpy().astype(np.float64); Yh = Y.cpu().numpy().astype(np.float64)
     ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
