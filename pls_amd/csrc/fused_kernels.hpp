@@ -350,6 +350,62 @@ int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_,
     return 0;
 }
 
+// Copy of a column-major matrix into row-tile-major storage with tiles of rdst rows (rdst divides R): read in the
+// 256-byte-segment pattern, written as contiguous tile pieces.  Used once per fit by the KERNEL plan on wide
+// matrices (1024 < K <= 4096), whose read-only passes then run fused on the short tiles.
+template <typename T, int V, int R, int NT, int CPT>
+__global__ __launch_bounds__(NT, (NT / 256) * 2) void retile_kernel(const T *src, i64 lds_, T *dst, i64 ldd, i64 tsd,
+                                                                    int rdst, i64 N, int K) {
+    constexpr int RP = R / V, CG = NT / RP;
+    const int rp = threadIdx.x % RP, cg = threadIdx.x / RP;
+    const uint32_t soff = (uint32_t)(((i64)rp * V + (i64)cg * lds_) * (i64)sizeof(T));
+    const int dsub = (rp * V) / rdst, dwithin = (rp * V) % rdst, dtiles = R / rdst;
+    const uint32_t doff = (uint32_t)(((i64)dsub * tsd + dwithin + (i64)cg * ldd) * (i64)sizeof(T));
+    constexpr uint32_t OOR = 0x80000000u;
+    const int ngroups = (K + CG - 1) / CG;
+    for (i64 tile = blockIdx.x; tile * R < N; tile += gridDim.x) {
+        const bool rowok = (tile * R + (i64)rp * V < N);
+        const uint32_t so = rowok ? soff : OOR, dof = rowok ? doff : OOR;
+        for (int g0 = 0; g0 < ngroups; g0 += CPT) {
+            Pack<T, V> x[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int cols = min(CG, K - CG * (g0 + j));
+                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * lds_ * (i64)sizeof(T)) : 0u;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<T *>(src + tile * R + (i64)(g0 + j) * CG * lds_), (short)0, (int)nrec, BUF_WORD3);
+                x[j] = buf_ld<T, V, AUX_NT>(rs, so);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int k = cg + CG * (g0 + j);
+                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+                    dst + tile * dtiles * tsd + (i64)(g0 + j) * CG * ldd, (short)0, 0x7fffffff, BUF_WORD3);
+                buf_st<T, V, AUX_NT>(rd, (k < K) ? dof : OOR, x[j]);
+            }
+        }
+    }
+}
+
+// rc as launch_fused_pass
+template <typename T>
+int launch_retile(hipStream_t stream, int num_cu, const T *src, i64 lds_, T *dst, i64 ldd, i64 tsd, int rdst, i64 N,
+                  int K) {
+    constexpr int V = 16 / sizeof(T);
+    constexpr int R = 256 / sizeof(T), NT = 512, CPT = 8;
+    constexpr int CG = NT / (R / V);
+    auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
+    if (!al(src, lds_) || !al(dst, ldd) || tsd % V != 0 || rdst < V || R % rdst != 0 || N < 1 || N % V != 0) return 1;
+    if ((i64)CG * lds_ * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    if (((i64)(R / rdst) * tsd + (i64)CG * ldd) * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    const i64 ntiles = (N + R - 1) / R;
+    const i64 grid = std::min<i64>(ntiles, 2 * (i64)num_cu);
+    hipLaunchKernelGGL((retile_kernel<T, V, R, NT, CPT>), dim3((unsigned)grid), dim3(NT), 0, stream, src, lds_, dst, ldd,
+                       tsd, rdst, N, K);
+    return 0;
+}
+
 // Will launch_deflate_score accept every deflating pass of a fit (decided once per fit, like fused_pass_covers)?
 template <typename T>
 bool deflate_score_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {

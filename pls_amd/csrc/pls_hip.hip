@@ -476,10 +476,15 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // SHORTER tiles (8-32 rows) that do fit the registers of a CU: from the third component on the fully fused
     // pass runs again (2 N K s per component instead of the semi-fused 3 N K s).  Only the first deflation has
     // to read the caller's column-major X in 256-byte pieces (deflate_score, writing the short tiles).
-    const int wide_cg = (semi_fit && tiled_work) ? (K <= 64 * 32 ? 64 : (K <= 128 * 32 ? 128 : 0)) : 0;
+    // KERNEL plan on such a matrix: X is copied ONCE into short tiles (read + write), after which every component
+    // is one fused read-only pass instead of two one-product passes -- pays from the third component on.
+    const bool retile_fit = !nipals && !type2 && c->opt_fuse && !fused_fit && N > 0 && A >= 3 && K <= 128 * 32 &&
+                            c->opt_work_layout != 0 && plsk::deflate_score_covers<T>(X, ldx, N, K, Tm, ldt);
+    const int wide_cg = ((semi_fit && tiled_work) || retile_fit) ? (K <= 64 * 32 ? 64 : (K <= 128 * 32 ? 128 : 0)) : 0;
     const i64 WR = wide_cg ? (512 / wide_cg) * (i64)(16 / sizeof(T)) : TR;  // rows per tile of the working copy
-    if (nipals && A > 1 && N > 0)
-        CHK(ensure(c, c->work, tiled_work ? (size_t)((N + WR - 1) / WR) * WR * K * sizeof(T) : (size_t)N * K * sizeof(T)));
+    if ((nipals && A > 1 && N > 0) || retile_fit)
+        CHK(ensure(c, c->work, (tiled_work || retile_fit) ? (size_t)((N + WR - 1) / WR) * WR * K * sizeof(T)
+                                                          : (size_t)N * K * sizeof(T)));
     double *part = (double *)c->part.p, *sspart = (double *)c->sspart.p;
     double *XY = (double *)c->xy.p, *v = (double *)c->v.p;
     T *work = (T *)c->work.p;
@@ -529,7 +534,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
 
     const T *Xc = X;
     i64 ldc = ldx, tsc = TR;  // column stride and tile stride of the current matrix
-    const i64 ldw = tiled_work ? WR : N, tsw = tiled_work ? WR * (i64)K : TR;
+    const i64 ldw = (tiled_work || retile_fit) ? WR : N, tsw = (tiled_work || retile_fit) ? WR * (i64)K : TR;
     bool cur_tiled = false;  // Xc is the row-tile-major working copy
     for (int a = 0; a < A; ++a) {
         if (N > 0) {
@@ -557,13 +562,21 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 } else {
                     return fail(c, PLS_HIP_ERR_DEVICE, "fused pass launch failed");
                 }
-            } else if (wide_cg && a >= 2) {
-                // short-tile fused pass on the working copy, in place
+            } else if (wide_cg && (nipals ? a >= 2 : a >= 1)) {
+                // short-tile fused pass on the working copy: NIPALS deflates it in place, KERNEL only reads it
                 int nb = 0, nss = 0, rc;
-                const T *tprev = Tm + (i64)(a - 1) * ldt;
-                const double *pprev = P + (i64)(a - 1) * K;
+                const T *tprev = nipals ? Tm + (i64)(a - 1) * ldt : nullptr;
+                const double *pprev = nipals ? P + (i64)(a - 1) * K : nullptr;
+                if (!nipals && a == 1) {  // the one-time copy into short tiles
+                    Scope s(c, PLS_HIP_FAM_DEFLATE, 2 * (i64)N * K * sizeof(T));
+                    if (plsk::launch_retile<T>(c->stream, c->num_cu, X, ldx, work, ldw, tsw, (int)WR, N, K) != 0) {
+                        s.on = false;
+                        return fail(c, PLS_HIP_ERR_DEVICE, "retile launch failed");
+                    }
+                    LAUNCH_CHECK(c);
+                }
                 {
-                    const i64 bytes = 2 * (i64)N * K * sizeof(T) + 2 * (i64)N * sizeof(T) + 3 * (i64)K * 8;
+                    const i64 bytes = (nipals ? 2 : 1) * ((i64)N * K * sizeof(T) + (i64)N * sizeof(T)) + 3 * (i64)K * 8;
                     Scope s(c, PLS_HIP_FAM_FUSED, bytes);
                     rc = wide_cg == 64
                              ? plsk::launch_fused_pass<T, 64>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v,
