@@ -386,6 +386,7 @@ int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX
                     CHK(ensure(c, c->zeros, 256));
                     HIPCHK(c, hipMemsetAsync(c->zeros.p, 0, 256, c->stream));
                 }
+                // PLS_HIP_SYRK_GLDS=0 in the environment selects the register-staged kernel (A/B measurements only)
                 static const bool glds = !(getenv("PLS_HIP_SYRK_GLDS") && atoi(getenv("PLS_HIP_SYRK_GLDS")) == 0);
                 rc = plsk::launch_syrk<T>(c->stream, c->num_cu, X, ldx, N, K, part, S * (i64)K * K, &nb,
                                           glds ? c->zeros.p : nullptr);

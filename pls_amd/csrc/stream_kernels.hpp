@@ -1,7 +1,8 @@
 // One-product-per-launch streaming kernels over the column-major N x K matrix X:
 //   xb_kernel      out = X * Bm        (t = X r, src/pls.cpp:419; X B :449-451; X R :439-442)
 //   xty_kernel     part = X^T Y        (XY = X^T Y, src/pls.cpp:396; p = X^T t, :421)
-//   deflate_kernel dst = src - t p^T   (the north-star rank-1 deflation; no reference line)
+//   deflate_piece_kernel / deflate_kernel   dst = src - t p^T   (the north-star rank-1 deflation; no reference
+//                  line): one contiguous 4 KB column piece per workgroup / the unaligned fallback
 //   reduce_partials_kernel             fixed-order sum of per-workgroup partials
 // Every one is HBM-bound (<= 4 flop/B).  Layout rule: element (i,k) is at
 // X[i + k*ld], so lanes map to consecutive ROWS -- a wave's load of one column is one
