@@ -532,8 +532,10 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     if ((i64)CG * ldx * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     const i64 ntiles = (N + R - 1) / R;
-    // CPT <= 16: two resident 512-thread workgroups per CU; CPT = 32 (256 VGPRs): one
-    const int per_cu = (CGX == 32 && K <= CG * 16) ? 2 : 1;
+    // Workgroups per CU.  Read-only passes: two (5 % faster than one on the caller's column-major X).  Read+write
+    // passes on the tiled copy: ONE once a tile is 16 columns per lane (2.7 % faster than two -- less in flight is
+    // better for the read/write mix, tools/fused_grid_sweep.py); 32 columns per lane (256 VGPRs) never fit two.
+    const int per_cu = (CGX == 32 && K <= CG * 16 && !(defl && K > CG * 8)) ? 2 : 1;
     i64 grid = grid_hint > 0 ? grid_hint : per_cu * (i64)num_cu;
     grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows);
     if (grid < 1) return 1;
