@@ -533,9 +533,10 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     const i64 ntiles = (N + R - 1) / R;
     // Workgroups per CU.  Read-only passes: two (5 % faster than one on the caller's column-major X).  Read+write
-    // passes on the tiled copy: ONE once a tile is 16 columns per lane (2.7 % faster than two -- less in flight is
-    // better for the read/write mix, tools/fused_grid_sweep.py); 32 columns per lane (256 VGPRs) never fit two.
-    const int per_cu = (CGX == 32 && K <= CG * 16 && !(defl && K > CG * 8)) ? 2 : 1;
+    // passes on the tiled copy: ONE (2.7 % faster than two at 16 columns per lane, 4 % at 4, equal at 8 -- less
+    // in flight is better for the read/write mix, tools/fused_grid_sweep.py); 32 columns per lane (256 VGPRs)
+    // never fit two.
+    const int per_cu = (CGX == 32 && K <= CG * 16 && !defl) ? 2 : 1;
     i64 grid = grid_hint > 0 ? grid_hint : per_cu * (i64)num_cu;
     grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows);
     if (grid < 1) return 1;
