@@ -1,7 +1,7 @@
 """Fused-pass launch time (HIP events, profile level 1) over storage types and widths: NIPALS (read+write) and
 KERNEL (read-only) plans."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pls_amd
 h = pls_amd.Handle(); h.set_option(pls_amd.OPT_PROFILE, 1)
 for algo in (1, 0):

@@ -1,5 +1,7 @@
+"""Wall time per fit with PLS_HIP_OPT_PROFILE = 0 / 1 / 2 (no events / HIP events around the streaming launches /
+around every launch) at 1/8 and all of config 3's rows: what the event brackets cost."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pls_amd
 h = pls_amd.Handle(); h.set_option(pls_amd.OPT_ALGO, 1)
 for N in (131072, 1048576):
