@@ -205,6 +205,23 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
         const double *b = Bm + (i64)c0 * ldb;
         T *o = out + (i64)c0 * ldo;
         const int cap = wide ? (FV == 2 ? 32 : 8) : 32;  // fp32 x 4 rows per lane: 8 columns = 32 fp64 accumulators
+        if (sizeof(T) == 4 && rem > 8 && vec_ok<T>(X, ldx, FV)) {
+            // fp32 storage, many columns: up to 32 per pass on the matrix cores (xb_mfma_kernel) -- the LDS-staged
+            // VALU kernel below holds only 8 columns of fp64 accumulators per pass at 4 rows per lane.  (For fp64
+            // storage, where it takes 32 columns per pass, it is the faster one: 0.86 vs 1.04 ms at 20 columns.)
+            const int use = std::min(rem, 32);
+            const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
+            Scope s(c, PLS_HIP_FAM_XB, bytes);
+            const i64 per = (i64)(plsk::WG / plsk::WAVE) * 16 * FV;  // rows per workgroup
+            const dim3 grid((unsigned)((N + per - 1) / per)), blk(plsk::WG);
+            if (use > 16)
+                hipLaunchKernelGGL((plsk::xb_mfma_kernel<T, FV, 2>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo);
+            else
+                hipLaunchKernelGGL((plsk::xb_mfma_kernel<T, FV, 1>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo);
+            LAUNCH_CHECK(c);
+            c0 += use;
+            continue;
+        }
         if (rem > 4) {
             // many columns: Bm through LDS, up to `cap` columns per pass over X; the tile is the column
             // count rounded up to a multiple of 4 (every extra column costs VEC fp64 FMAs per element)

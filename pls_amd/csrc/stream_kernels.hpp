@@ -105,6 +105,102 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
 }
 
 // ------------------------------------------------------------------------------------
+// out(N x ncols) = X * Bm for 4 < ncols <= 16 NB columns on the matrix cores (scores T = X R,
+// src/pls.cpp:439-442; fitted values X B :449-451).  X*Bm -- unlike X^T Y -- is MFMA-shaped as it lies in
+// memory: the M dimension of v_mfma_f64_16x16x4_f64 runs along the ROWS of X, the contiguous direction, so
+// the A operand comes straight from global memory in 16-byte accesses (lane = (row group li, column lq of the
+// 4-column step): a wave-load is 4 column segments of 256 bytes, the tile pattern of the fused pass) and the
+// V rows of a lane's pack feed V separate MFMAs (row set e = rows row0 + V i + e).  At 4 flop per byte the
+// kernel stays HBM-bound (the MFMA pipe could take 19 TB/s).  Bm fragments (4 x 16 doubles per step and
+// column block) come from global memory through L1/L2; accumulation is fp64 for both storage types.
+// Used for fp32 storage (where the VALU kernel below holds only 8 columns per pass); with fp64 storage and
+// 20 columns the VALU kernel is faster (0.86 vs 1.04 ms on config 3).
+// A wave owns 16 V rows and walks all K; 4 waves per workgroup, one-shot workgroups.
+// ------------------------------------------------------------------------------------
+typedef double xb_f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int V, int NB>
+__global__ __launch_bounds__(WG) void xb_mfma_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K,
+                                                     const double *__restrict__ Bm, i64 ldb, int ncols,
+                                                     T *__restrict__ out, i64 ldo) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    constexpr int RW = 16 * V;  // rows per wave
+    const i64 row0 = ((i64)blockIdx.x * (WG / WAVE) + wv) * RW;
+    if (row0 >= N) return;  // wave-uniform
+    const i64 r = row0 + (i64)V * li;
+    const bool rfull = (r + V <= N);
+
+    xb_f64x4 acc[V][NB];
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[e][b] = xb_f64x4{0.0, 0.0, 0.0, 0.0};
+    // columns >= ncols of a partially used block read column ncols-1 again (never stored)
+    const double *bp[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bp[b] = Bm + (i64)min(16 * b + li, ncols - 1) * ldb;
+
+    auto load_x = [&](int k) -> Pack<T, V> {
+        Pack<T, V> x;
+        if (rfull) {
+            x = ld_pack_nt<T, V>(X + r + (i64)k * ldx);
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) x.v[e] = (r + e < N) ? X[r + e + (i64)k * ldx] : (T)0;
+        }
+        return x;
+    };
+
+    constexpr int U = 8;  // k-steps in flight
+    int k0 = 0;
+    for (; k0 + 4 * U <= K; k0 += 4 * U) {
+        Pack<T, V> x[U];
+        double bv[U][NB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            x[u] = load_x(k0 + 4 * u + lq);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bv[u][b] = bp[b][k0 + 4 * u + lq];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    acc[e][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].v[e], bv[u][b], acc[e][b], 0, 0, 0);
+    }
+    for (; k0 < K; k0 += 4) {  // last steps, columns >= K contribute zeros
+        const int k = k0 + lq;
+        const bool kok = k < K;
+        const int kc = kok ? k : K - 1;
+        Pack<T, V> x = load_x(kc);
+        double bv[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bv[b] = kok ? bp[b][kc] : 0.0;
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                acc[e][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(kok ? (double)x.v[e] : 0.0, bv[b], acc[e][b], 0, 0, 0);
+    }
+    // D layout: lane holds D[i = lq + 4 q][j = li]; row of X = row0 + V i + e, column of out = 16 b + j
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int col = 16 * b + li;
+        if (col >= ncols) continue;
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const i64 row = row0 + (i64)V * (lq + 4 * q) + e;
+                if (row < N) out[row + (i64)col * ldo] = (T)acc[e][b][q];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // out(N x ncols) = X * Bm for 4 < ncols <= MT columns in ONE pass over X (scores T = X R with A columns,
 // src/pls.cpp:439-442; fitted values X B :449-451).  With many columns the per-column scalar loads of the
 // narrow kernel above expose their latency (SGPRs cannot hold K x ncols operands), so Bm is staged
