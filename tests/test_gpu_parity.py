@@ -402,6 +402,23 @@ def test_extreme_shapes(handle, oracle, po, mode, N, K, M, A):
     check_against(po, out, ref, Bref, ref["T"], col_err=cerr, tol_inv=1e-7)
 
 
+@pytest.mark.parametrize("N,K,C", [(64, 4, 9), (1000, 33, 16), (4099, 130, 17), (777, 63, 32), (2048, 257, 33), (300, 1025, 50)])
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_xb_many_columns(handle, N, K, C, dt):
+    """X * B with more than 8 columns: fp32 storage runs on the matrix cores (xb_mfma_kernel: 16-row MFMA tiles x
+    V row sets, ragged last rows, K not a multiple of the 4-column step, column blocks of 16), fp64 storage on the
+    LDS-staged kernel.  Against torch in fp64."""
+    torch = _torch()
+    dtype = torch.float32 if dt == "f32" else torch.float64
+    X = handle.synth_x(0, N, K, 21, dtype=dtype)
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    Bm = torch.randn(K, C, generator=g, dtype=torch.float64).cuda()
+    got = handle.xb(X, Bm); handle.synchronize()
+    ref = X.double() @ Bm
+    err = float((got.double() - ref).norm() / ref.norm())
+    assert err < (2e-7 if dt == "f32" else 1e-14), err
+
+
 @pytest.mark.parametrize("N,K,M,A", [(600, 1100, 2, 5), (257, 1500, 1, 4), (1030, 2048, 1, 6), (130, 2500, 2, 5),
                                      (96, 4096, 1, 4), (66, 4100, 2, 4)])
 def test_wide_matrix(handle, oracle, po, mode, N, K, M, A):
