@@ -496,8 +496,15 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // to read the caller's column-major X in 256-byte pieces (deflate_score, writing the short tiles).
     // KERNEL plan on such a matrix: X is copied ONCE into short tiles (read + write), after which every component
     // is one fused read-only pass instead of two one-product passes -- pays from the third component on.
-    const bool retile_fit = !nipals && !type2 && c->opt_fuse && !fused_fit && N > 0 && A >= 3 && K <= 128 * 32 &&
-                            c->opt_work_layout != 0 && plsk::deflate_score_covers<T>(X, ldx, N, K, Tm, ldt);
+    bool retile_fit = !nipals && !type2 && c->opt_fuse && !fused_fit && N > 0 && A >= 3 && K <= 128 * 32 &&
+                      c->opt_work_layout != 0 && plsk::deflate_score_covers<T>(X, ldx, N, K, Tm, ldt);
+    if (retile_fit) {  // the copy is optional: without room for it the one-product kernels do the job
+        const i64 wr = (512 / (K <= 64 * 32 ? 64 : 128)) * (i64)(16 / sizeof(T));
+        if (ensure(c, c->work, (size_t)((N + wr - 1) / wr) * wr * K * sizeof(T)) != PLS_HIP_OK) {
+            retile_fit = false;
+            c->err.clear();
+        }
+    }
     const int wide_cg = ((semi_fit && tiled_work) || retile_fit) ? (K <= 64 * 32 ? 64 : (K <= 128 * 32 ? 128 : 0)) : 0;
     const i64 WR = wide_cg ? (512 / wide_cg) * (i64)(16 / sizeof(T)) : TR;  // rows per tile of the working copy
     if ((nipals && A > 1 && N > 0) || retile_fit)
