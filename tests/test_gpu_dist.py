@@ -56,7 +56,7 @@ def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0):
 
 @pytest.mark.parametrize("N,K,M,A,world,algo,fuse", [
     (4098, 64, 1, 6, 2, 0, 1), (4098, 64, 1, 6, 2, 1, 1), (3001, 40, 3, 5, 2, 1, 0), (2, 5, 1, 2, 3, 0, 1),
-    (65536, 512, 1, 4, 3, 1, 1)])
+    (65536, 512, 1, 4, 3, 1, 1), (2052, 1300, 2, 5, 2, 1, 1), (2052, 1300, 2, 5, 2, 0, 1), (1030, 2500, 1, 4, 2, 1, 1)])
 def test_sharded_fit_matches_oracle(N, K, M, A, world, algo, fuse):
     import torch.multiprocessing as mp
     from oracle import pls_oracle as po
