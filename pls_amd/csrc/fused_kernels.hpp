@@ -68,11 +68,13 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
 // read+write pass 1.81 -> 1.70 ms (profiles/r1/tune_fused_cache_policy.txt).
 constexpr int AUX_NT = 2;
 
-template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX = AUX_NT, int STAUX = AUX_NT>
+// RDST: the destination is stored in tiles of rdst rows, rdst dividing R (the first deflation of a fit whose working
+// copy uses shorter tiles than the R rows read at a time from the caller's column-major X); otherwise rdst is ignored.
+template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX = AUX_NT, int STAUX = AUX_NT, bool RDST = false>
 __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pass_kernel(
     const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd, i64 N, int K,  // dst may alias X (in-place deflation)
     const double *__restrict__ v, const T *__restrict__ tprev, const double *__restrict__ pprev,
-    T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart) {
+    T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart, int rdst) {
     constexpr int RP = R / V;    // lanes along the rows of a tile
     constexpr int CG = NT / RP;  // column groups
     constexpr int NW = NT / WAVE;
@@ -109,7 +111,13 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
     double ss = 0.0;
     int buf = 0;
     const uint32_t xoff = (uint32_t)(((i64)rp * V + (i64)cg * ldx) * (i64)sizeof(T));
-    const uint32_t doff = DEFL ? (uint32_t)(((i64)rp * V + (i64)cg * ldd) * (i64)sizeof(T)) : 0u;
+    uint32_t doff = DEFL ? (uint32_t)(((i64)rp * V + (i64)cg * ldd) * (i64)sizeof(T)) : 0u;
+    i64 dtile = tsd;  // destination elements per source tile
+    if constexpr (RDST && DEFL) {
+        // the lane's rows rp*V.. fall into sub-tile (rp*V)/rdst of the R/rdst destination tiles a source tile covers
+        doff = (uint32_t)(((i64)((rp * V) / rdst) * tsd + (rp * V) % rdst + (i64)cg * ldd) * (i64)sizeof(T));
+        dtile = (R / rdst) * tsd;
+    }
     constexpr uint32_t OOR = 0x80000000u;  // beyond every num_records the launcher allows
 
     for (i64 tile = blockIdx.x; tile * R < N; tile += gridDim.x, buf ^= 1) {
@@ -145,11 +153,17 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
                 const double pk = ps[cgz + CG * j];
 #pragma unroll
                 for (int e = 0; e < V; ++e) x[j].v[e] = (T)fma(tp[e], pk, (double)x[j].v[e]);
-                const int cols = min(CG, K - CG * j);
-                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldd * (i64)sizeof(T)) : 0u;
-                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-                    dst + tile * tsd + (i64)j * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
-                buf_st<T, V, STAUX>(rd, dof, x[j]);
+                if constexpr (RDST) {  // lane offsets span several destination tiles: columns >= K masked per lane
+                    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+                        dst + tile * dtile + (i64)j * CG * ldd, (short)0, 0x7fffffff, BUF_WORD3);
+                    buf_st<T, V, STAUX>(rd, (cg + CG * j < K) ? dof : OOR, x[j]);
+                } else {
+                    const int cols = min(CG, K - CG * j);
+                    const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldd * (i64)sizeof(T)) : 0u;
+                    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+                        dst + tile * tsd + (i64)j * CG * ldd, (short)0, (int)nrec, BUF_WORD3);
+                    buf_st<T, V, STAUX>(rd, dof, x[j]);
+                }
             }
         }
         // score: partial over this lane's columns, then over the lanes / waves sharing the rows
@@ -515,10 +529,11 @@ bool fused_pass_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) 
 
 // rc: 0 = launched, 1 = shape/alignment not covered (caller falls back to the one-product
 // kernels), <0 = launch error.  grid_hint: 0 = auto.  (ldx, tsx) / (ldd, tsd): column and tile strides.
+// rdst > 0 (with CGX = 32 and a deflating pass): the destination uses tiles of rdst rows.
 template <typename T, int CGX = 32>
 int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd,
                       i64 N, int K, const double *v, const T *tprev, const double *pprev, T *tout,
-                      double *part, int max_rows, double *sspart, int *nb, int *nss, int grid_hint) {
+                      double *part, int max_rows, double *sspart, int *nb, int *nss, int grid_hint, int rdst = 0) {
     constexpr int V = 16 / sizeof(T);
     constexpr int R = tile_rows<T, CGX>(), NT = 512;
     constexpr int CG = NT / (R / V);
@@ -531,12 +546,15 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     // a column group's byte span (its num_records, and every lane offset) must stay below 2^31
     if ((i64)CG * ldx * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    if (rdst > 0 && (CGX != 32 || !defl || rdst < V || R % rdst != 0 ||
+                     ((i64)(R / rdst) * tsd + (i64)CG * ldd) * (i64)sizeof(T) >= (1ll << 31)))
+        return 1;
     const i64 ntiles = (N + R - 1) / R;
     // Workgroups per CU.  Read-only passes: two (5 % faster than one on the caller's column-major X).  Read+write
     // passes on the tiled copy: ONE (2.7 % faster than two at 16 columns per lane, 4 % at 4, equal at 8 -- less
     // in flight is better for the read/write mix, tools/fused_grid_sweep.py); 32 columns per lane (256 VGPRs)
     // never fit two.
-    const int per_cu = (CGX == 32 && K <= CG * 16 && !defl) ? 2 : 1;
+    const int per_cu = (K <= CG * 16 && !defl) ? 2 : 1;
     i64 grid = grid_hint > 0 ? grid_hint : per_cu * (i64)num_cu;
     grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows);
     if (grid < 1) return 1;
@@ -557,15 +575,22 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         }                                                                                                     \
         if (defl)                                                                                             \
             hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, true>), g, b, dyn, stream, X, ldx, tsx,  \
-                               dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart);                     \
+                               dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart, 0);                  \
         else                                                                                                  \
             hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, false>), g, b, dyn, stream, X, ldx, tsx, \
-                               dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart);                     \
+                               dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart, 0);                  \
     } while (0)
     if constexpr (CGX == 32) {
-        if (K <= CG * 4) FUSED_CASE(4);
+        if (rdst > 0) {  // first deflation into shorter tiles: only the 32-columns-per-lane shape needs it
+            if (K <= CG * 16) return 1;
+            hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true>), g, b, 0, stream, X, ldx, tsx,
+                               dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart, rdst);
+        } else if (K <= CG * 4) FUSED_CASE(4);
         else if (K <= CG * 8) FUSED_CASE(8);
         else if (K <= CG * 16) FUSED_CASE(16);
+        else FUSED_CASE(32);
+    } else if constexpr (CGX == 64) {
+        if (K <= CG * 16) FUSED_CASE(16);
         else FUSED_CASE(32);
     } else {
         FUSED_CASE(32);

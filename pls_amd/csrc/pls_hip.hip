@@ -506,7 +506,13 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         }
     }
     const int wide_cg = ((semi_fit && tiled_work) || retile_fit) ? (K <= 64 * 32 ? 64 : (K <= 128 * 32 ? 128 : 0)) : 0;
-    const i64 WR = wide_cg ? (512 / wide_cg) * (i64)(16 / sizeof(T)) : TR;  // rows per tile of the working copy
+    // 512 < K <= 1024: the resident tile of the caller's layout needs 32 columns per lane (one 8-wave workgroup per
+    // CU, 5.7-5.85 TB/s); on the tiled copy the same K fits half-height tiles at 16 columns per lane (6.0 TB/s).
+    // Component 0 reads X with the tall tile, the first deflation reads X tall and writes the short tiles (rdst),
+    // every later pass runs on the short tiles.
+    const int mid_cg = (nipals && fused_fit && tiled_work && K > 32 * 16 && A > 2) ? 64 : 0;
+    const int work_cg = wide_cg ? wide_cg : (mid_cg ? mid_cg : 32);
+    const i64 WR = (512 / work_cg) * (i64)(16 / sizeof(T));  // rows per tile of the working copy
     if ((nipals && A > 1 && N > 0) || retile_fit)
         CHK(ensure(c, c->work, (tiled_work || retile_fit) ? (size_t)((N + WR - 1) / WR) * WR * K * sizeof(T)
                                                           : (size_t)N * K * sizeof(T)));
@@ -574,9 +580,15 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     const i64 bytes = (tprev ? 2 : 1) * (i64)N * K * sizeof(T) +
                                       (tprev ? 2 : 1) * (i64)N * sizeof(T) + (tprev ? 3 : 2) * (i64)K * 8;
                     Scope s(c, PLS_HIP_FAM_FUSED, bytes);
-                    rc = plsk::launch_fused_pass<T>(c->stream, c->num_cu, Xc, ldc, tsc, tprev ? work : nullptr, ldw, tsw,
-                                                    N, K, v, tprev, pprev, Tm + (i64)a * ldt, part,
-                                                    (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid);
+                    if (mid_cg && a >= 2)  // half-height tiles of the working copy, in place
+                        rc = plsk::launch_fused_pass<T, 64>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v,
+                                                            tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
+                                                            &nb, &nss, (int)c->opt_fused_grid);
+                    else  // (a == 1 with mid_cg: X in 256-byte segments -> half-height tiles)
+                        rc = plsk::launch_fused_pass<T>(c->stream, c->num_cu, Xc, ldc, tsc, tprev ? work : nullptr, ldw, tsw,
+                                                        N, K, v, tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
+                                                        &nb, &nss, (int)c->opt_fused_grid,
+                                                        (mid_cg && tprev) ? (int)WR : 0);
                     if (rc != 0) s.on = false;  // nothing was launched: drop the event pair
                 }
                 if (rc == 0) {
