@@ -136,6 +136,36 @@ __global__ __launch_bounds__(NTH) void defl_oneshot(const double* __restrict__ X
     }
 }
 
+// read-only sweeps: one-shot contiguous chunks of U*4 KB per workgroup, and persistent grid-stride
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void oneshot_read(const P2* __restrict__ A, double* sink) {
+    const i64 base = (i64)blockIdx.x * (U * 256) + threadIdx.x;
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        P2 x;
+        if (NT) { x.v[0] = __builtin_nontemporal_load(&A[base + u * 256].v[0]); x.v[1] = __builtin_nontemporal_load(&A[base + u * 256].v[1]); }
+        else x = A[base + u * 256];
+        acc += x.v[0] * x.v[1];
+    }
+    if (acc == 1.2345e300) sink[0] = acc;
+}
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void persist_read(const P2* __restrict__ A, double* sink, i64 nchunks) {
+    double acc = 0.0;
+    for (i64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const i64 base = c * (U * 256) + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            P2 x;
+            if (NT) { x.v[0] = __builtin_nontemporal_load(&A[base + u * 256].v[0]); x.v[1] = __builtin_nontemporal_load(&A[base + u * 256].v[1]); }
+            else x = A[base + u * 256];
+            acc += x.v[0] * x.v[1];
+        }
+    }
+    if (acc == 1.2345e300) sink[0] = acc;
+}
+
 template <typename F>
 double time_ms(F&& launch, int reps = 7) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -156,6 +186,24 @@ int main() {
     CK(hipMalloc(&X, N * K * 8)); CK(hipMalloc(&Xo, N * K * 8));
     CK(hipMemset(X, 0, N * K * 8)); CK(hipMemset(Xo, 0, N * K * 8));
     const i64 npacks = N * K / 2;
+    if (getenv("RW_PROBE_READS")) {
+        const double rbytes = 1.0 * N * K * 8;
+#define RD(U)                                                                                                             \
+        {                                                                                                                 \
+            const i64 g = npacks / (U * 256);                                                                             \
+            double a = time_ms([&] { hipLaunchKernelGGL((oneshot_read<U, false>), dim3(g), dim3(256), 0, 0, (const P2*)X, Xo); }); \
+            double b = time_ms([&] { hipLaunchKernelGGL((oneshot_read<U, true>), dim3(g), dim3(256), 0, 0, (const P2*)X, Xo); });  \
+            printf("read oneshot %3d KB/WG: plain %.0f nt %.0f GB/s |", U * 4, rbytes / a / 1e6, rbytes / b / 1e6);       \
+            for (int pg : {512, 2048, 8192}) {                                                                            \
+                double e = time_ms([&] { hipLaunchKernelGGL((persist_read<U, false>), dim3(pg), dim3(256), 0, 0, (const P2*)X, Xo, g); }); \
+                double f = time_ms([&] { hipLaunchKernelGGL((persist_read<U, true>), dim3(pg), dim3(256), 0, 0, (const P2*)X, Xo, g); });  \
+                printf(" persistent %d: plain %.0f nt %.0f |", pg, rbytes / e / 1e6, rbytes / f / 1e6);                   \
+            }                                                                                                             \
+            printf("\n");                                                                                                 \
+        }
+        RD(1) RD(2) RD(4) RD(8) RD(16) RD(32)
+        return 0;
+    }
 #define ONESHOT(U)                                                                                                        \
     {                                                                                                                     \
         const i64 g = npacks / (U * 256);                                                                                 \
