@@ -421,7 +421,8 @@ def test_xb_many_columns(handle, N, K, C, dt):
 
 
 @pytest.mark.parametrize("N,K,M,A", [(600, 1100, 2, 5), (257, 1500, 1, 4), (1030, 2048, 1, 6), (130, 2500, 2, 5),
-                                     (96, 4096, 1, 4), (66, 4100, 2, 4)])
+                                     (96, 4096, 1, 4), (66, 4100, 2, 4), (130, 2500, 2, 1), (130, 2500, 2, 2),
+                                     (130, 2500, 2, 3), (1030, 700, 1, 2), (1030, 700, 1, 3), (2050, 1024, 3, 4)])
 def test_wide_matrix(handle, oracle, po, mode, N, K, M, A):
     """K beyond the 256-byte-segment resident tile (K > 1024).  NIPALS plan: short-tile fused pass on the working
     copy for K <= 2048 (16-row fp64 tiles) and K <= 4096 (8-row tiles) from component 2 on, the semi-fused
