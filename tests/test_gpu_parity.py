@@ -227,6 +227,32 @@ def test_work_layouts_bit_identical(handle, N, K, M, A, dt):
         handle.set_option(pls_amd.OPT_ALGO, 0)
 
 
+@pytest.mark.parametrize("name,algo,method,N,K,M,A,dt", [
+    ("nipals", 1, 0, 65536, 512, 1, 5, "f64"), ("gram", 2, 0, 65536, 512, 1, 6, "f64"), ("type2-f32", 0, 1, 65536, 384, 3, 6, "f32"),
+    ("nipals-wide-f32", 1, 0, 8192, 4096, 8, 5, "f32"), ("kernel-wide", 0, 0, 8192, 2048, 2, 5, "f64"),
+    ("nipals-mid", 1, 0, 32768, 1024, 4, 5, "f64")])
+def test_race_screen_repeated_fits(handle, name, algo, method, N, K, M, A, dt):
+    """Every kernel is deterministic (fixed-order reductions, no atomics on data): a bit that differs between repeated
+    fits of the same inputs is a synchronisation bug -- e.g. an LDS-DMA slab of the SYRK read before it landed, a tile
+    of the working copy read before the previous pass finished.  (tools/determinism_soak.py runs this 150 times.)"""
+    import pls_amd
+    torch = _torch()
+    dtype = torch.float64 if dt == "f64" else torch.float32
+    handle.set_option(pls_amd.OPT_ALGO, algo)
+    try:
+        X = handle.synth_x(0, N, K, 7, dtype=dtype); Y = handle.synth_y(0, N, M, 7, dtype=dtype)
+        ref = {k: v.clone() for k, v in handle.fit_device(X, Y, A, method=method).items() if v is not None}
+        handle.synchronize()
+        for _ in range(12):
+            out = handle.fit_device(X, Y, A, method=method); handle.synchronize()
+            for k, v in ref.items():
+                if k == "T" and method == 1:
+                    continue
+                assert torch.equal(out[k], v), (name, k)
+    finally:
+        handle.set_option(pls_amd.OPT_ALGO, 0)
+
+
 def test_t_orthogonal_full_rank_components(handle, po):
     """A = K components on a small matrix: scores mutually orthogonal, P^T R = I, and the
     regression reproduces least squares (B_A=K == lstsq) -- a size-independent property."""
