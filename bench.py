@@ -57,6 +57,9 @@ def parse():
                     help="N > 1: torch.distributed all_reduce from a callback (default) or the library's own RCCL "
                          "communicator issued on the launch stream (include/pls_hip_rccl.h)")
     ap.add_argument("--no-alt", action="store_true", help="skip the alternative execution plans")
+    ap.add_argument("--defer", type=int, default=1, choices=[1, 2, 3, 4],
+                    help="NIPALS plan: write the deflated matrix back every D-th component only (default 1 = explicit "
+                         "deflation every component, the headline)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=1 << 20, help="rows of the CPU baseline sample (default: the whole workload, ~10 s on one core)")
     return ap.parse_args()
@@ -179,6 +182,7 @@ def main():
     algo = {"nipals": pls_amd.ALGO_NIPALS, "kernel": pls_amd.ALGO_KERNEL, "gram": pls_amd.ALGO_GRAM}[a.algo]
     h.set_option(pls_amd.OPT_ALGO, algo)
     h.set_option(pls_amd.OPT_FUSE, a.fuse)
+    h.set_option(pls_amd.OPT_DEFER, a.defer)
     # HIP events around every streaming launch (the roofline figures).  At N = 1 they bracket the launches of the
     # timed steps themselves; the brackets cost ~8 us per component (0.5 % of a single-GPU component, but 4 % of a
     # 1/8-size one), so at N > 1 the timed steps run without them and the roofline comes from extra profiled steps
@@ -200,7 +204,7 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dt, "data": "synthetic",
         "config": {"workload": f"{a.workload}: synthetic tall n={N} x p={K}, m={M}, A={A}, {dt}, resident in HBM",
-                   "algo": a.algo, "fuse": a.fuse, "rows_per_gpu": nrows,
+                   "algo": a.algo, "fuse": a.fuse, "deflation_written_back_every": a.defer, "rows_per_gpu": nrows,
                    "parallelism": f"row-shard x{world}" if world > 1 else "single GPU"},
         "roofline": roofline_of(tm),
         # end-to-end effective stream rate: (2A) N K s / t_fit, the fused lower bound
@@ -228,6 +232,20 @@ def main():
                 st = max(2, a.steps // 2)
                 alt[name] = {"components_per_s": round(A * st / e2, 2), "ms_per_fit": round(e2 / st * 1e3, 3),
                              "roofline": roofline_of(t2)}
+            # opt-in variant of the NIPALS plan: the deflated matrix is written back every D-th component only, the
+            # pending rank-1 updates are re-applied in registers (same roundings as the explicit plan; K <= 512)
+            if K <= 512:
+                h.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_NIPALS)
+                h.set_option(pls_amd.OPT_FUSE, 1)
+                for D in (2, 4):
+                    h.set_option(pls_amd.OPT_DEFER, D)
+                    st = max(2, a.steps // 2)
+                    e2, t2 = timed_fits(h, torch, dist, 1, X, Y, A, st, 1, out)
+                    alt[f"nipals_deferred_writeback_every_{D}"] = {
+                        "components_per_s": round(A * st / e2, 2), "ms_per_fit": round(e2 / st * 1e3, 3),
+                        "roofline": roofline_of(t2),
+                        "note": "X_a materialised in HBM every D-th component; not the headline plan"}
+                h.set_option(pls_amd.OPT_DEFER, 1)
             # METHOD::KERNEL_TYPE2 (XX = X^T X on the matrix cores, then no pass over X; T not computed)
             if K <= 2048:
                 h.set_option(pls_amd.OPT_ALGO, 0)

@@ -94,7 +94,9 @@ typedef enum {
     PLS_HIP_OPT_PROFILE = 3,    /* HIP events on the launch stream: 1 = around the streaming kernels over X, 2 = around every kernel */
     PLS_HIP_OPT_POWER_ITERS = 4, /* squarings of the S^T S power iteration (m > 1); default 48 */
     PLS_HIP_OPT_FUSED_GRID = 5,  /* workgroups of the fused pass; 0 (default) = 2 per CU */
-    PLS_HIP_OPT_WORK_LAYOUT = 6  /* NIPALS work buffer (the deflated copy of X) of a fused fit: 1 (default) row-tile-major, 0 column-major */
+    PLS_HIP_OPT_WORK_LAYOUT = 6, /* NIPALS work buffer (the deflated copy of X) of a fused fit: 1 (default) row-tile-major, 0 column-major */
+    PLS_HIP_OPT_DEFER = 7        /* NIPALS plan, K <= 512: write the deflated matrix back every D-th component only (1..4); the
+                                    D - 1 pending rank-1 updates are re-applied in registers.  1 (default) = explicit deflation */
 } pls_hip_option;
 
 /*

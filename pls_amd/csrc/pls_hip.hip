@@ -14,6 +14,7 @@
 
 #include "../../include/pls_hip.h"
 #include "fused_kernels.hpp"
+#include "defer_kernels.hpp"
 #include "small_kernels.hpp"
 #include "stream_kernels.hpp"
 #include "syrk_kernels.hpp"
@@ -46,7 +47,7 @@ struct pls_hip_context {
     double *user_red = nullptr;
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
-    i64 opt_fused_grid = 0, opt_work_layout = 1;
+    i64 opt_fused_grid = 0, opt_work_layout = 1, opt_defer = 1;
     DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
@@ -511,6 +512,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // Component 0 reads X with the tall tile, the first deflation reads X tall and writes the short tiles (rdst),
     // every later pass runs on the short tiles.
     const int mid_cg = (nipals && fused_fit && tiled_work && K > 32 * 16 && A > 2) ? 64 : 0;
+    // opt-in deferred write-back (defer_kernels.hpp): up to `defer` rank-1 updates pending per stored matrix
+    const int defer = (nipals && fused_fit && tiled_work && K <= 32 * 16) ? (int)c->opt_defer : 1;
     const int work_cg = wide_cg ? wide_cg : (mid_cg ? mid_cg : 32);
     const i64 WR = (512 / work_cg) * (i64)(16 / sizeof(T));  // rows per tile of the working copy
     if ((nipals && A > 1 && N > 0) || retile_fit)
@@ -567,10 +570,35 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     i64 ldc = ldx, tsc = TR;  // column stride and tile stride of the current matrix
     const i64 ldw = (tiled_work || retile_fit) ? WR : N, tsw = (tiled_work || retile_fit) ? WR * (i64)K : TR;
     bool cur_tiled = false;  // Xc is the row-tile-major working copy
+    int defer_b = 0;         // deferred write-back: index of the stored matrix X_b
     for (int a = 0; a < A; ++a) {
         if (N > 0) {
             bool done = false;
-            if (fused_fit) {
+            if (fused_fit && defer > 1 && a > 0) {
+                // deferred write-back: the stored matrix is X_b (the caller's X for b = 0, the working copy after the
+                // first store); apply the a - b pending updates in registers, store X_a when `defer` are pending
+                int nb = 0, nss = 0, rc;
+                const int np = a - defer_b;
+                const bool store = (np == defer) && (a + 1 < A);
+                plsk::PendingUpdates<T> pend{};
+                for (int n = 0; n < np; ++n) {
+                    pend.t[n] = Tm + (i64)(defer_b + n) * ldt;
+                    pend.p[n] = P + (i64)(defer_b + n) * K;
+                }
+                {
+                    const i64 bytes = (store ? 2 : 1) * (i64)N * K * sizeof(T) + (np + 1) * (i64)N * sizeof(T) +
+                                      (np + 2) * (i64)K * 8;
+                    Scope s(c, PLS_HIP_FAM_FUSED, bytes);
+                    rc = plsk::launch_fused_defer<T>(c->stream, c->num_cu, Xc, ldc, tsc, work, ldw, tsw, N, K, v, np, pend,
+                                                     store, Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss);
+                    if (rc != 0) s.on = false;
+                }
+                if (rc != 0) return fail(c, PLS_HIP_ERR_DEVICE, "deferred fused pass launch failed");
+                LAUNCH_CHECK(c);
+                done = true;
+                if (store) { Xc = work; ldc = ldw; tsc = tsw; cur_tiled = true; defer_b = a; }
+                CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
+            } else if (fused_fit) {
                 // tile-resident pass: [deflate with (t_{a-1}, p_{a-1}) +] t_a = X v, X^T t_a partials
                 int nb = 0, nss = 0;
                 const T *tprev = (nipals && a > 0) ? Tm + (i64)(a - 1) * ldt : nullptr;
@@ -799,6 +827,10 @@ int pls_hip_set_option(pls_hip_handle h, int option, int64_t value) {
             h->opt_fused_grid = value;
             return PLS_HIP_OK;
         case PLS_HIP_OPT_WORK_LAYOUT: h->opt_work_layout = value ? 1 : 0; return PLS_HIP_OK;
+        case PLS_HIP_OPT_DEFER:
+            if (value < 1 || value > plsk::DEFER_MAX) return fail(h, PLS_HIP_ERR_INVALID, "defer out of range");
+            h->opt_defer = value;
+            return PLS_HIP_OK;
         default: return fail(h, PLS_HIP_ERR_INVALID, "unknown option");
     }
 }
@@ -813,6 +845,7 @@ int pls_hip_get_option(pls_hip_handle h, int option, int64_t *value) {
         case PLS_HIP_OPT_POWER_ITERS: *value = h->opt_power_iters; return PLS_HIP_OK;
         case PLS_HIP_OPT_FUSED_GRID: *value = h->opt_fused_grid; return PLS_HIP_OK;
         case PLS_HIP_OPT_WORK_LAYOUT: *value = h->opt_work_layout; return PLS_HIP_OK;
+        case PLS_HIP_OPT_DEFER: *value = h->opt_defer; return PLS_HIP_OK;
         default: return fail(h, PLS_HIP_ERR_INVALID, "unknown option");
     }
 }

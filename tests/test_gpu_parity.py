@@ -253,6 +253,36 @@ def test_race_screen_repeated_fits(handle, name, algo, method, N, K, M, A, dt):
         handle.set_option(pls_amd.OPT_ALGO, 0)
 
 
+@pytest.mark.parametrize("N,K,M,A,dt", [(3000, 96, 3, 9, "f64"), (4098, 512, 1, 7, "f64"), (32 * 300 + 2, 40, 2, 5, "f64"),
+                                        (5000, 200, 2, 8, "f32"), (2048, 130, 8, 2, "f64")])
+@pytest.mark.parametrize("D", [2, 3, 4])
+def test_deferred_write_back_matches_explicit_deflation(handle, oracle, po, N, K, M, A, dt, D):
+    """OPT_DEFER = D: the deflated matrix is written back every D-th component only and the pending rank-1 updates
+    are re-applied in registers with the explicit plan's own roundings.  Same tiles, same bits in the registers:
+    W, P, Q, R, T, B must agree with the explicit plan (D = 1) to the rounding of the partial sums, and with the oracle."""
+    import pls_amd
+    torch = _torch()
+    dtype = torch.float64 if dt == "f64" else torch.float32
+    X = handle.synth_x(0, N, K, 123, dtype=dtype); Y = handle.synth_y(0, N, M, 123, dtype=dtype)
+    handle.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_NIPALS)
+    try:
+        handle.set_option(pls_amd.OPT_DEFER, 1)
+        ref = {k: v.clone() for k, v in handle.fit_device(X, Y, A).items()}; handle.synchronize()
+        handle.set_option(pls_amd.OPT_DEFER, D)
+        out = handle.fit_device(X, Y, A); handle.synchronize()
+        for k in "WPQRTB":
+            a, b = out[k].double(), ref[k].double()
+            assert torch.isfinite(a).all(), k
+            assert float((a - b).norm() / b.norm()) < (1e-11 if dt == "f64" else 5e-6), k
+        if dt == "f64":
+            Xh = X.cpu().numpy(); Yh = Y.cpu().numpy()
+            r, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+            check_against(po, out, r, Bref, r["T"], col_err=cerr)
+    finally:
+        handle.set_option(pls_amd.OPT_DEFER, 1)
+        handle.set_option(pls_amd.OPT_ALGO, 0)
+
+
 def test_t_orthogonal_full_rank_components(handle, po):
     """A = K components on a small matrix: scores mutually orthogonal, P^T R = I, and the
     regression reproduces least squares (B_A=K == lstsq) -- a size-independent property."""
