@@ -6,7 +6,7 @@
  *     char id[PLS_HIP_RCCL_ID_BYTES];
  *     if (rank == 0) pls_hip_rccl_unique_id(id);          // then broadcast id to every rank (MPI, sockets, ...)
  *     void *comm;
- *     pls_hip_rccl_attach(handle, id, rank, nranks, &comm); // ncclCommInitRank + pls_hip_set_reducer
+ *     pls_hip_rccl_attach(handle, device, id, rank, nranks, &comm); // ncclCommInitRank + pls_hip_set_reducer
  *     pls_hip_fit(handle, X_local, ...);                    // partial products are summed over xGMI
  *     pls_hip_rccl_detach(handle, comm);
  *
