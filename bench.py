@@ -53,9 +53,10 @@ def parse():
     ap.add_argument("--fuse", type=int, default=1)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (gloo: rehearsal with ranks sharing one GPU)")
-    ap.add_argument("--reducer", default="torch", choices=["torch", "rccl"],
-                    help="N > 1: torch.distributed all_reduce from a callback (default) or the library's own RCCL "
-                         "communicator issued on the launch stream (include/pls_hip_rccl.h)")
+    ap.add_argument("--reducer", default=None, choices=["torch", "rccl"],
+                    help="N > 1: rccl (default with --backend nccl) = the library's own RCCL communicator, ncclAllReduce "
+                         "issued on the launch stream with no Python in the component loop (include/pls_hip_rccl.h); "
+                         "torch (default with --backend gloo) = torch.distributed all_reduce from a ctypes callback")
     ap.add_argument("--no-alt", action="store_true", help="skip the alternative execution plans")
     ap.add_argument("--defer", type=int, default=1, choices=[1, 2, 3, 4],
                     help="NIPALS plan: write the deflated matrix back every D-th component only (default 1 = explicit "
@@ -145,8 +146,26 @@ def cpu_baseline(N, K, M, A, rows):
     return base, omp
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks the way the driver does (one process per
+    GPU through torch.distributed.run) as a CHILD process -- nothing in this process has touched the GPU yet --
+    and exit with its status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
+    if a.reducer is None:
+        a.reducer = "rccl" if a.backend == "nccl" else "torch"
     import torch
     import torch.distributed as dist
 
@@ -156,7 +175,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     ndev = torch.cuda.device_count()
     local = local if a.backend == "nccl" else local % max(ndev, 1)
@@ -205,7 +224,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dt, "data": "synthetic",
         "config": {"workload": f"{a.workload}: synthetic tall n={N} x p={K}, m={M}, A={A}, {dt}, resident in HBM",
                    "algo": a.algo, "fuse": a.fuse, "deflation_written_back_every": a.defer, "rows_per_gpu": nrows,
-                   "parallelism": f"row-shard x{world}" if world > 1 else "single GPU"},
+                   "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
+                   "reducer": (a.reducer if a.backend == "nccl" else "torch") if world > 1 else None},
         "roofline": roofline_of(tm),
         # end-to-end effective stream rate: (2A) N K s / t_fit, the fused lower bound
         "effective_gbs": round(2 * A * N * K * es / (el / a.steps) / 1e9, 1),

@@ -146,10 +146,12 @@ def _u24(stream, idx):
 
 def synth_x(row0: int, nrows: int, K: int, seed: int = SEED_DEFAULT) -> np.ndarray:
     with np.errstate(over="ignore"):
-        sE, sZ, sL = (int(_mix64(_U64(seed + d))) for d in (0, 1, 2))
+        sE, sZ, sL, sA = (int(_mix64(_U64(seed + d))) for d in (0, 1, 2, 5))
         i = (np.arange(nrows, dtype=_U64) + _U64(row0))[:, None]
         k = np.arange(K, dtype=_U64)[None, :]
-        X = 0.25 * _u24(sE, i * _U64(K) + k)
+        ha = _mix64(_U64(sA) ^ k)   # column noise amplitude 2^-(h%4) * (8 + (h/4)%8)/32  (pls_oracle.c, synth_noise_amp)
+        amp = np.ldexp(((ha >> _U64(2)) & _U64(7)).astype(np.float64) + 8.0, -5 - (ha & _U64(3)).astype(np.int64))
+        X = amp * _u24(sE, i * _U64(K) + k)
         ltab = np.array([-1.0, -0.5, 0.0, 0.5, 1.0])
         for f in range(SYN_F):
             z = _u24(sZ, i * _U64(SYN_F) + _U64(f))
@@ -234,10 +236,27 @@ class OracleLib:
         L.oracle_synth_y.restype = None
         L.oracle_synth_y.argtypes = [_dp, _i64, _i64, _i64, _i64, ctypes.c_uint64]
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_set_f32_storage.restype = None
+        L.oracle_set_f32_storage.argtypes = [ctypes.c_int]
+        L.oracle_set_compensated.restype = None
+        L.oracle_set_compensated.argtypes = [ctypes.c_int]
 
     # -- fit ---------------------------------------------------------------------------
-    def plsr(self, X, Y, A, method=0, nipals=False):
+    def plsr(self, X, Y, A, method=0, nipals=False, f32_storage=False, compensated=False):
+        """f32_storage: emulate fp32 storage of the scores (and of the deflated matrix in the NIPALS form) with
+        fp64 arithmetic -- BASELINE config 4's mode, which the reference does not have (pls_oracle.c).
+        compensated: every sum in error-free (double-double) form: the same operation sequence without the
+        N*eps summation error of index-order sums (pls_oracle.c, "Compensated arithmetic")."""
         X, Y = _f(X), _f(Y)
+        self.lib.oracle_set_f32_storage(1 if f32_storage else 0)
+        self.lib.oracle_set_compensated(1 if compensated else 0)
+        try:
+            return self._plsr(X, Y, A, method, nipals)
+        finally:
+            self.lib.oracle_set_f32_storage(0)
+            self.lib.oracle_set_compensated(0)
+
+    def _plsr(self, X, Y, A, method, nipals):
         N, K = X.shape
         M = Y.shape[1]
         W = np.zeros((K, A), order="F"); P = np.zeros((K, A), order="F")

@@ -5,6 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace plsk {
 
 typedef int64_t i64;
@@ -77,6 +81,27 @@ __device__ __forceinline__ double block_sum(double x, double *smem) {
 #pragma unroll
     for (int i = 0; i < NW; ++i) s += smem[i];
     return s;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): a process that drives several
+// GPUs (pls_hip_group) must raise it once on each of them.  true = the kernel may be launched with `bytes` of
+// dynamic LDS on the current device.
+inline bool raise_dynamic_lds(const void *fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({fn, dev})) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    done.insert({fn, dev});
+    return true;
 }
 
 }  // namespace plsk

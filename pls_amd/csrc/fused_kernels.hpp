@@ -345,17 +345,9 @@ int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_,
     if ((i64)CG * lds_ * (i64)sizeof(T) >= (1ll << 31) || (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     const size_t dyn = (size_t)K * 16;  // w and p_prev
     if (dyn > 72 * 1024) return 1;      // two workgroups per CU must fit the 160 KiB LDS
-    if (dyn > 48 * 1024) {
-        static bool raised = false;  // per instantiation
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&deflate_score_kernel<T, V, R, NT, CPT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess) {
-                (void)hipGetLastError();
-                return 1;
-            }
-            raised = true;
-        }
-    }
+    if (dyn > 48 * 1024 &&
+        !raise_dynamic_lds(reinterpret_cast<const void *>(&deflate_score_kernel<T, V, R, NT, CPT>), 72 * 1024))
+        return 1;
     const i64 ntiles = (N + R - 1) / R;
     const i64 grid = std::min<i64>(std::min<i64>(ntiles, 2 * (i64)num_cu), max_rows);
     hipLaunchKernelGGL((deflate_score_kernel<T, V, R, NT, CPT>), dim3((unsigned)grid), dim3(NT), (size_t)K * 16,
@@ -563,15 +555,9 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     do {                                                                                                      \
         const size_t dyn = ((size_t)2 * CG * CPT_ * sizeof(double) > 48 * 1024) ? (size_t)2 * CG * CPT_ * sizeof(double) : 0; \
         if (dyn > 48 * 1024) {                                                                                \
-            static bool raised[2] = {false, false};                                                           \
             const void *fn = defl ? reinterpret_cast<const void *>(&fused_pass_kernel<T, V, R, NT, CPT_, true>) \
                                   : reinterpret_cast<const void *>(&fused_pass_kernel<T, V, R, NT, CPT_, false>); \
-            if (!raised[defl] &&                                                                              \
-                hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { \
-                (void)hipGetLastError();                                                                      \
-                return 1;                                                                                     \
-            }                                                                                                 \
-            raised[defl] = true;                                                                              \
+            if (!raise_dynamic_lds(fn, (int)dyn)) return 1;                                                   \
         }                                                                                                     \
         if (defl)                                                                                             \
             hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, true>), g, b, dyn, stream, X, ldx, tsx,  \

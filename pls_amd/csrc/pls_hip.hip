@@ -341,10 +341,10 @@ int launch_deflate(pls_hip_context *c, const T *src, i64 lds, T *dst, i64 ldd, i
 }
 
 int launch_reduce(pls_hip_context *c, const double *part, int nb, int L, const double *sspart,
-                  int nss, double *red) {
+                  int nss, double *red, i64 out_stride = 0) {
     Scope s(c, PLS_HIP_FAM_SMALL, ((i64)nb * L + nss + (i64)plsk::RED_SLICES * (L + 1)) * 8);
     hipLaunchKernelGGL(plsk::reduce_partials_kernel, dim3((L + 63) / 64, plsk::RED_SLICES),
-                       dim3(plsk::WG), 0, c->stream, part, nb, L, sspart, nss, red);
+                       dim3(plsk::WG), 0, c->stream, part, nb, L, sspart, nss, red, out_stride);
     LAUNCH_CHECK(c);
     return PLS_HIP_OK;
 }
@@ -352,10 +352,10 @@ int launch_reduce(pls_hip_context *c, const double *part, int nb, int L, const d
 // n*K (values of P and of R the r update must read) above which it is split over many workgroups
 constexpr i64 ROTATE_SPLIT_MIN = 16384;
 
+// nip: 0 = KERNEL algo (next pass is X r), 1 = NIPALS (next pass X_a w)
 int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, double *P,
-                  double *Q, double *R, double *v, int K, int M, int A, int a, bool next_is_w) {
+                  double *Q, double *R, double *v, int K, int M, int A, int a, int nip) {
     const int n = a + 1;
-    const int nip = (int)next_is_w;
     const bool split = n < A && n > 0 && (i64)n * K >= ROTATE_SPLIT_MIN;
     Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * M * 3 + (i64)K * (2 * (a + 2)) + K) * 8);
     hipLaunchKernelGGL(plsk::component_update_kernel, dim3(1), dim3(plsk::UPD_THREADS),
@@ -382,63 +382,62 @@ int do_allreduce(pls_hip_context *c, double *buf, i64 count) {
 
 // XX(K x K, fp64) = X^T X summed over ranks: matrix-core SYRK when the layout allows it, otherwise the
 // column-reduction kernel in 32-column blocks.  Uses c->part / c->red2 as scratch.
+// Whichever kernels the LOCAL shard takes (its row count, alignment and leading dimension decide, and an
+// empty shard runs none), the exchange is always ONE all-reduce of RED_SLICES*K*K values in the same layout:
+// the ranks of a sharded fit can never disagree on the sequence of collectives.
 template <typename T>
 int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX) {
     constexpr int CB = 32;
-    double *part = nullptr, *red2 = nullptr;
-    const i64 prow = max_partial_rows(c, N, K);
-    bool have_xx = false;
-    {
+    const i64 KK = (i64)K * K;
+    CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * KK * 8));
+    double *red2 = (double *)c->red2.p;
+    bool have = false;
+    if (N > 0) {
         // matrix-core path: 128 x 128 blocks on v_mfma_f64_16x16x4_f64, row-split partial blocks
         const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
         const i64 S = std::max<i64>(1, (16 * (i64)c->num_cu + nbk * (nbk + 1) / 2 - 1) / (nbk * (nbk + 1) / 2));  // capacity bound
-        if (N > 0 && ensure(c, c->part, (size_t)S * K * K * 8) == PLS_HIP_OK &&
-            ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * K * 8) == PLS_HIP_OK) {
-            part = (double *)c->part.p;
-            red2 = (double *)c->red2.p;
+        if (ensure(c, c->part, (size_t)S * KK * 8) == PLS_HIP_OK) {
+            double *part = (double *)c->part.p;
             int nb = 0;
             int rc;
             {
-                Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) * ((nbk + 1)) + (i64)K * K * 8);
+                Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) * ((nbk + 1)) + KK * 8);
                 if (!c->zeros.p) {  // source of out-of-range rows for the LDS-DMA panels
                     CHK(ensure(c, c->zeros, 256));
                     HIPCHK(c, hipMemsetAsync(c->zeros.p, 0, 256, c->stream));
                 }
                 // PLS_HIP_SYRK_GLDS=0 in the environment selects the register-staged kernel (A/B measurements only)
                 static const bool glds = !(getenv("PLS_HIP_SYRK_GLDS") && atoi(getenv("PLS_HIP_SYRK_GLDS")) == 0);
-                rc = plsk::launch_syrk<T>(c->stream, c->num_cu, X, ldx, N, K, part, S * (i64)K * K, &nb,
+                rc = plsk::launch_syrk<T>(c->stream, c->num_cu, X, ldx, N, K, part, S * KK, &nb,
                                           glds ? c->zeros.p : nullptr);
                 if (rc != 0) s.on = false;
             }
             if (rc == 0) {
                 LAUNCH_CHECK(c);
-                CHK(launch_reduce(c, part, nb, K * K, nullptr, 0, red2));
-                CHK(do_allreduce(c, red2, (i64)plsk::RED_SLICES * K * K));
-                hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((K * K + plsk::WG - 1) / plsk::WG), dim3(plsk::WG),
-                                   0, c->stream, (const double *)red2, K * K, XX);
-                LAUNCH_CHECK(c);
-                have_xx = true;
+                CHK(launch_reduce(c, part, nb, (int)KK, nullptr, 0, red2));
+                have = true;
+            }
+        } else {
+            c->err.clear();  // no room for the partial blocks: the column-block path needs far less
+        }
+        if (!have) {  // unaligned layouts: column blocks of X^T X through the column-reduction kernel, into the same slices
+            const i64 prow = max_partial_rows(c, N, K);
+            CHK(ensure(c, c->part, (size_t)prow * (size_t)K * CB * 8));
+            double *part = (double *)c->part.p;
+            for (int c0 = 0; c0 < K; c0 += CB) {
+                const int cb = std::min(CB, K - c0);
+                int nb = 0;
+                CHK(launch_xty<T>(c, X, ldx, X + (i64)c0 * ldx, ldx, N, K, cb, part, &nb));
+                CHK(launch_reduce(c, part, nb, K * cb, nullptr, 0, red2 + (i64)c0 * K, KK));
             }
         }
+    } else {
+        HIPCHK(c, hipMemsetAsync(red2, 0, (size_t)plsk::RED_SLICES * KK * 8, c->stream));
     }
-    for (int c0 = 0; c0 < K && !have_xx; c0 += CB) {
-        const int cb = std::min(CB, K - c0);
-        CHK(ensure(c, c->part, (size_t)prow * (size_t)K * CB * 8));
-        CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * CB * 8));
-        part = (double *)c->part.p;
-        red2 = (double *)c->red2.p;
-        if (N > 0) {
-            int nb = 0;
-            CHK(launch_xty<T>(c, X, ldx, X + (i64)c0 * ldx, ldx, N, K, cb, part, &nb));
-            CHK(launch_reduce(c, part, nb, K * cb, nullptr, 0, red2));
-        } else {
-            HIPCHK(c, hipMemsetAsync(red2, 0, (size_t)plsk::RED_SLICES * K * cb * 8, c->stream));
-        }
-        CHK(do_allreduce(c, red2, (i64)plsk::RED_SLICES * K * cb));
-        hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((K * cb + plsk::WG - 1) / plsk::WG), dim3(plsk::WG), 0,
-                           c->stream, (const double *)red2, K * cb, XX + (i64)c0 * K);
-        LAUNCH_CHECK(c);
-    }
+    CHK(do_allreduce(c, red2, (i64)plsk::RED_SLICES * KK));
+    hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((unsigned)((KK + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
+                       c->stream, (const double *)red2, (int)KK, XX);
+    LAUNCH_CHECK(c);
     return PLS_HIP_OK;
 }
 
@@ -464,6 +463,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     const bool gram = (method == PLS_HIP_KERNEL_TYPE1) && (algo == PLS_HIP_ALGO_GRAM);
     const bool type2 = (method == PLS_HIP_KERNEL_TYPE2) || gram;
     const bool nipals = !type2 && (algo == PLS_HIP_ALGO_NIPALS);
+    const int nip = nipals ? 1 : 0;
     const i64 L0 = (i64)K * M;
     const i64 redn = (i64)plsk::RED_SLICES * std::max<i64>(L0, K + 1);
     const i64 prow = max_partial_rows(c, N, K);
@@ -532,7 +532,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         HIPCHK(c, hipMemsetAsync(red, 0, (size_t)plsk::RED_SLICES * L0 * 8, c->stream));
     }
     CHK(do_allreduce(c, red, (i64)plsk::RED_SLICES * L0));
-    CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, -1, nipals));
+    CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, -1, nip));
 
     if (type2) {
         // KERNEL_TYPE2 (src/pls.cpp:398, :422-425): XX = X^T X once, then the A-loop never touches X:
@@ -552,7 +552,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             hipLaunchKernelGGL(plsk::type2_pack_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream,
                                (const double *)praw, (const double *)v, K, red);
             LAUNCH_CHECK(c);
-            CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a, false));
+            CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a, 0));
         }
         if (B) {
             const int nblk = (int)((L0 + plsk::WG - 1) / plsk::WG);
@@ -705,7 +705,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             HIPCHK(c, hipMemsetAsync(red, 0, (size_t)plsk::RED_SLICES * (K + 1) * 8, c->stream));
         }
         CHK(do_allreduce(c, red, (i64)plsk::RED_SLICES * (K + 1)));
-        CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a, nipals));  // :427-433 and :403-416 of a+1
+        CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a, nip));  // :427-433 and :403-416 of a+1
     }
     if (B) {
         Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * A + (i64)M * A + (i64)K * M) * 8);
@@ -1315,11 +1315,11 @@ int pls_hip_synth_x(pls_hip_handle h, void *X, int64_t ldx, int64_t row0, int64_
         return fail(h, PLS_HIP_ERR_INVALID, "bad synth_x arguments");
     if (nrows == 0) return PLS_HIP_OK;
     CHK(set_device(h));
-    CHK(ensure(h, h->tab, (size_t)K * plsk::SYN_F * 8));
+    CHK(ensure(h, h->tab, (size_t)K * (plsk::SYN_F + 1) * 8));
     const uint64_t sE = plsk::mix64(seed), sZ = plsk::mix64(seed + 1), sL = plsk::mix64(seed + 2);
     const int ntab = (int)((K * plsk::SYN_F + plsk::WG - 1) / plsk::WG);
     hipLaunchKernelGGL(plsk::synth_table_kernel, dim3(ntab), dim3(plsk::WG), 0, h->stream,
-                       (double *)h->tab.p, (int)K, sL, 0);
+                       (double *)h->tab.p, (int)K, sL, 0, plsk::mix64(seed + 5));
     LAUNCH_CHECK(h);
     constexpr int KC = 64;
     const dim3 grid((unsigned)((nrows + plsk::WG - 1) / plsk::WG), (unsigned)((K + KC - 1) / KC));
@@ -1347,7 +1347,7 @@ int pls_hip_synth_y(pls_hip_handle h, void *Y, int64_t ldy, int64_t row0, int64_
     const uint64_t sZ = plsk::mix64(seed + 1), sC = plsk::mix64(seed + 3), sN = plsk::mix64(seed + 4);
     const int ntab = (int)((M * plsk::SYN_F + plsk::WG - 1) / plsk::WG);
     hipLaunchKernelGGL(plsk::synth_table_kernel, dim3(ntab), dim3(plsk::WG), 0, h->stream,
-                       (double *)h->tab.p, (int)M, sC, 1);
+                       (double *)h->tab.p, (int)M, sC, 1, (uint64_t)0);
     LAUNCH_CHECK(h);
     const dim3 grid((unsigned)((nrows + plsk::WG - 1) / plsk::WG));
     if (dtype == PLS_HIP_F64)

@@ -372,6 +372,10 @@ __device__ __forceinline__ void narrow_update(const double *__restrict__ red, in
 //            -> Q[:,a];  XY -= (p q^T) tt (:429).
 //   then, when a+1 < A: w from XY (:403-411) -> W[:,a+1];  r (:412-416) -> R[:,a+1];
 //   vnext = r (KERNEL algo: next pass is X r) or w (NIPALS algo: next pass is X_a w).
+//   (r stays inside the loop for the NIPALS algo too although its passes never read it: q must be formed with r_a.
+//   Forming it with w_a instead -- equal in exact arithmetic, the deflated XY being orthogonal to every earlier r_j --
+//   and computing R after the loop was tried in round 2: once A exceeds the numerical rank B = R Q^T stops reproducing
+//   least squares (A = K = 200: relative error 26 instead of 1e-9), so the reference's form is kept.)
 // Dynamic LDS: A doubles (the p_j^T w inner products).
 // Body shared by component_update_kernel (one fit) and cv_folds_kernel (one fold per workgroup).
 // red == nullptr with a < 0: XY already holds the covariance.  nsl: slices in red.
@@ -389,16 +393,17 @@ __device__ __forceinline__ void component_update_body(const double *__restrict__
     // is one workgroup reduction instead of one wave walking K, and XY is not re-read.
     const bool fast = (M == 1 && K <= 4 * UPD_THREADS && a >= 0);
     const bool narrow = (M >= 2 && M <= 8);
+    const double *Rq = R;
     if (narrow) {
         if (M <= 2)
-            narrow_update<2>(red, nsl, XY, P, Q, R, W, K, M, A, a, power_iters, sh);
+            narrow_update<2>(red, nsl, XY, P, Q, Rq, W, K, M, A, a, power_iters, sh);
         else if (M <= 4)
-            narrow_update<4>(red, nsl, XY, P, Q, R, W, K, M, A, a, power_iters, sh);
+            narrow_update<4>(red, nsl, XY, P, Q, Rq, W, K, M, A, a, power_iters, sh);
         else
-            narrow_update<8>(red, nsl, XY, P, Q, R, W, K, M, A, a, power_iters, sh);
+            narrow_update<8>(red, nsl, XY, P, Q, Rq, W, K, M, A, a, power_iters, sh);
     } else if (fast) {
         const double tt = red_sum_n(red, nsl, K + 1, K);
-        const double *ra = R + (i64)a * K;
+        const double *ra = Rq + (i64)a * K;
         double xv[4], pv[4];
         double part = 0.0;
 #pragma unroll
@@ -434,7 +439,7 @@ __device__ __forceinline__ void component_update_body(const double *__restrict__
             for (int j = tid; j < K * M; j += UPD_THREADS) XY[j] = red_sum_n(red, nsl, K * M, j);
     } else {
         const double tt = red_sum_n(red, nsl, K + 1, K);
-        const double *ra = R + (i64)a * K;
+        const double *ra = Rq + (i64)a * K;
         for (int m = wv; m < M; m += UPD_WAVES) {  // q_m = (r^T XY[:,m]) / tt
             const double *xm = XY + (i64)m * K;
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // 4 independent chains: 8 loads in flight per lane

@@ -579,6 +579,7 @@ __global__ __launch_bounds__(WG) void sse_components_kernel(const T *__restrict_
 // and, when nss > 0,      red[s*LP + L] = sum_{b in slice s of nss} sspart[b]     (LP = L+1).
 // With nss == 0, LP = L.  The consumer (component_update_kernel, after the all-reduce of the
 // whole RED_SLICES*LP buffer in a sharded fit) adds the slices in index order.
+// out_stride > 0 replaces LP as the distance between the slices of `red` (a column block of a larger sliced matrix).
 // grid = (ceil(L/64), RED_SLICES); 256 threads = 64 columns x 4 interleaved sub-slices.
 // ------------------------------------------------------------------------------------
 constexpr int RED_SLICES = 8;
@@ -586,10 +587,11 @@ constexpr int RED_SLICES = 8;
 __global__ __launch_bounds__(WG) void reduce_partials_kernel(const double *__restrict__ part,
                                                              int nb, int L,
                                                              const double *__restrict__ sspart,
-                                                             int nss, double *__restrict__ red) {
+                                                             int nss, double *__restrict__ red,
+                                                             i64 out_stride) {
     __shared__ double sm[4][64];
     __shared__ double sm1[WG / WAVE];
-    const int LP = L + (nss > 0 ? 1 : 0);
+    const i64 LP = out_stride > 0 ? out_stride : (i64)(L + (nss > 0 ? 1 : 0));
     const int sl = blockIdx.y;
     const int jl = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + jl;

@@ -282,29 +282,13 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         Sg = std::max<i64>(1, std::min<i64>(Sg, nslabs_g));
         Sg = std::min<i64>(Sg, part_capacity_doubles / ((i64)K * K));
         if (Sg < 1) return 1;
-        static bool raised_g = false;
-        if (!raised_g) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_glds_kernel<T>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_G) != hipSuccess) {
-                (void)hipGetLastError();
-                return 1;
-            }
-            raised_g = true;
-        }
+        if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_glds_kernel<T>), (int)LDS_G)) return 1;
         hipLaunchKernelGGL(syrk_glds_kernel<T>, dim3(nblocks, (unsigned)Sg), dim3(256), LDS_G, stream, X, ldx, N, K, nbk,
                            static_cast<const T *>(zeros), part);
         *nb = (int)Sg;
         return 0;
     }
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&syrk_kernel<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYRK_LDS_BYTES) != hipSuccess) {
-            (void)hipGetLastError();
-            return 1;
-        }
-        raised = true;
-    }
+    if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_kernel<T>), (int)SYRK_LDS_BYTES)) return 1;
     hipLaunchKernelGGL(syrk_kernel<T>, dim3(nblocks, (unsigned)S), dim3(256), SYRK_LDS_BYTES, stream, X, ldx, N, K, nbk,
                        part);
     *nb = (int)S;

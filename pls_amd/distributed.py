@@ -48,6 +48,8 @@ def attach_reducer(handle, K: int, M: int, group=None):
         def __init__(self, ptr, n):
             self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
+    streams = {}  # hipStream_t -> torch view of it (the library's launch stream, whatever torch's current one is)
+
     def _cb(_user, buf, n, _stream):
         try:
             off = (int(buf) - base) // 8
@@ -55,16 +57,24 @@ def attach_reducer(handle, K: int, M: int, group=None):
                 view = stage[off:off + n]           # the staging tensor handed over with set_reduce_buffer
             else:                                   # other reductions (X^T X blocks, column statistics, SSE)
                 view = torch.as_tensor(_Raw(int(buf), int(n)), device=dev)
-            if backend == "nccl":
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
-            else:
-                if host["buf"].numel() < n:  # bounce buffer grows with the largest message
-                    host["buf"] = torch.zeros(int(n), dtype=torch.float64).pin_memory()
-                hb = host["buf"][:n]
-                torch.cuda.current_stream(dev).synchronize()
-                hb.copy_(view)
-                dist.all_reduce(hb, op=dist.ReduceOp.SUM, group=group)
-                view.copy_(hb, non_blocking=False)
+            # The contract (include/pls_hip.h): the reduction is ordered on the stream the library passes -- the
+            # handle's launch stream, which need not be torch's current stream at callback time.
+            key = int(_stream or 0)
+            st = streams.get(key)
+            if st is None:
+                st = streams[key] = torch.cuda.ExternalStream(key, device=dev) if key else torch.cuda.default_stream(dev)
+            with torch.cuda.stream(st):
+                if backend == "nccl":
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+                else:
+                    if host["buf"].numel() < n:  # bounce buffer grows with the largest message
+                        host["buf"] = torch.zeros(int(n), dtype=torch.float64).pin_memory()
+                    hb = host["buf"][:n]
+                    st.synchronize()
+                    hb.copy_(view)
+                    dist.all_reduce(hb, op=dist.ReduceOp.SUM, group=group)
+                    view.copy_(hb, non_blocking=False)
+                    st.synchronize()
             return 0
         except Exception:  # an exception must not unwind through the C frame
             import traceback

@@ -68,3 +68,19 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["parallelism"] == "row-shard x2"
     assert d["roofline"]["measured_over"].startswith("separate profiled steps")
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_alone_starts_the_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) must not fall back to a silent
+    single-GPU run: it starts the two ranks itself (child torch.distributed.run, before any GPU call) and the one
+    JSON line says n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "tiny", "--backend", "gloo"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "row-shard x2" and d["config"]["reducer"] == "torch"

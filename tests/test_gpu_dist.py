@@ -20,7 +20,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0):
+def _split(N, world, rank, splits):
+    """(row0, nrows): the even partition of pls_amd.distributed, or explicit block sizes (ragged / empty shards)"""
+    if splits is None:
+        from pls_amd.distributed import row_partition
+        return row_partition(N, world, rank)
+    assert sum(splits) == N and len(splits) == world
+    return sum(splits[:rank]), splits[rank]
+
+
+def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0, splits=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import torch
@@ -33,7 +42,7 @@ def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0):
         h = pls_amd.Handle()
         h.set_option(pls_amd.OPT_ALGO, algo)
         h.set_option(pls_amd.OPT_FUSE, fuse)
-        row0, nrows = row_partition(N, world, rank)
+        row0, nrows = _split(N, world, rank, splits)
         X = h.synth_x(row0, nrows, K, pls_amd.SEED_DEFAULT)
         Y = h.synth_y(row0, nrows, M, pls_amd.SEED_DEFAULT)
         attach_reducer(h, K, M)
@@ -52,6 +61,73 @@ def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0):
         raise
     finally:
         dist.destroy_process_group()
+
+
+def _run(world, N, K, M, A, algo, fuse, method=0, splits=None, timeout=180):
+    """spawn `world` ranks sharing the GPU; returns [(rank, outputs)] sorted by rank"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, K, M, A, algo, fuse, q, method, splits))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=timeout) for _ in procs), key=lambda t: t[0])
+    assert not any("error" in r[1] for r in res), [r[1].get("error") for r in res]
+    for p in procs:
+        p.join(timeout=timeout)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,splits,algo", [(2, None, 1), (2, None, 0), (3, [2050, 2044, 2], 1), (3, [2048, 0, 2048], 0),
+                                               (3, [1365, 1366, 1365], 1)],
+                         ids=["2ranks-nipals", "2ranks-kernel", "3ranks-tiny-shard-nipals", "3ranks-empty-shard-kernel",
+                              "3ranks-odd-shards-nipals"])
+def test_sharded_config5_shape(world, splits, algo):
+    """BASELINE config 5's own K = 1,024, m = 4, A = 20 (N reduced to the 4,096 rows of the committed twin), row-sharded
+    over 2 and 3 ranks -- even shards, a 2-row shard, an empty shard, odd shard sizes (no 16-byte row packs: the
+    one-product kernels on those ranks, the fused pass on the others).  Against the committed fixture and the oracle."""
+    from conftest import GOLDEN
+    from oracle import pls_oracle as po
+    g = np.load(os.path.join(GOLDEN, "c5twin_4096x1024_m4_A20.npz"))
+    N, K, M, A = (int(g[k]) for k in ("N", "K", "M", "A"))
+    res = _run(world, N, K, M, A, algo, 1, splits=splits)
+    ora = po.OracleLib()
+    X = ora.synth_x(0, N, K); Y = ora.synth_y(0, N, M)
+    ref = ora.plsr(X, Y, A)
+    for rank, out in res:
+        assert po.rel_fro(out["B"], g["B"]) < 1e-10, rank
+        for k in "WPQRB":
+            assert np.array_equal(out[k], res[0][1][k]), (rank, k)
+    T = np.concatenate([out["T"] for _, out in res], axis=0)
+    assert T.shape == (N, A)
+    s = po.sign_align(ref["W"], res[0][1]["W"])
+    lim = np.maximum(1e-9, 20 * g["col_err"])
+    err = np.linalg.norm(T * s - ref["T"], axis=0) / np.linalg.norm(ref["T"], axis=0)
+    assert (err <= lim).all(), err
+    got = dict(res[0][1]); got["T"] = T
+    assert (po.column_errors(ref, got) <= lim).all()
+
+
+@pytest.mark.parametrize("algo,method,splits", [(2, 0, [1500, 0, 1500]), (0, 1, [1500, 0, 1500]), (2, 0, [1001, 998, 1001]),
+                                                (0, 1, [1001, 998, 1001])],
+                         ids=["gram-empty-rank", "type2-empty-rank", "gram-odd-shards", "type2-odd-shards"])
+def test_sharded_xx_collective_shape(algo, method, splits):
+    """X^T X of a sharded KERNEL_TYPE2 / GRAM fit with K > 32 when the ranks take DIFFERENT local paths: an empty
+    rank (memset), odd row counts (the 32-column-block fallback instead of the matrix-core SYRK).  The exchange is one
+    all-reduce of 8*K*K values on every rank whatever its local path; a mismatch would hang or corrupt XX."""
+    from oracle import pls_oracle as po
+    N, K, M, A = 3000, 130, 2, 6
+    res = _run(3, N, K, M, A, algo, 1, method=method, splits=splits)
+    ora = po.OracleLib()
+    X = ora.synth_x(0, N, K); Y = ora.synth_y(0, N, M)
+    ref = ora.plsr(X, Y, A)
+    Bref = ora.coefficients(ref["R"], ref["Q"])
+    for rank, out in res:
+        assert po.rel_fro(out["B"], Bref) < 1e-10, rank
+        assert np.array_equal(out["W"], res[0][1]["W"])
 
 
 @pytest.mark.parametrize("N,K,M,A,world,algo,fuse", [

@@ -407,14 +407,16 @@ def test_random_shapes_all_plans(handle, oracle, po, mode, N, K, M, A):
     if not np.isfinite(Bref).all():  # degenerate draw (rank exhausted): NaN behaviour is covered elsewhere
         pytest.skip("rank-deficient draw")
     out = handle.fit_device(to_dev(Xh), to_dev(Yh), A); handle.synchronize()
-    # components whose independent CPU routes already disagree badly carry no information
+    # B is held at the north star's 1e-10 whatever the conditioning of the individual components (B depends on
+    # the subspace the first A weight vectors span, not on the vectors); the per-component tolerance of W, P, Q, R, T
+    # follows the disagreement of the two independent fp64 CPU routes on that component, capped at 1e-3 -- beyond
+    # that a component's direction carries no information and only B and the invariants are checked.
+    got = out["B"].cpu().numpy()
+    assert np.isfinite(got).all()
+    assert po.rel_fro(got, Bref) < TOL_B
     if np.max(cerr) > 1e-3:
-        got = out["B"].cpu().numpy()
-        assert np.isfinite(got).all()
-        assert po.rel_fro(got, Bref) < 1e-6
         return
-    check_against(po, out, ref, Bref, Tref=ref["T"], col_err=cerr,
-                  tol_b=max(TOL_B, 50 * float(np.max(cerr))), tol_inv=1e-6)
+    check_against(po, out, ref, Bref, Tref=ref["T"], col_err=cerr, tol_b=TOL_B, tol_inv=1e-6)
 
 
 @pytest.mark.parametrize("N,K,M,A", [(10, 15, 2, 2), (60, 401, 1, 10), (5000, 40, 3, 7), (1 << 18, 64, 2, 20)])

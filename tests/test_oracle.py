@@ -22,7 +22,11 @@ def _inputs(oracle, po, name, g):
         return (oracle.z_scores(po.read_csv(os.path.join(DATA, "nir.csv"))),
                 oracle.z_scores(po.read_csv(os.path.join(DATA, "octane.csv"))))
     N, K, M, seed = (int(g[k]) for k in ("N", "K", "M", "seed"))
-    return oracle.synth_x(0, N, K, seed), oracle.synth_y(0, N, M, seed)
+    X, Y = oracle.synth_x(0, N, K, seed), oracle.synth_y(0, N, M, seed)
+    if "f32" in g.files and int(g["f32"]):  # fp32 storage: the generator's values rounded once (config 4 twin)
+        X = np.asfortranarray(X.astype(np.float32).astype(np.float64))
+        Y = np.asfortranarray(Y.astype(np.float32).astype(np.float64))
+    return X, Y
 
 
 @pytest.mark.parametrize("name", _cases())
@@ -33,7 +37,8 @@ def test_oracle_reproduces_golden(oracle, po, name):
     c = oracle.plsr(X, Y, A)
     assert po.rel_fro(oracle.coefficients(c["R"], c["Q"]), g["B"]) < 1e-13
     for k in "WPQR":
-        assert po.rel_fro(c[k], g[k]) < 1e-12, k
+        if k in g.files:  # the config twins pin B, Q and tt only
+            assert po.rel_fro(c[k], g[k]) < 1e-12, k
     assert np.allclose((c["T"] ** 2).sum(0), g["tt"], rtol=1e-12)
 
 
@@ -114,7 +119,7 @@ def test_synth_twins_bit_identical(oracle, po):
     X = oracle.synth_x(0, 4096, 64)
     assert np.array_equal(X[100:200], oracle.synth_x(100, 100, 64))   # shards of one global matrix
     assert abs(X.mean()) < 0.05 and 0.8 < X.std() < 1.6
-    assert np.all(X * 2 ** 25 == np.round(X * 2 ** 25))                # dyadic: exact in fp64
+    assert np.all(X * 2 ** 31 == np.round(X * 2 ** 31))                # dyadic (noise amplitudes down to 2^-8 steps): exact in fp64
 
 
 def test_oracle_bad_arguments(oracle):
