@@ -234,6 +234,65 @@ PLS_HIP_API int pls_hip_synth_x(pls_hip_handle h, void *X, int64_t ldx, int64_t 
 PLS_HIP_API int pls_hip_synth_y(pls_hip_handle h, void *Y, int64_t ldy, int64_t row0, int64_t nrows,
                     int64_t M, uint64_t seed, int dtype);
 
+/* ---- one process, several GPUs: a group of handles behind one call ------------------
+ *
+ * The reference's Model is one object driven by one host thread (include/PLS/pls.h:187-199, src/pls.cpp:340-353).
+ * A group keeps that shape while the rows of X and Y are spread over the GPUs of the node: it owns one handle and
+ * one stream per member and runs every call with one host thread per member inside the library.  The members'
+ * partial products are summed by a reducer the group installs itself -- a fixed-order all-reduce in which
+ * every member reads the other members' partials directly over xGMI (peer access) and sums them in rank order, so
+ * all members hold identical bits; it is ordered on the members' streams with HIP events, no host synchronisation.
+ * `devices[r]` is the HIP ordinal of member r; an ordinal may repeat ("virtual shards" sharing one GPU: the way the
+ * sharded path is exercised on a one-GPU machine).  A group of one member is a plain single-GPU fit.
+ *
+ * Matrices live on the device(s) between calls (288 GB of HBM per GPU: the training data of a Model stays resident
+ * instead of being copied on the host as src/pls.cpp:344 does): pls_hip_group_upload spreads a HOST matrix over the
+ * members by rows -- member r owns a contiguous block, the same partition for every matrix of the same row
+ * count -- through a double-buffered pinned staging pipeline (host threads repack a tile while the DMA engine
+ * transfers the previous one).
+ */
+typedef struct pls_hip_group_s *pls_hip_group;
+typedef struct pls_hip_matrix_s *pls_hip_matrix;
+
+PLS_HIP_API int pls_hip_group_create(pls_hip_group *out, int n, const int *devices);
+PLS_HIP_API int pls_hip_group_destroy(pls_hip_group g);
+PLS_HIP_API int pls_hip_group_size(pls_hip_group g);
+/* member r's handle (options, timing); it stays owned by the group */
+PLS_HIP_API int pls_hip_group_handle(pls_hip_group g, int rank, pls_hip_handle *out);
+PLS_HIP_API int pls_hip_group_set_option(pls_hip_group g, int option, int64_t value);
+PLS_HIP_API const char *pls_hip_group_last_error(pls_hip_group g);
+
+/* N x K host matrix (column-major, ld) -> resident, row-sharded.  Returns when the data has left `host`. */
+PLS_HIP_API int pls_hip_group_upload(pls_hip_group g, const void *host, int64_t ld, int64_t N, int64_t K,
+                                     int dtype, pls_hip_matrix *out);
+/* uninitialised resident N x K matrix (e.g. the scores T of a fit) */
+PLS_HIP_API int pls_hip_group_alloc(pls_hip_group g, int64_t N, int64_t K, int dtype, pls_hip_matrix *out);
+/* columns [col0, col0 + ncols) of a resident matrix -> host (N x ncols, ld) */
+PLS_HIP_API int pls_hip_group_download(pls_hip_group g, pls_hip_matrix m, int64_t col0, int64_t ncols, void *host,
+                                       int64_t ld);
+PLS_HIP_API int pls_hip_group_free(pls_hip_group g, pls_hip_matrix m);
+PLS_HIP_API int pls_hip_matrix_shape(pls_hip_matrix m, int64_t *N, int64_t *K, int *dtype);
+/* member r's block of a resident matrix: device pointer, leading dimension, first row, row count */
+PLS_HIP_API int pls_hip_matrix_block(pls_hip_matrix m, int rank, void **data, int64_t *ld, int64_t *row0,
+                                     int64_t *nrows);
+
+/* pls_hip_fit on resident X (N x K), Y (N x M); T: resident N x A (scores stay on the devices; NULL for
+ * PLS_HIP_KERNEL_TYPE2).  W, P, R (K x A), Q (M x A), B (K x M, may be NULL) are HOST memory, ld = rows.  Every
+ * member derives the same W, P, Q, R, B bit for bit; the call checks that before it returns
+ * (PLS_HIP_ERR_REDUCER otherwise). */
+PLS_HIP_API int pls_hip_group_fit(pls_hip_group g, pls_hip_matrix X, pls_hip_matrix Y, int64_t A, int method,
+                                  double *W, double *P, double *Q, double *R, pls_hip_matrix T, double *B);
+/* out (resident N x C) = X * Bm, Bm HOST K x C fp64 (Model::scores / fitted_values, src/pls.cpp:439-451) */
+PLS_HIP_API int pls_hip_group_xb(pls_hip_group g, pls_hip_matrix X, const double *Bm, int64_t ldb, int64_t C,
+                                 pls_hip_matrix out);
+/* pls_hip_model_sse on resident data; R, Q, SSE (M x A) HOST */
+PLS_HIP_API int pls_hip_group_model_sse(pls_hip_group g, pls_hip_matrix X, pls_hip_matrix Y, int64_t A,
+                                        const double *R, const double *Q, double *SSE);
+/* pls_hip_cv_folds on resident data, E (M x nobs x A) HOST.  Groups of one member only (the fold kernel works on
+ * K-sized data of ONE device); PLS_HIP_ERR_UNSUPPORTED otherwise. */
+PLS_HIP_API int pls_hip_group_cv_folds(pls_hip_group g, pls_hip_matrix X, pls_hip_matrix Y, int64_t A,
+                                       const int64_t *test_idx, int64_t test_size, int64_t num_folds, double *E);
+
 #ifdef __cplusplus
 }
 #endif

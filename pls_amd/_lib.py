@@ -71,6 +71,24 @@ PROTOTYPES = [
     ("pls_hip_cv_folds", _int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _int, _int, _vp]),
     ("pls_hip_synth_x", _int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_uint64, _int]),
     ("pls_hip_synth_y", _int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_uint64, _int]),
+    # one process, several GPUs: groups and resident matrices
+    ("pls_hip_group_create", _int, [ctypes.POINTER(_vp), _int, ctypes.POINTER(_int)]),
+    ("pls_hip_group_destroy", _int, [_vp]),
+    ("pls_hip_group_size", _int, [_vp]),
+    ("pls_hip_group_handle", _int, [_vp, _int, ctypes.POINTER(_vp)]),
+    ("pls_hip_group_set_option", _int, [_vp, _int, _i64]),
+    ("pls_hip_group_last_error", ctypes.c_char_p, [_vp]),
+    ("pls_hip_group_upload", _int, [_vp, _vp, _i64, _i64, _i64, _int, ctypes.POINTER(_vp)]),
+    ("pls_hip_group_alloc", _int, [_vp, _i64, _i64, _int, ctypes.POINTER(_vp)]),
+    ("pls_hip_group_download", _int, [_vp, _vp, _i64, _i64, _vp, _i64]),
+    ("pls_hip_group_free", _int, [_vp, _vp]),
+    ("pls_hip_matrix_shape", _int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_int)]),
+    ("pls_hip_matrix_block", _int, [_vp, _int, ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                                    ctypes.POINTER(_i64)]),
+    ("pls_hip_group_fit", _int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("pls_hip_group_xb", _int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    ("pls_hip_group_model_sse", _int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    ("pls_hip_group_cv_folds", _int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp]),
 ]
 
 _LIB = None

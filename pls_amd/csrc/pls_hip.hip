@@ -20,6 +20,7 @@
 #include "syrk_kernels.hpp"
 #include "cv_kernels.hpp"
 #include "synth_kernels.hpp"
+#include "host_pipeline.hpp"
 
 using plsk::i64;
 
@@ -58,6 +59,9 @@ struct pls_hip_context {
     Launch cur_fit{};
     bool fit_timed = false;
     int num_cu = 256;
+    // host <-> device staging (host_pipeline.hpp): pinned double buffer + copy threads, created on first large transfer
+    plsh::Stager stager;
+    int copy_threads = 0;  // 0 = default (PLS_HIP_COPY_THREADS or min(8, cores))
 };
 
 namespace {
@@ -741,15 +745,28 @@ void end_fit_timing(pls_hip_context *c) {
     c->fit_timed = false;
 }
 
-// host <-> device staging of a column-major matrix with leading dimension
+// host <-> device staging of a column-major matrix with leading dimension.  Matrices of a few MB and more go
+// through the pinned double-buffer pipeline of host_pipeline.hpp (the caller's pageable memory is repacked by host
+// threads while the DMA engine moves the previous tile); small ones are one plain copy.
+constexpr size_t PIPELINE_MIN_BYTES = (size_t)4 << 20;
 int h2d(pls_hip_context *c, void *dst, i64 ldd, const void *src, i64 lds, i64 rows, i64 cols, size_t es) {
     if (rows == 0 || cols == 0) return PLS_HIP_OK;
+    if ((size_t)rows * (size_t)cols * es >= PIPELINE_MIN_BYTES) {
+        HIPCHK(c, c->stager.ensure(c->copy_threads > 0 ? c->copy_threads : plsh::default_copy_threads()));
+        HIPCHK(c, plsh::upload(c->stager, c->stream, dst, ldd, src, lds, rows, cols, es));
+        return PLS_HIP_OK;
+    }
     HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)ldd * es, src, (size_t)lds * es, (size_t)rows * es,
                                (size_t)cols, hipMemcpyHostToDevice, c->stream));
     return PLS_HIP_OK;
 }
 int d2h(pls_hip_context *c, void *dst, i64 ldd, const void *src, i64 lds, i64 rows, i64 cols, size_t es) {
     if (rows == 0 || cols == 0) return PLS_HIP_OK;
+    if ((size_t)rows * (size_t)cols * es >= PIPELINE_MIN_BYTES) {
+        HIPCHK(c, c->stager.ensure(c->copy_threads > 0 ? c->copy_threads : plsh::default_copy_threads()));
+        HIPCHK(c, plsh::download(c->stager, c->stream, dst, ldd, src, lds, rows, cols, es));
+        return PLS_HIP_OK;
+    }
     HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)ldd * es, src, (size_t)lds * es, (size_t)rows * es,
                                (size_t)cols, hipMemcpyDeviceToHost, c->stream));
     return PLS_HIP_OK;
@@ -795,6 +812,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    h->stager.release();
     delete h;
     return PLS_HIP_OK;
 }
@@ -1266,12 +1284,13 @@ int pls_hip_model_sse(pls_hip_handle h, const void *X, int64_t ldx, const void *
     CHK(check_handle(h));
     if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
     if (mem != PLS_HIP_MEM_HOST && mem != PLS_HIP_MEM_DEVICE) return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
-    if (N < 1 || K < 1 || M < 1 || A < 1 || A * M > 1024 || K > (1 << 30) || !X || !Y || !R || !Q || !SSE ||
-        ldx < N || ldy < N)
+    const bool empty_member = (N == 0 && h->nranks > 1);  // an empty shard still takes part in the reduction
+    if (N < 0 || (N == 0 && !empty_member) || K < 1 || M < 1 || A < 1 || A * M > 1024 || K > (1 << 30) ||
+        (N > 0 && (!X || !Y)) || !R || !Q || !SSE || ldx < std::max<i64>(N, 1) || ldy < std::max<i64>(N, 1))
         return fail(h, PLS_HIP_ERR_INVALID, "bad model_sse arguments");
     CHK(set_device(h));
     const size_t es = esize(dtype);
-    const i64 ldn = N + (N & 1);
+    const i64 ldn = std::max<i64>(N, 1) + (std::max<i64>(N, 1) & 1);
     const void *dX = X, *dY = Y;
     const double *dR = R, *dQ = Q;
     double *dE = SSE;
@@ -1293,10 +1312,10 @@ int pls_hip_model_sse(pls_hip_handle h, const void *X, int64_t ldx, const void *
     CHK(ensure(h, h->hOut, (size_t)ldn * A * es));  // the scores S = X R stay on the device
     int nss = 0, rc;
     if (dtype == PLS_HIP_F64) {
-        CHK(launch_xb<double>(h, (const double *)dX, dldx, N, (int)K, dR, K, (int)A, (double *)h->hOut.p, ldn, nullptr, &nss));
+        if (N > 0) CHK(launch_xb<double>(h, (const double *)dX, dldx, N, (int)K, dR, K, (int)A, (double *)h->hOut.p, ldn, nullptr, &nss));
         rc = sse_device<double>(h, (const double *)h->hOut.p, ldn, (const double *)dY, dldy, N, (int)A, (int)M, dQ, dE);
     } else {
-        CHK(launch_xb<float>(h, (const float *)dX, dldx, N, (int)K, dR, K, (int)A, (float *)h->hOut.p, ldn, nullptr, &nss));
+        if (N > 0) CHK(launch_xb<float>(h, (const float *)dX, dldx, N, (int)K, dR, K, (int)A, (float *)h->hOut.p, ldn, nullptr, &nss));
         rc = sse_device<float>(h, (const float *)h->hOut.p, ldn, (const float *)dY, dldy, N, (int)A, (int)M, dQ, dE);
     }
     if (rc != PLS_HIP_OK) return rc;
@@ -1361,3 +1380,5 @@ int pls_hip_synth_y(pls_hip_handle h, void *Y, int64_t ldy, int64_t row0, int64_
 }
 
 }  // extern "C"
+
+#include "group_impl.hpp"

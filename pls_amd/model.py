@@ -311,6 +311,116 @@ class Handle:
 
 
 # ---------------------------------------------------------------------------------------------
+# one process, several GPUs (include/pls_hip.h: pls_hip_group) -- what the C++ PLS::Model drives
+# ---------------------------------------------------------------------------------------------
+
+class Group:
+    """n member handles, one per entry of `devices` (an ordinal may repeat: virtual shards on one GPU), one host
+    thread per member inside the library, row-sharded resident matrices, in-process fixed-order all-reduce.
+    Host (numpy) matrices in, host results out."""
+
+    def __init__(self, devices):
+        self._lib = L.lib()
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        g = ctypes.c_void_p()
+        L.check(self._lib.pls_hip_group_create(ctypes.byref(g), len(devices), devs))
+        self.g = g
+        self.n = len(devices)
+
+    def _check(self, rc):
+        if rc != L.OK:
+            raw = self._lib.pls_hip_group_last_error(self.g)
+            raise L.PlsHipError(rc, raw.decode("utf-8", "replace") if raw else "")
+
+    def close(self):
+        if getattr(self, "g", None):
+            self._lib.pls_hip_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, opt: int, value: int):
+        self._check(self._lib.pls_hip_group_set_option(self.g, opt, int(value)))
+
+    def upload(self, a, dtype=np.float64):
+        a = _np_f(a, dtype)
+        m = ctypes.c_void_p()
+        self._check(self._lib.pls_hip_group_upload(self.g, a.ctypes.data_as(ctypes.c_void_p), max(a.shape[0], 1), a.shape[0],
+                                                   a.shape[1], L.F64 if dtype == np.float64 else L.F32, ctypes.byref(m)))
+        return m
+
+    def alloc(self, N: int, K: int, dtype=np.float64):
+        m = ctypes.c_void_p()
+        self._check(self._lib.pls_hip_group_alloc(self.g, N, K, L.F64 if dtype == np.float64 else L.F32, ctypes.byref(m)))
+        return m
+
+    def shape(self, m):
+        n, k, dt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        L.check(self._lib.pls_hip_matrix_shape(m, ctypes.byref(n), ctypes.byref(k), ctypes.byref(dt)))
+        return int(n.value), int(k.value), (np.float64 if dt.value == L.F64 else np.float32)
+
+    def blocks(self, m):
+        """[(row0, nrows)] of the members"""
+        out = []
+        for r in range(self.n):
+            r0, nr = ctypes.c_int64(), ctypes.c_int64()
+            L.check(self._lib.pls_hip_matrix_block(m, r, None, None, ctypes.byref(r0), ctypes.byref(nr)))
+            out.append((int(r0.value), int(nr.value)))
+        return out
+
+    def download(self, m, col0: int = 0, ncols: int | None = None):
+        N, K, dt = self.shape(m)
+        ncols = K - col0 if ncols is None else ncols
+        out = np.zeros((N, ncols), dtype=dt, order="F")
+        self._check(self._lib.pls_hip_group_download(self.g, m, col0, ncols, out.ctypes.data_as(ctypes.c_void_p), N))
+        return out
+
+    def free(self, m):
+        self._check(self._lib.pls_hip_group_free(self.g, m))
+
+    def fit(self, X, Y, A: int, method: int = KERNEL_TYPE1):
+        """X, Y: resident matrices.  Returns dict(W,P,Q,R,B numpy; T resident matrix or None)."""
+        N, K, dt = self.shape(X)
+        M = self.shape(Y)[1]
+        W = np.zeros((K, A), order="F"); P = np.zeros((K, A), order="F"); R = np.zeros((K, A), order="F")
+        Q = np.zeros((M, A), order="F"); B = np.zeros((K, M), order="F")
+        T = self.alloc(N, A, dt) if method == KERNEL_TYPE1 else None
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self._check(self._lib.pls_hip_group_fit(self.g, X, Y, A, method, p(W), p(P), p(Q), p(R), T, p(B)))
+        return dict(W=W, P=P, Q=Q, R=R, T=T, B=B)
+
+    def xb(self, X, Bm):
+        N, K, dt = self.shape(X)
+        Bm = _np_f(Bm, np.float64)
+        out = self.alloc(N, Bm.shape[1], dt)
+        self._check(self._lib.pls_hip_group_xb(self.g, X, Bm.ctypes.data_as(ctypes.c_void_p), K, Bm.shape[1], out))
+        return out
+
+    def model_sse(self, X, Y, R, Q):
+        R = _np_f(R, np.float64); Q = _np_f(Q, np.float64)
+        M, A = Q.shape
+        sse = np.zeros((M, A), order="F")
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self._check(self._lib.pls_hip_group_model_sse(self.g, X, Y, A, p(R), p(Q), p(sse)))
+        return sse
+
+    def cv_folds(self, X, Y, A: int, test_idx):
+        idx = np.ascontiguousarray(np.asarray(test_idx, dtype=np.int64))
+        if idx.ndim == 1:
+            idx = idx[:, None]
+        nf, ts = idx.shape
+        M = self.shape(Y)[1]
+        E = np.zeros((M, A, nf * ts))
+        self._check(self._lib.pls_hip_group_cv_folds(self.g, X, Y, A, idx.ctypes.data_as(ctypes.c_void_p), ts, nf,
+                                                     E.ctypes.data_as(ctypes.c_void_p)))
+        return E.transpose(0, 2, 1)
+
+
+# ---------------------------------------------------------------------------------------------
 # PLS::Model
 # ---------------------------------------------------------------------------------------------
 
