@@ -16,6 +16,7 @@
 #include <algorithm>  // sort
 #include <complex>
 #include <iostream>  // std::cerr default streams
+#include <memory>    // shared_ptr (device-resident data of a Model)
 #include <numeric>   // iota
 #include <random>    // std::mt19937
 #include <string>
@@ -164,10 +165,17 @@ struct Model {
     void print_state(std::ostream &os = std::cerr) const;
 
 private:
-    const Mat2D _X, _Y;  // kept for the cross-validation methods
+    // The reference keeps host copies `const Mat2D _X, _Y` of the training data for its cross-validation methods
+    // and a complex N x A score matrix T (include/PLS/pls.h:250-253 upstream).  Here the training data and the
+    // scores of the last fit stay RESIDENT ON THE DEVICE(S) instead (row-sharded over the GPUs PLS_HIP_DEVICES
+    // names): no second host copy of X, no N x A read-back per fit; print_state() fetches T when it is asked for.
+    struct Resident;
+    std::shared_ptr<const Resident> _data;    // X, Y of the constructor
+    std::shared_ptr<const Resident> _scores;  // T of the last plsr() (KERNEL_TYPE1 only, as upstream)
     size_t A;
-    Mat2Dc P, W, R, Q, T;
+    Mat2Dc P, W, R, Q;
     PLS::METHOD method;
+    void fit_resident(const Resident &d, const METHOD &algorithm);
 
     // shape-only models used by cv_LSO: no data yet, plsr() is called per trial
     Model(const size_t &num_predictors, const size_t &num_responses, const METHOD &algorithm = KERNEL_TYPE1);

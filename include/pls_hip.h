@@ -200,7 +200,8 @@ PLS_HIP_API int pls_hip_colwise_z_scores(pls_hip_handle h, const void *X, int64_
                                          double *mean, double *sd);
 /* SSE(M x A, ld M)[m, c-1] = sum_i (Y[i,m] - (S[:, :c] Q[:, :c]^T)[i,m])^2 for c = 1..A in one sweep
  * over the scores S = X R (N x A): Model::SSE for every component count (src/pls.cpp:457-459) without the
- * A separate X*B passes of print_explained_variance (:551-562).  A*M <= 1024. */
+ * A separate X*B passes of print_explained_variance (:551-562).  Any A (long component lists are swept in ranges of
+ * 1024/M component counts); M <= 1024. */
 PLS_HIP_API int pls_hip_sse_by_components(pls_hip_handle h, const void *S, int64_t lds, const void *Y,
                                           int64_t ldy, int64_t N, int64_t A, int64_t M, const double *Q,
                                           int dtype, double *SSE);
@@ -265,6 +266,15 @@ PLS_HIP_API const char *pls_hip_group_last_error(pls_hip_group g);
 /* N x K host matrix (column-major, ld) -> resident, row-sharded.  Returns when the data has left `host`. */
 PLS_HIP_API int pls_hip_group_upload(pls_hip_group g, const void *host, int64_t ld, int64_t N, int64_t K,
                                      int dtype, pls_hip_matrix *out);
+/* X (N x K) and Y (N x M) of one data set together.  While the rows of X stream in over PCIe, every member
+ * accumulates X^T X and X^T Y of its rows block by block on the matrix cores (a block's SYRK takes a fraction of
+ * its transfer time), and the pair keeps them: a later pls_hip_group_fit(X, Y) under PLS_HIP_ALGO_AUTO or _GRAM (and
+ * KERNEL_TYPE2) starts its component loop at once -- no pass over X before it, one (T = X R) after it -- and
+ * pls_hip_group_cv_folds skips its own X^T X.  Layouts the matrix-core kernel declines (K > 4096, unaligned)
+ * simply upload; the fit then forms the products itself. */
+PLS_HIP_API int pls_hip_group_upload_xy(pls_hip_group g, const void *hostX, int64_t ldx, const void *hostY,
+                                        int64_t ldy, int64_t N, int64_t K, int64_t M, int dtype,
+                                        pls_hip_matrix *X, pls_hip_matrix *Y);
 /* uninitialised resident N x K matrix (e.g. the scores T of a fit) */
 PLS_HIP_API int pls_hip_group_alloc(pls_hip_group g, int64_t N, int64_t K, int dtype, pls_hip_matrix *out);
 /* columns [col0, col0 + ncols) of a resident matrix -> host (N x ncols, ld) */

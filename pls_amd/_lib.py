@@ -79,6 +79,8 @@ PROTOTYPES = [
     ("pls_hip_group_set_option", _int, [_vp, _int, _i64]),
     ("pls_hip_group_last_error", ctypes.c_char_p, [_vp]),
     ("pls_hip_group_upload", _int, [_vp, _vp, _i64, _i64, _i64, _int, ctypes.POINTER(_vp)]),
+    ("pls_hip_group_upload_xy", _int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, ctypes.POINTER(_vp),
+                                       ctypes.POINTER(_vp)]),
     ("pls_hip_group_alloc", _int, [_vp, _i64, _i64, _int, ctypes.POINTER(_vp)]),
     ("pls_hip_group_download", _int, [_vp, _vp, _i64, _i64, _vp, _i64]),
     ("pls_hip_group_free", _int, [_vp, _vp]),

@@ -69,6 +69,10 @@ struct pls_hip_matrix_s {
     i64 N = 0, K = 0;
     std::vector<void *> data;  // per member: device block (nrows x K, ld)
     std::vector<i64> ld, row0, nrows;
+    // pls_hip_group_upload_xy: per member X^T X (K x K) and X^T Y (K x M) of its rows, formed during the upload
+    std::vector<double *> gram_xx, gram_xy;
+    uint64_t id = 0, gram_with = 0;  // serial number of this matrix / of the Y the products were formed with
+    bool gram_ok = false;
 };
 
 struct pls_hip_group_s;
@@ -282,6 +286,8 @@ int pls_hip_group_alloc(pls_hip_group g, int64_t N, int64_t K, int dtype, pls_hi
     if (N < 1 || K < 1 || (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32)) return gfail(g, PLS_HIP_ERR_INVALID, "bad matrix shape");
     std::unique_ptr<pls_hip_matrix_s> m(new (std::nothrow) pls_hip_matrix_s());
     if (!m) return PLS_HIP_ERR_ALLOC;
+    static std::atomic<uint64_t> serial{0};
+    m->id = ++serial;
     m->dtype = dtype;
     m->N = N;
     m->K = K;
@@ -307,12 +313,13 @@ int pls_hip_group_alloc(pls_hip_group g, int64_t N, int64_t K, int dtype, pls_hi
 int pls_hip_group_free(pls_hip_group g, pls_hip_matrix m) {
     if (!m) return PLS_HIP_OK;
     if (!g) return PLS_HIP_ERR_INVALID;
-    for (int r = 0; r < (int)m->data.size() && r < g->n; ++r)
-        if (m->data[r]) {
-            (void)hipSetDevice(g->dev[r]);
-            (void)hipStreamSynchronize(g->stream[r]);  // launches of this member may still use the block
-            (void)hipFree(m->data[r]);
-        }
+    for (int r = 0; r < (int)m->data.size() && r < g->n; ++r) {
+        (void)hipSetDevice(g->dev[r]);
+        (void)hipStreamSynchronize(g->stream[r]);  // launches of this member may still use the block
+        if (m->data[r]) (void)hipFree(m->data[r]);
+        if (r < (int)m->gram_xx.size() && m->gram_xx[r]) (void)hipFree(m->gram_xx[r]);
+        if (r < (int)m->gram_xy.size() && m->gram_xy[r]) (void)hipFree(m->gram_xy[r]);
+    }
     delete m;
     return PLS_HIP_OK;
 }
@@ -356,6 +363,66 @@ int pls_hip_group_upload(pls_hip_group g, const void *host, int64_t ld, int64_t 
     return PLS_HIP_OK;
 }
 
+int pls_hip_group_upload_xy(pls_hip_group g, const void *hostX, int64_t ldx, const void *hostY, int64_t ldy, int64_t N,
+                            int64_t K, int64_t M, int dtype, pls_hip_matrix *Xo, pls_hip_matrix *Yo) {
+    if (!g || !Xo || !Yo) return PLS_HIP_ERR_INVALID;
+    *Xo = *Yo = nullptr;
+    if (!hostX || !hostY || N < 1 || ldx < N || ldy < N || K < 1 || M < 1)
+        return gfail(g, PLS_HIP_ERR_INVALID, "bad upload_xy arguments");
+    pls_hip_matrix X = nullptr, Y = nullptr;
+    CHK(pls_hip_group_alloc(g, N, K, dtype, &X));
+    int rc = pls_hip_group_alloc(g, N, M, dtype, &Y);
+    if (rc != PLS_HIP_OK) {
+        pls_hip_group_free(g, X);
+        return rc;
+    }
+    X->gram_xx.assign(g->n, nullptr);
+    X->gram_xy.assign(g->n, nullptr);
+    const size_t es = esize(dtype);
+    std::vector<char> okv(g->n, 0);
+    rc = run_members(g, [&](int r) -> int {
+        pls_hip_context *c = g->h[r];
+        if (hipMalloc((void **)&X->gram_xx[r], (size_t)K * K * 8) != hipSuccess ||
+            hipMalloc((void **)&X->gram_xy[r], (size_t)K * M * 8) != hipSuccess) {
+            (void)hipGetLastError();  // no room for the products: a plain upload
+            CHK(h2d(c, Y->data[r], Y->ld[r], (const char *)hostY + (size_t)Y->row0[r] * es, ldy, Y->nrows[r], M, es));
+            CHK(h2d(c, X->data[r], X->ld[r], (const char *)hostX + (size_t)X->row0[r] * es, ldx, X->nrows[r], K, es));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            return PLS_HIP_OK;
+        }
+        CHK(h2d(c, Y->data[r], Y->ld[r], (const char *)hostY + (size_t)Y->row0[r] * es, ldy, Y->nrows[r], M, es));
+        bool ok = false;
+        if (X->nrows[r] == 0) {  // an empty member contributes zeros
+            HIPCHK(c, hipMemsetAsync(X->gram_xx[r], 0, (size_t)K * K * 8, c->stream));
+            HIPCHK(c, hipMemsetAsync(X->gram_xy[r], 0, (size_t)K * M * 8, c->stream));
+            ok = true;
+        } else if (dtype == PLS_HIP_F64) {
+            CHK(upload_accumulate<double>(c, (double *)X->data[r], X->ld[r], (const double *)hostX + X->row0[r], ldx,
+                                          X->nrows[r], (int)K, (const double *)Y->data[r], Y->ld[r], (int)M,
+                                          X->gram_xx[r], X->gram_xy[r], &ok));
+        } else {
+            CHK(upload_accumulate<float>(c, (float *)X->data[r], X->ld[r], (const float *)hostX + X->row0[r], ldx,
+                                         X->nrows[r], (int)K, (const float *)Y->data[r], Y->ld[r], (int)M, X->gram_xx[r],
+                                         X->gram_xy[r], &ok));
+        }
+        okv[r] = ok ? 1 : 0;
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's memory has been read, the products are complete
+        return PLS_HIP_OK;
+    });
+    if (rc != PLS_HIP_OK) {
+        pls_hip_group_free(g, X);
+        pls_hip_group_free(g, Y);
+        return rc;
+    }
+    bool all = true;  // the members must agree on the plan of a later fit: all of them hold the products, or none is used
+    for (int r = 0; r < g->n; ++r) all = all && okv[r];
+    X->gram_ok = all;
+    X->gram_with = Y->id;
+    *Xo = X;
+    *Yo = Y;
+    return PLS_HIP_OK;
+}
+
 int pls_hip_group_download(pls_hip_group g, pls_hip_matrix m, int64_t col0, int64_t ncols, void *host, int64_t ld) {
     if (!g || !same_partition(g, m) || !host || col0 < 0 || ncols < 0 || col0 + ncols > m->K || ld < m->N)
         return g ? gfail(g, PLS_HIP_ERR_INVALID, "bad download arguments") : PLS_HIP_ERR_INVALID;
@@ -391,9 +458,16 @@ int pls_hip_group_fit(pls_hip_group g, pls_hip_matrix X, pls_hip_matrix Y, int64
         CHK(ensure(c, c->hQ, nQ * 8));
         if (B) CHK(ensure(c, c->hB, nB * 8));
         const bool t1 = (method == PLS_HIP_KERNEL_TYPE1);
-        CHK(pls_hip_fit(c, X->data[r], X->ld[r], Y->data[r], Y->ld[r], X->nrows[r], K, M, A, method, X->dtype,
-                        PLS_HIP_MEM_DEVICE, (double *)c->hW.p, (double *)c->hP.p, (double *)c->hQ.p, (double *)c->hR.p,
-                        t1 ? T->data[r] : nullptr, t1 ? T->ld[r] : 1, B ? (double *)c->hB.p : nullptr));
+        if (X->gram_ok && X->gram_with == Y->id) {  // X^T X and X^T Y of this member's rows came with the upload
+            c->pre_xx = X->gram_xx[r];
+            c->pre_xy = X->gram_xy[r];
+        }
+        const int frc = pls_hip_fit(c, X->data[r], X->ld[r], Y->data[r], Y->ld[r], X->nrows[r], K, M, A, method, X->dtype,
+                                    PLS_HIP_MEM_DEVICE, (double *)c->hW.p, (double *)c->hP.p, (double *)c->hQ.p,
+                                    (double *)c->hR.p, t1 ? T->data[r] : nullptr, t1 ? T->ld[r] : 1,
+                                    B ? (double *)c->hB.p : nullptr);
+        c->pre_xx = c->pre_xy = nullptr;
+        CHK(frc);
         double *w = r == 0 ? W : scratch[r - 1].data();
         double *p = r == 0 ? P : w + nW, *rr = r == 0 ? R : w + 2 * nW, *q = r == 0 ? Q : w + 3 * nW;
         double *b = r == 0 ? B : w + 3 * nW + nQ;
@@ -467,9 +541,15 @@ int pls_hip_group_cv_folds(pls_hip_group g, pls_hip_matrix X, pls_hip_matrix Y, 
     // the residuals land in a device buffer of the member (pls_hip_cv_folds returns synchronised) and are read back
     DevBuf tmp;
     int rc = ensure(c, tmp, (size_t)nobs * A * Y->K * 8);
-    if (rc == PLS_HIP_OK)
+    if (rc == PLS_HIP_OK) {
+        if (X->gram_ok && X->gram_with == Y->id) {  // the folds downdate X^T X and X^T Y: both came with the upload
+            c->pre_xx = X->gram_xx[0];
+            c->pre_xy = X->gram_xy[0];
+        }
         rc = pls_hip_cv_folds(c, X->data[0], X->ld[0], Y->data[0], Y->ld[0], X->N, X->K, Y->K, A, test_idx, test_size,
                               num_folds, X->dtype, PLS_HIP_MEM_DEVICE, (double *)tmp.p);
+        c->pre_xx = c->pre_xy = nullptr;
+    }
     if (rc == PLS_HIP_OK && hipMemcpy(E, tmp.p, (size_t)nobs * A * Y->K * 8, hipMemcpyDeviceToHost) != hipSuccess) {
         c->err = "hipMemcpy of the fold residuals failed";
         rc = PLS_HIP_ERR_DEVICE;

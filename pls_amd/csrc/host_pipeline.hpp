@@ -9,14 +9,18 @@
 // exactly once.  Device -> host runs the same pipeline in reverse.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -26,8 +30,22 @@ namespace plsh {
 // is single-threaded by contract).  The calling thread works too.
 class CopyPool {
 public:
-    explicit CopyPool(int nthreads) {
-        for (int i = 1; i < nthreads; ++i) workers_.emplace_back([this] { loop(); });
+    // cpus: CPUs the workers may run on (empty = wherever the scheduler puts them)
+    explicit CopyPool(int nthreads, const std::vector<int> &cpus = std::vector<int>())
+        : caller_works_(cpus.empty() || nthreads < 3) {
+        // with workers bound to the device's NUMA node the calling thread (which may sit on another socket, where every
+        // piece it copied would cross the inter-socket link twice) only hands out the work and waits
+        for (int i = caller_works_ ? 1 : 0; i < nthreads; ++i)
+            workers_.emplace_back([this, cpus] {
+                if (!cpus.empty()) {
+                    cpu_set_t set;
+                    CPU_ZERO(&set);
+                    for (int c : cpus)
+                        if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+                    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);  // best effort
+                }
+                loop();
+            });
     }
     ~CopyPool() {
         {
@@ -55,7 +73,7 @@ public:
             ++epoch_;
         }
         cv_.notify_all();
-        run();
+        if (caller_works_) run();
         // every worker acknowledges the epoch: none of them can still be inside run() when the next one is set up,
         // and a job that was taken has been completed by its taker before that thread left run()
         std::unique_lock<std::mutex> lk(mu_);
@@ -96,6 +114,7 @@ private:
     std::atomic<int> next_{0};
     uint64_t epoch_ = 0;
     bool stop_ = false;
+    const bool caller_works_;
 };
 
 inline int default_copy_threads() {
@@ -104,11 +123,48 @@ inline int default_copy_threads() {
         if (v >= 1 && v <= 256) return v;
     }
     const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(8u, hw ? hw : 1u));
+    return (int)std::max(1u, std::min(16u, (hw ? hw : 1u) / 2));
 }
 
-constexpr size_t STAGE_BYTES = (size_t)32 << 20;  // per pinned buffer; two per handle
-constexpr size_t PIECE_BYTES = (size_t)512 << 10; // one copy job
+// CPUs of the NUMA node closest to `device` (hipDeviceAttributeHostNumaId + the node's sysfs cpulist, "0-63,128-191");
+// empty when the platform does not say.  The pinned staging buffers live on that node; copy threads running there
+// repack at the local memory rate whatever core the caller's thread happens to be on (measured on a two-socket host:
+// 47-52 GB/s staged from the device's socket, 28-34 GB/s from the other one).
+inline std::vector<int> device_numa_cpus(int device) {
+    std::vector<int> cpus;
+    if (const char *e = std::getenv("PLS_HIP_COPY_BIND"))
+        if (std::atoi(e) == 0) return cpus;
+    int node = -1;
+    if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, device) != hipSuccess || node < 0) {
+        (void)hipGetLastError();
+        return cpus;
+    }
+    std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+    std::string spec;
+    if (!f.is_open() || !std::getline(f, spec)) return cpus;
+    size_t pos = 0;
+    while (pos < spec.size()) {
+        size_t end = spec.find(',', pos);
+        if (end == std::string::npos) end = spec.size();
+        const std::string tok = spec.substr(pos, end - pos);
+        const size_t dash = tok.find('-');
+        const int a = std::atoi(tok.c_str()), b = dash == std::string::npos ? a : std::atoi(tok.c_str() + dash + 1);
+        for (int c = a; c <= b && c - a < 4096; ++c) cpus.push_back(c);
+        pos = end + 1;
+    }
+    return cpus;
+}
+
+inline size_t env_size(const char *name, size_t dflt, size_t lo, size_t hi) {
+    if (const char *e = std::getenv(name)) {
+        const long v = std::atol(e);
+        if (v >= (long)lo && v <= (long)hi) return (size_t)v;
+    }
+    return dflt;
+}
+// per pinned buffer (two per handle), MiB: PLS_HIP_STAGE_MB; one copy job, KiB: PLS_HIP_PIECE_KB
+static const size_t STAGE_BYTES = env_size("PLS_HIP_STAGE_MB", 32, 1, 1024) << 20;
+static const size_t PIECE_BYTES = env_size("PLS_HIP_PIECE_KB", 512, 4, 65536) << 10;
 
 struct Stager {
     void *buf[2] = {nullptr, nullptr};
@@ -117,7 +173,7 @@ struct Stager {
     CopyPool *pool = nullptr;
     int slot = 0;
 
-    hipError_t ensure(int threads) {
+    hipError_t ensure(int threads, int device) {
         if (buf[0]) return hipSuccess;
         for (int i = 0; i < 2; ++i) {
             hipError_t e = hipHostMalloc(&buf[i], STAGE_BYTES, hipHostMallocDefault);
@@ -125,7 +181,7 @@ struct Stager {
             e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
             if (e != hipSuccess) return e;
         }
-        pool = new CopyPool(threads);
+        pool = new CopyPool(threads, device_numa_cpus(device));
         return hipSuccess;
     }
     void release() {

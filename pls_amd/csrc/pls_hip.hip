@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -61,7 +62,11 @@ struct pls_hip_context {
     int num_cu = 256;
     // host <-> device staging (host_pipeline.hpp): pinned double buffer + copy threads, created on first large transfer
     plsh::Stager stager;
-    int copy_threads = 0;  // 0 = default (PLS_HIP_COPY_THREADS or min(8, cores))
+    int copy_threads = 0;  // 0 = default (PLS_HIP_COPY_THREADS or min(16, cores/2))
+    hipStream_t copy_stream = nullptr;  // transfers that run beside kernels of `stream` (upload_accumulate)
+    // X^T X (K x K) and X^T Y (K x M) of THIS member's rows, already formed while the rows were uploaded
+    // (upload_accumulate): a fit that may use the Gram plan takes them instead of two passes over X
+    const double *pre_xx = nullptr, *pre_xy = nullptr;
 };
 
 namespace {
@@ -455,7 +460,10 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // model (measured rates on MI355X: ~6 TB/s streaming reads, ~60 TFLOP/s executed in the fp64 SYRK of
     // which the symmetric half is computed).  GRAM pays off for A >~ K/50.
     i64 algo = c->opt_algo;
-    if (algo == PLS_HIP_ALGO_AUTO) {
+    const bool have_pre = c->pre_xx && c->pre_xy && K <= 16384;
+    if (algo == PLS_HIP_ALGO_AUTO && have_pre) {
+        algo = PLS_HIP_ALGO_GRAM;  // X^T X is already there: the component loop needs no pass over X at all
+    } else if (algo == PLS_HIP_ALGO_AUTO) {
         const double pass_s = (double)N * K * sizeof(T) / 6.0e12;
         const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
         const double syrk_s = 2.0 * N * (double)K * K * (nbk + 1) / (2.0 * nbk) / 60.0e12;
@@ -528,7 +536,12 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     T *work = (T *)c->work.p;
 
     // prologue: XY = X^T Y (src/pls.cpp:396), summed over ranks
-    if (N > 0) {
+    const bool use_pre = have_pre && (gram || method == PLS_HIP_KERNEL_TYPE2);
+    if (use_pre) {
+        hipLaunchKernelGGL(plsk::fill_slices_kernel, dim3((unsigned)((L0 + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
+                           c->stream, c->pre_xy, (int)L0, red);
+        LAUNCH_CHECK(c);
+    } else if (N > 0) {
         int nb = 0;
         CHK(launch_xty<T>(c, X, ldx, Y, ldy, N, K, M, part, &nb));
         CHK(launch_reduce(c, part, nb, (int)L0, nullptr, 0, red));
@@ -545,7 +558,19 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         CHK(ensure(c, c->xx, (size_t)K * K * 8));
         CHK(ensure(c, c->praw, (size_t)K * 8));
         double *XX = (double *)c->xx.p, *praw = (double *)c->praw.p;
-        CHK(compute_xx<T>(c, X, ldx, N, K, XX));
+        if (use_pre) {  // this member's X^T X came with the upload: present it as slice 0, sum over the members
+            const i64 KK = (i64)K * K;
+            CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * KK * 8));
+            hipLaunchKernelGGL(plsk::fill_slices_kernel, dim3((unsigned)((KK + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
+                               c->stream, c->pre_xx, (int)KK, (double *)c->red2.p);
+            LAUNCH_CHECK(c);
+            CHK(do_allreduce(c, (double *)c->red2.p, (i64)plsk::RED_SLICES * KK));
+            hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((unsigned)((KK + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
+                               c->stream, (const double *)c->red2.p, (int)KK, XX);
+            LAUNCH_CHECK(c);
+        } else {
+            CHK(compute_xx<T>(c, X, ldx, N, K, XX));
+        }
         for (int a = 0; a < A; ++a) {
             {
                 Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * K + 2 * K) * 8);
@@ -752,7 +777,7 @@ constexpr size_t PIPELINE_MIN_BYTES = (size_t)4 << 20;
 int h2d(pls_hip_context *c, void *dst, i64 ldd, const void *src, i64 lds, i64 rows, i64 cols, size_t es) {
     if (rows == 0 || cols == 0) return PLS_HIP_OK;
     if ((size_t)rows * (size_t)cols * es >= PIPELINE_MIN_BYTES) {
-        HIPCHK(c, c->stager.ensure(c->copy_threads > 0 ? c->copy_threads : plsh::default_copy_threads()));
+        HIPCHK(c, c->stager.ensure(c->copy_threads > 0 ? c->copy_threads : plsh::default_copy_threads(), c->device));
         HIPCHK(c, plsh::upload(c->stager, c->stream, dst, ldd, src, lds, rows, cols, es));
         return PLS_HIP_OK;
     }
@@ -763,12 +788,77 @@ int h2d(pls_hip_context *c, void *dst, i64 ldd, const void *src, i64 lds, i64 ro
 int d2h(pls_hip_context *c, void *dst, i64 ldd, const void *src, i64 lds, i64 rows, i64 cols, size_t es) {
     if (rows == 0 || cols == 0) return PLS_HIP_OK;
     if ((size_t)rows * (size_t)cols * es >= PIPELINE_MIN_BYTES) {
-        HIPCHK(c, c->stager.ensure(c->copy_threads > 0 ? c->copy_threads : plsh::default_copy_threads()));
+        HIPCHK(c, c->stager.ensure(c->copy_threads > 0 ? c->copy_threads : plsh::default_copy_threads(), c->device));
         HIPCHK(c, plsh::download(c->stager, c->stream, dst, ldd, src, lds, rows, cols, es));
         return PLS_HIP_OK;
     }
     HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)ldd * es, src, (size_t)lds * es, (size_t)rows * es,
                                (size_t)cols, hipMemcpyDeviceToHost, c->stream));
+    return PLS_HIP_OK;
+}
+
+// Upload of X (host, rows x K) in ROW blocks with X^T X and X^T Y accumulated block by block on the compute stream
+// while the DMA engine already moves the next block: the matrix-core SYRK of a block (2 rb K^2 flops) takes a
+// fraction of the block's PCIe time (K * 2e-4 of it), so by the time the last rows have arrived the Gram matrix of
+// the whole shard is complete and a Gram-plan fit needs no further pass over X for its component loop.
+// dY: the member's rows of Y, already on the device.  *ok = false: the layout does not allow it (plain upload done).
+template <typename T>
+int upload_accumulate(pls_hip_context *c, T *dX, i64 ldd, const T *hX, i64 ldx, i64 N, int K, const T *dY, i64 ldy,
+                      int M, double *XXacc, double *XYacc, bool *ok) {
+    constexpr int FV = 16 / sizeof(T);
+    const size_t es = sizeof(T);
+    *ok = false;
+    const i64 KK = (i64)K * K, L0 = (i64)K * M;
+    i64 rb = (i64)(plsh::STAGE_BYTES / ((size_t)K * es)) & ~(i64)63;
+    const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
+    const i64 S = std::max<i64>(1, (2 * (i64)c->num_cu) / (nbk * (nbk + 1) / 2));
+    if (N < 1 || K > 4096 || M > plsk::MMAX || rb < 64 || !vec_ok<T>(dX, ldd, FV) || !vec_ok<T>(dY, ldy, FV) ||
+        ensure(c, c->red2, (size_t)plsk::RED_SLICES * KK * 8) != PLS_HIP_OK ||
+        ensure(c, c->part, std::max<size_t>((size_t)S * KK, (size_t)max_partial_rows(c, rb, K) * L0) * 8) != PLS_HIP_OK ||
+        ensure(c, c->red, (size_t)plsk::RED_SLICES * std::max<i64>(L0, K + 1) * 8) != PLS_HIP_OK) {
+        c->err.clear();
+        return h2d(c, dX, ldd, hX, ldx, N, K, es);
+    }
+    HIPCHK(c, c->stager.ensure(c->copy_threads > 0 ? c->copy_threads : plsh::default_copy_threads(), c->device));
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->zeros.p) {
+        CHK(ensure(c, c->zeros, 256));
+        HIPCHK(c, hipMemsetAsync(c->zeros.p, 0, 256, c->stream));
+    }
+    HIPCHK(c, hipMemsetAsync(XXacc, 0, (size_t)KK * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(XYacc, 0, (size_t)L0 * 8, c->stream));
+    plsh::Stager &st = c->stager;
+    double *part = (double *)c->part.p, *red2 = (double *)c->red2.p, *red = (double *)c->red.p;
+    bool acc = true;
+    for (i64 r0 = 0; r0 < N; r0 += rb) {
+        const i64 rbn = std::min(rb, N - r0);
+        const int s = st.slot;
+        if (st.busy[s]) HIPCHK(c, hipEventSynchronize(st.ev[s]));
+        plsh::repack(*st.pool, (char *)st.buf[s], (char *)const_cast<T *>(hX), ldx, r0, 0, rbn, K, es, true);
+        HIPCHK(c, hipMemcpy2DAsync(dX + r0, (size_t)ldd * es, st.buf[s], (size_t)rbn * es, (size_t)rbn * es, (size_t)K,
+                                   hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipEventRecord(st.ev[s], c->copy_stream));
+        st.busy[s] = true;
+        st.slot ^= 1;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, st.ev[s], 0));  // kernels of this block (and of the fit) after its rows
+        if (!acc) continue;
+        int nb = 0;
+        if (plsk::launch_syrk<T>(c->stream, c->num_cu, dX + r0, ldd, rbn, K, part, S * KK, &nb, c->zeros.p) != 0) {
+            acc = false;  // ragged block the matrix-core kernel declines: the fit forms X^T X itself
+            continue;
+        }
+        LAUNCH_CHECK(c);
+        CHK(launch_reduce(c, part, nb, (int)KK, nullptr, 0, red2));
+        hipLaunchKernelGGL(plsk::accumulate_slices_kernel, dim3((unsigned)((KK + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
+                           c->stream, (const double *)red2, (int)KK, XXacc);
+        LAUNCH_CHECK(c);
+        CHK(launch_xty<T>(c, dX + r0, ldd, dY + r0, ldy, rbn, K, M, part, &nb));
+        CHK(launch_reduce(c, part, nb, (int)L0, nullptr, 0, red));
+        hipLaunchKernelGGL(plsk::accumulate_slices_kernel, dim3((unsigned)((L0 + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
+                           c->stream, (const double *)red, (int)L0, XYacc);
+        LAUNCH_CHECK(c);
+    }
+    *ok = acc;
     return PLS_HIP_OK;
 }
 
@@ -813,6 +903,7 @@ int pls_hip_destroy(pls_hip_handle h) {
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     h->stager.release();
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     delete h;
     return PLS_HIP_OK;
 }
@@ -1138,22 +1229,26 @@ int zscores_device(pls_hip_context *c, const T *X, i64 ldx, i64 N, i64 n_total, 
 template <typename T>
 int sse_device(pls_hip_context *c, const T *S, i64 lds, const T *Y, i64 ldy, i64 N, int A, int M,
                const double *Q, double *SSE) {
-    const int AM = A * M;
+    // ranges of component counts with at most 1024 running sums each (the sweep keeps them per wave in LDS)
+    const int step = std::max(1, 1024 / M);
     const int G = (int)std::min<i64>(std::max<i64>(1, (N + plsk::WG - 1) / plsk::WG), 4 * (i64)c->num_cu);
-    CHK(ensure(c, c->part, (size_t)G * AM * 8));
-    CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * AM * 8));
-    {
-        Scope s(c, PLS_HIP_FAM_XB, (i64)N * (A + M) * sizeof(T) + (i64)AM * 8);
-        hipLaunchKernelGGL((plsk::sse_components_kernel<T>), dim3(G), dim3(plsk::WG),
-                           (size_t)(plsk::WG / plsk::WAVE) * AM * 8, c->stream, S, lds, Y, ldy, N, A, M, Q,
-                           (double *)c->part.p);
+    for (int c_lo = 0; c_lo < A; c_lo += step) {
+        const int c_hi = std::min(A, c_lo + step), AM = (c_hi - c_lo) * M;
+        CHK(ensure(c, c->part, (size_t)G * AM * 8));
+        CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * AM * 8));
+        {
+            Scope s(c, PLS_HIP_FAM_XB, (i64)N * (c_hi + M) * sizeof(T) + (i64)AM * 8);
+            hipLaunchKernelGGL((plsk::sse_components_kernel<T>), dim3(G), dim3(plsk::WG),
+                               (size_t)(plsk::WG / plsk::WAVE) * AM * 8, c->stream, S, lds, Y, ldy, N, c_lo, c_hi, M, Q,
+                               (double *)c->part.p);
+            LAUNCH_CHECK(c);
+        }
+        CHK(launch_reduce(c, (const double *)c->part.p, G, AM, nullptr, 0, (double *)c->red2.p));
+        CHK(do_allreduce(c, (double *)c->red2.p, (i64)plsk::RED_SLICES * AM));
+        hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((AM + plsk::WG - 1) / plsk::WG), dim3(plsk::WG), 0, c->stream,
+                           (const double *)c->red2.p, AM, SSE + (i64)c_lo * M);
         LAUNCH_CHECK(c);
     }
-    CHK(launch_reduce(c, (const double *)c->part.p, G, AM, nullptr, 0, (double *)c->red2.p));
-    CHK(do_allreduce(c, (double *)c->red2.p, (i64)plsk::RED_SLICES * AM));
-    hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((AM + plsk::WG - 1) / plsk::WG), dim3(plsk::WG), 0, c->stream,
-                       (const double *)c->red2.p, AM, SSE);
-    LAUNCH_CHECK(c);
     return PLS_HIP_OK;
 }
 
@@ -1178,7 +1273,7 @@ int pls_hip_sse_by_components(pls_hip_handle h, const void *S, int64_t lds, cons
                               int64_t N, int64_t A, int64_t M, const double *Q, int dtype, double *SSE) {
     CHK(check_handle(h));
     if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
-    if (N < 1 || A < 1 || M < 1 || A * M > 1024 || !S || !Y || !Q || !SSE || lds < N || ldy < N)
+    if (N < 1 || A < 1 || M < 1 || M > 1024 || A > (1 << 20) || !S || !Y || !Q || !SSE || lds < N || ldy < N)
         return fail(h, PLS_HIP_ERR_INVALID, "bad sse arguments");
     CHK(set_device(h));
     if (dtype == PLS_HIP_F64)
@@ -1204,9 +1299,14 @@ int cv_folds_device(pls_hip_context *h, const T *dX, i64 dldx, const T *dY, i64 
     CHK(ensure(h, h->cvy, (size_t)nobs * M * 8));
     CHK(ensure(h, h->cvws, (size_t)num_folds * (size_t)L.total * 8));
     double *XX = (double *)h->xx.p, *XYd = (double *)h->xy.p;
-    // XX and XY of the whole matrix, once
-    CHK(compute_xx<T>(h, dX, dldx, N, Ki, XX));
-    {
+    // XX and XY of the whole matrix, once (or taken from the upload that already formed them)
+    if (h->pre_xx && h->pre_xy) {
+        HIPCHK(h, hipMemcpyAsync(XX, h->pre_xx, (size_t)K * K * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(XYd, h->pre_xy, (size_t)K * M * 8, hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        CHK(compute_xx<T>(h, dX, dldx, N, Ki, XX));
+    }
+    if (!(h->pre_xx && h->pre_xy)) {
         CHK(ensure(h, h->part, (size_t)max_partial_rows(h, N, Ki) * (size_t)(K * M) * 8));
         CHK(ensure(h, h->red, (size_t)plsk::RED_SLICES * std::max<i64>(K * M, K + 1) * 8));
         int nb = 0;
@@ -1285,7 +1385,7 @@ int pls_hip_model_sse(pls_hip_handle h, const void *X, int64_t ldx, const void *
     if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
     if (mem != PLS_HIP_MEM_HOST && mem != PLS_HIP_MEM_DEVICE) return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
     const bool empty_member = (N == 0 && h->nranks > 1);  // an empty shard still takes part in the reduction
-    if (N < 0 || (N == 0 && !empty_member) || K < 1 || M < 1 || A < 1 || A * M > 1024 || K > (1 << 30) ||
+    if (N < 0 || (N == 0 && !empty_member) || K < 1 || M < 1 || A < 1 || M > 1024 || A > (1 << 20) || K > (1 << 30) ||
         (N > 0 && (!X || !Y)) || !R || !Q || !SSE || ldx < std::max<i64>(N, 1) || ldy < std::max<i64>(N, 1))
         return fail(h, PLS_HIP_ERR_INVALID, "bad model_sse arguments");
     CHK(set_device(h));

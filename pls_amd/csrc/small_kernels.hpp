@@ -662,6 +662,23 @@ __global__ __launch_bounds__(WG) void sum_slices_kernel(const double *__restrict
     if (j < L) out[j] = red_sum(red, L, j);
 }
 
+// out[j] += sum of the RED_SLICES slices (X^T X / X^T Y accumulated row block by row block while X streams in)
+__global__ __launch_bounds__(WG) void accumulate_slices_kernel(const double *__restrict__ red, int L,
+                                                               double *__restrict__ out) {
+    const int j = blockIdx.x * WG + threadIdx.x;
+    if (j < L) out[j] += red_sum(red, L, j);
+}
+
+// red slice 0 = src, the other slices zero: a locally finished sum presented in the sliced layout the reducer and
+// the K-sized kernels expect
+__global__ __launch_bounds__(WG) void fill_slices_kernel(const double *__restrict__ src, int L, double *__restrict__ red) {
+    const int j = blockIdx.x * WG + threadIdx.x;
+    if (j >= L) return;
+    red[j] = src[j];
+#pragma unroll
+    for (int i = 1; i < RED_SLICES; ++i) red[(i64)i * L + j] = 0.0;
+}
+
 // B[k + m*K] = sum_{j<c} R[k + j*K] * Q[m + j*M]     Model::coefficients, src/pls.cpp:444-447
 __global__ __launch_bounds__(WG) void coefficients_kernel(const double *__restrict__ R,
                                                           const double *__restrict__ Q, int K,

@@ -543,11 +543,13 @@ __global__ __launch_bounds__(WG) void zscale_kernel(const T *X, i64 ldx, T *Z, i
 template <typename T>
 __global__ __launch_bounds__(WG) void sse_components_kernel(const T *__restrict__ S, i64 lds_,
                                                             const T *__restrict__ Y, i64 ldy, i64 N,
-                                                            int A, int M, const double *__restrict__ Q,
+                                                            int c_lo, int c_hi, int M, const double *__restrict__ Q,
                                                             double *__restrict__ part) {
-    extern __shared__ double acc[];  // [WG/WAVE][A*M] per-wave running sums (no barrier in the sweep)
+    // component counts c_lo+1 .. c_hi of the model (the fitted values of the first c_lo components are rebuilt
+    // without being recorded, so that a long component list can be covered in ranges of (c_hi - c_lo)*M <= 1024 sums)
+    extern __shared__ double acc[];  // [WG/WAVE][(c_hi - c_lo)*M] per-wave running sums (no barrier in the sweep)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int AM = A * M;
+    const int AM = (c_hi - c_lo) * M;
     double *mine = acc + (i64)wv * AM;
     for (int j = lane; j < AM; j += WAVE) mine[j] = 0.0;
     for (i64 i0 = (i64)blockIdx.x * WG; i0 < N; i0 += (i64)gridDim.x * WG) {
@@ -555,12 +557,13 @@ __global__ __launch_bounds__(WG) void sse_components_kernel(const T *__restrict_
         for (int m = 0; m < M; ++m) {
             const double y = (i < N) ? (double)Y[i + (i64)m * ldy] : 0.0;
             double yhat = 0.0;
-            for (int c = 0; c < A; ++c) {
+            for (int c = 0; c < c_hi; ++c) {
                 const double s = (i < N) ? (double)S[i + (i64)c * lds_] : 0.0;
                 yhat = fma(s, Q[m + (i64)c * M], yhat);
+                if (c < c_lo) continue;
                 const double e = y - yhat;
                 const double tot = wave_sum(e * e);
-                if (lane == 0) mine[m + c * M] += tot;
+                if (lane == 0) mine[m + (c - c_lo) * M] += tot;
             }
         }
     }

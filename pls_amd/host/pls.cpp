@@ -22,34 +22,107 @@ namespace {
 
 typedef Eigen::Index Index;
 
-// One device context per process, created on first use; the library keeps its workspace in
-// it, so the O(N) refits of the cross-validation drivers reuse the same device buffers.
-std::mutex g_mu;
-pls_hip_handle g_handle = nullptr;
+// One device context per process, created on first use: a pls_hip_group (include/pls_hip.h) over the GPUs that
+// PLS_HIP_DEVICES names -- "4" = devices 0..3, "0,2,5" = that list (an ordinal may repeat: virtual shards on one
+// GPU); default: the single device PLS_HIP_DEVICE (or 0).  The rows of every matrix are spread over the members,
+// one host thread per member inside the library; the library keeps its workspace in the member handles, so
+// repeated fits reuse the same device buffers.
+std::recursive_mutex g_mu;  // recursive: resident temporaries are released while a caller still holds it
+pls_hip_group g_group = nullptr;
 
-pls_hip_handle device() {
-    if (!g_handle) {
-        int dev = 0;
-        if (const char *e = std::getenv("PLS_HIP_DEVICE")) dev = std::atoi(e);
-        const int rc = pls_hip_create(&g_handle, dev, nullptr);
-        if (rc != PLS_HIP_OK)
-            throw std::runtime_error("PLS: no usable MI355X (gfx950) device (pls_hip_create status " +
-                                     std::to_string(rc) + "); this library has no CPU path");
-        if (const char *e = std::getenv("PLS_HIP_ALGO")) {  // kernel (default) | nipals | gram | auto
-            const std::string a(e);
-            pls_hip_set_option(g_handle, PLS_HIP_OPT_ALGO,
-                               a == "nipals" ? PLS_HIP_ALGO_NIPALS
-                               : a == "gram" ? PLS_HIP_ALGO_GRAM
-                               : a == "auto" ? PLS_HIP_ALGO_AUTO
-                                             : PLS_HIP_ALGO_KERNEL);
+std::vector<int> device_list() {
+    std::vector<int> devs;
+    if (const char *e = std::getenv("PLS_HIP_DEVICES")) {
+        const std::string spec(e);
+        if (spec.find(',') == std::string::npos) {
+            const int n = std::atoi(spec.c_str());
+            for (int i = 0; i < n; ++i) devs.push_back(i);
+        } else {
+            size_t start = 0;
+            while (start <= spec.size()) {
+                const size_t pos = spec.find(',', start);
+                const std::string tok = spec.substr(start, pos == std::string::npos ? std::string::npos : pos - start);
+                if (!tok.empty()) devs.push_back(std::atoi(tok.c_str()));
+                if (pos == std::string::npos) break;
+                start = pos + 1;
+            }
         }
     }
-    return g_handle;
+    if (devs.empty()) {
+        const char *e = std::getenv("PLS_HIP_DEVICE");
+        devs.push_back(e ? std::atoi(e) : 0);
+    }
+    return devs;
+}
+
+pls_hip_group group() {
+    if (!g_group) {
+        const std::vector<int> devs = device_list();
+        const int rc = pls_hip_group_create(&g_group, static_cast<int>(devs.size()), devs.data());
+        if (rc != PLS_HIP_OK)
+            throw std::runtime_error("PLS: no usable MI355X (gfx950) device (pls_hip_group_create status " +
+                                     std::to_string(rc) + "); this library has no CPU path");
+        // PLS_HIP_ALGO = auto (default) | kernel | nipals | gram.  auto: the Gram plan whenever X^T X came with the
+        // upload (it is accumulated on the matrix cores while the rows cross PCIe) or the cost model favours it, the
+        // reference's own operation sequence (kernel) otherwise; same results to rounding either way.
+        const char *e = std::getenv("PLS_HIP_ALGO");
+        const std::string a(e ? e : "auto");
+        pls_hip_group_set_option(g_group, PLS_HIP_OPT_ALGO,
+                                 a == "nipals" ? PLS_HIP_ALGO_NIPALS
+                                 : a == "gram" ? PLS_HIP_ALGO_GRAM
+                                 : a == "kernel" ? PLS_HIP_ALGO_KERNEL
+                                                 : PLS_HIP_ALGO_AUTO);
+    }
+    return g_group;
+}
+
+pls_hip_handle device() {  // member 0's handle: the K-sized products that need no sharding
+    pls_hip_handle h = nullptr;
+    pls_hip_group_handle(group(), 0, &h);
+    return h;
 }
 
 void check(int rc, const char *what) {
-    if (rc != PLS_HIP_OK)
-        throw std::runtime_error(std::string("PLS: ") + what + " failed: " + pls_hip_last_error(g_handle));
+    if (rc != PLS_HIP_OK) {
+        std::string msg = g_group ? pls_hip_group_last_error(g_group) : "";
+        if (msg.empty() && g_group) msg = pls_hip_last_error(device());
+        throw std::runtime_error(std::string("PLS: ") + what + " failed: " + msg);
+    }
+}
+
+// a host matrix placed on the device(s); freed with the last owner
+struct ResidentMatrix {
+    pls_hip_matrix m = nullptr;
+    ResidentMatrix() {}
+    ResidentMatrix(const ResidentMatrix &) = delete;
+    ResidentMatrix &operator=(const ResidentMatrix &) = delete;
+    ~ResidentMatrix() {
+        if (m && g_group) {
+            std::lock_guard<std::recursive_mutex> lock(g_mu);
+            pls_hip_group_free(g_group, m);
+        }
+    }
+    void upload(const Mat2D &src) {  // caller holds g_mu
+        check(pls_hip_group_upload(group(), src.data(), src.rows(), src.rows(), src.cols(), PLS_HIP_F64, &m),
+              "pls_hip_group_upload");
+    }
+    void alloc(Index rows, Index cols) {
+        check(pls_hip_group_alloc(group(), rows, cols, PLS_HIP_F64, &m), "pls_hip_group_alloc");
+    }
+    Mat2D download(Index col0, Index ncols) const {
+        int64_t N = 0, K = 0;
+        pls_hip_matrix_shape(m, &N, &K, nullptr);
+        Mat2D out(static_cast<Index>(N), ncols);
+        check(pls_hip_group_download(group(), m, col0, ncols, out.data(), N), "pls_hip_group_download");
+        return out;
+    }
+};
+
+// X and Y of one data set: X^T X and X^T Y are formed while X streams in and stay with the pair (pls_hip.h)
+void upload_pair(const Mat2D &X, const Mat2D &Y, ResidentMatrix &dX, ResidentMatrix &dY) {
+    check(pls_hip_group_upload_xy(group(), X.data(), X.rows(), Y.data(), Y.rows(), X.rows(), X.cols(), Y.cols(),
+                                  PLS_HIP_F64, &dX.m, &dY.m),
+          "pls_hip_group_upload_xy");
 }
 
 Row column_means(const Mat2D &mat) {
@@ -79,6 +152,12 @@ std::vector<float_type> real_part(const Mat2Dc &m, Index cols) {
 }
 
 }  // namespace
+
+// what a Model keeps on the device(s): the training data of its constructor, or the scores of its last fit
+struct PLS::Model::Resident {
+    ResidentMatrix X, Y, T;
+    Index N = 0, K = 0, M = 0;
+};
 
 namespace PLS {
 
@@ -289,17 +368,26 @@ Model::Model(const size_t &num_predictors, const size_t &num_responses, const ME
 Model::Model(const size_t &num_predictors, const size_t &num_responses, const METHOD &algorithm)
     : Model(num_predictors, num_responses, algorithm, num_predictors) {}
 
+// The reference deep-copies X and Y into host members (ref :344).  Here the one copy that is made anyway -- the
+// transfer to the device(s) -- IS the model's copy: the caller may destroy X and Y afterwards, exactly as upstream.
 Model::Model(const Mat2D &X, const Mat2D &Y, const METHOD &algorithm, const size_t &max_components)
-    : _X(X), _Y(Y), A(max_components), method(algorithm) {
+    : A(max_components), method(algorithm) {
     // the reference only assert()s these (ref :345-347); a Release build would run into UB
-    if (max_components > static_cast<size_t>(_X.cols()) || _X.rows() == 0 || _X.rows() != _Y.rows())
+    if (max_components > static_cast<size_t>(X.cols()) || X.rows() == 0 || X.rows() != Y.rows())
         throw std::invalid_argument("PLS::Model: need max_components <= X.cols(), X.rows() > 0, X.rows() == Y.rows()");
-    const Index K = _X.cols(), M = _Y.cols();
+    const Index K = X.cols(), M = Y.cols();
     P.setZero(K, static_cast<Index>(A));
     W.setZero(K, static_cast<Index>(A));
     R.setZero(K, static_cast<Index>(A));
     Q.setZero(M, static_cast<Index>(A));
-    plsr(_X, _Y, algorithm);
+    std::shared_ptr<Resident> d = std::make_shared<Resident>();
+    d->N = X.rows(); d->K = K; d->M = M;
+    {
+        std::lock_guard<std::recursive_mutex> lock(g_mu);
+        upload_pair(X, Y, d->X, d->Y);
+    }
+    _data = d;
+    fit_resident(*d, algorithm);
 }
 
 Model::Model(const Mat2D &X, const Mat2D &Y, const METHOD &algorithm)
@@ -309,39 +397,72 @@ Model::Model(const Mat2D &X, const Mat2D &Y, const METHOD &algorithm)
 // the fit (ref :390-437): one call into the device library
 // ---------------------------------------------------------------------------------------------
 void Model::plsr(const Mat2D &X, const Mat2D &Y, const METHOD &algorithm) {
-    method = algorithm;
-    const Index N = X.rows(), K = X.cols(), M = Y.cols();
-    const Index Ai = static_cast<Index>(A);
-    std::vector<float_type> w(static_cast<size_t>(K * Ai)), p(w.size()), r(w.size());
-    std::vector<float_type> q(static_cast<size_t>(M * Ai)), t(static_cast<size_t>(N * Ai));
+    if (X.rows() == 0 || X.rows() != Y.rows() || static_cast<size_t>(X.cols()) < A)
+        throw std::invalid_argument("PLS::Model::plsr: need X.rows() > 0, X.rows() == Y.rows(), X.cols() >= A");
+    Resident d;  // data of this call only: the constructor's X, Y stay what the cross-validation methods use (ref :487)
+    d.N = X.rows(); d.K = X.cols(); d.M = Y.cols();
     {
-        std::lock_guard<std::mutex> lock(g_mu);
-        check(pls_hip_fit(device(), X.data(), N, Y.data(), N, N, K, M, Ai,
-                          algorithm == KERNEL_TYPE1 ? PLS_HIP_KERNEL_TYPE1 : PLS_HIP_KERNEL_TYPE2, PLS_HIP_F64,
-                          PLS_HIP_MEM_HOST, w.data(), p.data(), q.data(), r.data(), t.data(), N, nullptr),
-              "pls_hip_fit");
+        std::lock_guard<std::recursive_mutex> lock(g_mu);
+        upload_pair(X, Y, d.X, d.Y);
     }
+    fit_resident(d, algorithm);
+}
+
+void Model::fit_resident(const Resident &d, const METHOD &algorithm) {
+    method = algorithm;
+    const Index K = d.K, M = d.M, Ai = static_cast<Index>(A);
+    std::vector<float_type> w(static_cast<size_t>(K * Ai)), p(w.size()), r(w.size());
+    std::vector<float_type> q(static_cast<size_t>(M * Ai));
+    std::shared_ptr<Resident> sc;
+    {
+        std::lock_guard<std::recursive_mutex> lock(g_mu);
+        if (algorithm == KERNEL_TYPE1) {  // T exists for KERNEL_TYPE1 only (ref :394,434); it stays on the device(s)
+            sc = std::make_shared<Resident>();
+            sc->N = d.N; sc->K = Ai;
+            sc->T.alloc(d.N, Ai);
+        }
+        check(pls_hip_group_fit(group(), d.X.m, d.Y.m, Ai,
+                                algorithm == KERNEL_TYPE1 ? PLS_HIP_KERNEL_TYPE1 : PLS_HIP_KERNEL_TYPE2, w.data(), p.data(),
+                                q.data(), r.data(), sc ? sc->T.m : nullptr, nullptr),
+              "pls_hip_group_fit");
+    }
+    _scores = sc;
     W = to_complex(w, K, Ai);
     P = to_complex(p, K, Ai);
     R = to_complex(r, K, Ai);
     Q = to_complex(q, M, Ai);
-    if (algorithm == KERNEL_TYPE1) T = to_complex(t, N, Ai);  // T exists for KERNEL_TYPE1 only (ref :394,434)
 }
 
 // ---------------------------------------------------------------------------------------------
 // predict and metrics (ref :439-467)
 // ---------------------------------------------------------------------------------------------
+namespace {
+
+// X_new (host) * Bm (K x C, host) -> N x C on the host: X_new goes to the device(s) through the staging pipeline,
+// the product runs row-sharded, the result comes back
+Mat2D product_on_device(const Mat2D &X_new, const std::vector<float_type> &bm, Index C) {
+    const Index N = X_new.rows(), K = X_new.cols();
+    Mat2D out(N, C);
+    if (N == 0 || C == 0) return out;
+    std::lock_guard<std::recursive_mutex> lock(g_mu);
+    ResidentMatrix X, O;
+    X.upload(X_new);
+    O.alloc(N, C);
+    check(pls_hip_group_xb(group(), X.m, bm.data(), K, C, O.m), "pls_hip_group_xb");
+    check(pls_hip_group_download(group(), O.m, 0, C, out.data(), N), "pls_hip_group_download");
+    return out;
+}
+
+}  // namespace
+
 const Mat2Dc Model::scores(const Mat2D &X_new, const size_t comp) const {
     if (comp > A) throw std::invalid_argument("PLS::Model::scores: comp > A");  // assert in the reference (ref :440)
-    const Index N = X_new.rows(), K = X_new.cols(), c = static_cast<Index>(comp);
-    const std::vector<float_type> r = real_part(R, c);
-    std::vector<float_type> out(static_cast<size_t>(N * c));
-    if (N > 0 && c > 0) {
-        std::lock_guard<std::mutex> lock(g_mu);
-        check(pls_hip_xb(device(), X_new.data(), N, N, K, r.data(), K, c, PLS_HIP_F64, PLS_HIP_MEM_HOST, out.data(), N),
-              "pls_hip_xb");
-    }
-    return to_complex(out, N, c);
+    const Index N = X_new.rows(), c = static_cast<Index>(comp);
+    const Mat2D s = product_on_device(X_new, real_part(R, c), c);
+    Mat2Dc out(N, c);
+    for (Index j = 0; j < c; ++j)
+        for (Index i = 0; i < N; ++i) out(i, j) = std::complex<float_type>(s(i, j), 0);
+    return out;
 }
 
 const Mat2Dc Model::loadingsX(const size_t comp) const { return P.leftCols(static_cast<Index>(comp)); }
@@ -353,25 +474,17 @@ const Mat2Dc Model::coefficients(const size_t comp) const {
     const std::vector<float_type> r = real_part(R, Ai), q = real_part(Q, Ai);
     std::vector<float_type> b(static_cast<size_t>(K * M));
     {
-        std::lock_guard<std::mutex> lock(g_mu);
-        check(pls_hip_coefficients(device(), r.data(), q.data(), K, M, Ai, static_cast<Index>(comp), PLS_HIP_MEM_HOST,
-                                   b.data()),
-              "pls_hip_coefficients");
+        std::lock_guard<std::recursive_mutex> lock(g_mu);
+        if (pls_hip_coefficients(device(), r.data(), q.data(), K, M, Ai, static_cast<Index>(comp), PLS_HIP_MEM_HOST,
+                                 b.data()) != PLS_HIP_OK)
+            throw std::runtime_error(std::string("PLS: pls_hip_coefficients failed: ") + pls_hip_last_error(device()));
     }
     return to_complex(b, K, M);
 }
 
 const Mat2D Model::fitted_values(const Mat2D &X_new, const size_t comp) const {
     const Mat2Dc Bc = coefficients(comp);
-    const Index N = X_new.rows(), K = X_new.cols(), M = Bc.cols();
-    const std::vector<float_type> b = real_part(Bc, M);
-    Mat2D out(N, M);
-    if (N > 0) {
-        std::lock_guard<std::mutex> lock(g_mu);
-        check(pls_hip_xb(device(), X_new.data(), N, N, K, b.data(), K, M, PLS_HIP_F64, PLS_HIP_MEM_HOST, out.data(), N),
-              "pls_hip_xb");
-    }
-    return out;
+    return product_on_device(X_new, real_part(Bc, Bc.cols()), Bc.cols());
 }
 
 const Mat2D Model::residuals(const Mat2D &X_new, const Mat2D &Y_new, const size_t comp) const {
@@ -404,6 +517,8 @@ const Row Model::explained_variance(const Mat2D &X_new, const Mat2D &Y_new, cons
 // handed to the device together (pls_hip_cv_folds): XX = X^T X and XY = X^T Y are formed once, every
 // fold works on their downdates by its held-out rows, and the residuals come back in the layout of
 // Residual::errors().  Same numbers up to fp64 rounding (tests compare with one refit per fold).
+// The folds read the model's RESIDENT training data; with several devices the fold kernel still needs the
+// whole matrix on one of them, so the data is gathered to the host once and handed to member 0.
 //
 // Deliberate difference kept from the first version: the reference builds its inner models with
 // A = X.cols() components (the 3-argument constructors, ref :334-337, :356-359, used at :477 and :531)
@@ -413,17 +528,26 @@ const Row Model::explained_variance(const Mat2D &X_new, const Mat2D &Y_new, cons
 namespace {
 
 // residuals of `folds` (each `test_size` held-out rows, row-major index list) -> M matrices nobs x A
-std::vector<Mat2D> run_folds(const Mat2D &X, const Mat2D &Y, size_t A, const std::vector<int64_t> &test_idx,
-                             size_t test_size, size_t num_folds) {
-    const Index N = X.rows(), K = X.cols(), M = Y.cols();
+std::vector<Mat2D> run_folds(const ResidentMatrix &X, const ResidentMatrix &Y, Index N, Index K, Index M, size_t A,
+                             const std::vector<int64_t> &test_idx, size_t test_size, size_t num_folds) {
     const Index nobs = static_cast<Index>(num_folds * test_size), Ai = static_cast<Index>(A);
     std::vector<float_type> e(static_cast<size_t>(nobs * Ai * M));
     {
-        std::lock_guard<std::mutex> lock(g_mu);
-        check(pls_hip_cv_folds(device(), X.data(), N, Y.data(), N, N, K, M, Ai, test_idx.data(),
-                               static_cast<int64_t>(test_size), static_cast<int64_t>(num_folds), PLS_HIP_F64,
-                               PLS_HIP_MEM_HOST, e.data()),
-              "pls_hip_cv_folds");
+        std::lock_guard<std::recursive_mutex> lock(g_mu);
+        if (pls_hip_group_size(group()) == 1) {
+            check(pls_hip_group_cv_folds(group(), X.m, Y.m, Ai, test_idx.data(), static_cast<int64_t>(test_size),
+                                         static_cast<int64_t>(num_folds), e.data()),
+                  "pls_hip_group_cv_folds");
+        } else {  // several devices: gather the rows once, member 0 runs the folds
+            const Mat2D Xh = X.download(0, K), Yh = Y.download(0, M);
+            static pls_hip_handle plain = nullptr;  // a member handle carries the group's reducer; folds need none
+            if (!plain && pls_hip_create(&plain, device_list()[0], nullptr) != PLS_HIP_OK)
+                throw std::runtime_error("PLS: pls_hip_create failed for the cross-validation handle");
+            if (pls_hip_cv_folds(plain, Xh.data(), N, Yh.data(), N, N, K, M, Ai, test_idx.data(),
+                                 static_cast<int64_t>(test_size), static_cast<int64_t>(num_folds), PLS_HIP_F64,
+                                 PLS_HIP_MEM_HOST, e.data()) != PLS_HIP_OK)
+                throw std::runtime_error(std::string("PLS: pls_hip_cv_folds failed: ") + pls_hip_last_error(plain));
+        }
     }
     std::vector<Mat2D> Ev(static_cast<size_t>(M), Mat2D::Zero(nobs, Ai));
     for (Index m = 0; m < M; ++m)
@@ -436,15 +560,16 @@ std::vector<Mat2D> run_folds(const Mat2D &X, const Mat2D &Y, size_t A, const std
 }  // namespace
 
 Residual Model::cv_LOO() const {
-    const size_t N = static_cast<size_t>(_X.rows());
+    if (!_data) throw std::invalid_argument("PLS::Model::cv_LOO: the model holds no training data");
+    const size_t N = static_cast<size_t>(_data->N);
     if (N < 2) throw std::invalid_argument("PLS::Model::cv_LOO: need at least two observations");
     std::vector<int64_t> idx(N);
     std::iota(idx.begin(), idx.end(), int64_t(0));  // fold i leaves out row i (ref :478-488)
-    return Residual(run_folds(_X, _Y, A, idx, 1, N), "LOO");
+    return Residual(run_folds(_data->X, _data->Y, _data->N, _data->K, _data->M, A, idx, 1, N), "LOO");
 }
 
 Residual Model::cv_NEW_DATA(const Mat2D &X_new, const Mat2D &Y_new) const {
-    if (X_new.cols() != _X.cols() || Y_new.cols() != _Y.cols())
+    if (X_new.cols() != R.rows() || Y_new.cols() != Q.rows())
         throw std::invalid_argument("PLS::Model::cv_NEW_DATA: column counts differ from the training data");
     std::vector<Mat2D> Ev(static_cast<size_t>(Y_new.cols()), Mat2D::Zero(X_new.rows(), static_cast<Index>(A)));
     for (size_t nc = 1; nc <= A; ++nc) {
@@ -456,7 +581,8 @@ Residual Model::cv_NEW_DATA(const Mat2D &X_new, const Mat2D &Y_new) const {
 }
 
 Residual Model::cv_LSO(const float_type test_fraction, const size_t num_trials, std::mt19937 &rng) const {
-    const size_t N = static_cast<size_t>(_X.rows());
+    if (!_data) throw std::invalid_argument("PLS::Model::cv_LSO: the model holds no training data");
+    const size_t N = static_cast<size_t>(_data->N);
     const size_t test_size = static_cast<size_t>(test_fraction * N + 0.5);
     const size_t train_size = N - test_size;
     if (test_size == 0 || train_size == 0) throw std::invalid_argument("PLS::Model::cv_LSO: empty train or test split");
@@ -470,7 +596,7 @@ Residual Model::cv_LSO(const float_type test_fraction, const size_t num_trials, 
         rand_nchoosek(rng, full, sample, complement);
         for (size_t i = 0; i < test_size; ++i) idx[rep * test_size + i] = static_cast<int64_t>(complement[i]);
     }
-    return Residual(run_folds(_X, _Y, A, idx, test_size, num_trials), "LSO");
+    return Residual(run_folds(_data->X, _data->Y, _data->N, _data->K, _data->M, A, idx, test_size, num_trials), "LSO");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -481,14 +607,15 @@ Residual Model::cv_LSO(const float_type test_fraction, const size_t num_trials, 
 // (pls_hip_model_sse): SSE_c follows from Yhat_c = S[:, :c] Q[:, :c]^T.
 void Model::print_explained_variance(const Mat2D &X, const Mat2D &Y, std::ostream &os) const {
     const int wd = static_cast<int>(std::ceil(std::log10(static_cast<double>(A))));
-    const Index N = X.rows(), K = X.cols(), M = Y.cols(), Ai = static_cast<Index>(A);
+    const Index M = Y.cols(), Ai = static_cast<Index>(A);
     const std::vector<float_type> r = real_part(R, Ai), q = real_part(Q, Ai);
     std::vector<float_type> sse(static_cast<size_t>(M * Ai));
     {
-        std::lock_guard<std::mutex> lock(g_mu);
-        check(pls_hip_model_sse(device(), X.data(), N, Y.data(), N, N, K, M, Ai, r.data(), q.data(), PLS_HIP_F64,
-                                PLS_HIP_MEM_HOST, sse.data()),
-              "pls_hip_model_sse");
+        std::lock_guard<std::recursive_mutex> lock(g_mu);
+        ResidentMatrix dX, dY;
+        dX.upload(X);
+        dY.upload(Y);
+        check(pls_hip_group_model_sse(group(), dX.m, dY.m, Ai, r.data(), q.data(), sse.data()), "pls_hip_group_model_sse");
     }
     const Row sst = SST(Y);
     for (size_t nc = 1; nc <= A; ++nc) {
@@ -507,6 +634,14 @@ void Model::print_state(std::ostream &os) const {
     os << "W:" << std::endl << W << std::endl;
     os << "R:" << std::endl << R << std::endl;
     os << "Q:" << std::endl << Q << std::endl;
+    Mat2Dc T;  // fetched from the device(s) only here; empty for KERNEL_TYPE2, as upstream (ref :394,434)
+    if (_scores) {
+        std::lock_guard<std::recursive_mutex> lock(g_mu);
+        const Mat2D t = _scores->T.download(0, static_cast<Index>(A));
+        T = Mat2Dc(t.rows(), t.cols());
+        for (Index j = 0; j < t.cols(); ++j)
+            for (Index i = 0; i < t.rows(); ++i) T(i, j) = std::complex<float_type>(t(i, j), 0);
+    }
     os << "T:" << std::endl << T << std::endl;
     os << "coefficients:" << std::endl << coefficients() << std::endl;
 }

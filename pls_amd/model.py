@@ -353,6 +353,17 @@ class Group:
                                                    a.shape[1], L.F64 if dtype == np.float64 else L.F32, ctypes.byref(m)))
         return m
 
+    def upload_xy(self, X, Y, dtype=np.float64):
+        """X and Y of one data set; X^T X and X^T Y are accumulated on the matrix cores while X streams in and kept
+        with the pair for fits under ALGO_AUTO / ALGO_GRAM / KERNEL_TYPE2"""
+        X = _np_f(X, dtype); Y = _np_f(Y, dtype)
+        mx, my = ctypes.c_void_p(), ctypes.c_void_p()
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self._check(self._lib.pls_hip_group_upload_xy(self.g, p(X), max(X.shape[0], 1), p(Y), max(Y.shape[0], 1), X.shape[0],
+                                                      X.shape[1], Y.shape[1], L.F64 if dtype == np.float64 else L.F32,
+                                                      ctypes.byref(mx), ctypes.byref(my)))
+        return mx, my
+
     def alloc(self, N: int, K: int, dtype=np.float64):
         m = ctypes.c_void_p()
         self._check(self._lib.pls_hip_group_alloc(self.g, N, K, L.F64 if dtype == np.float64 else L.F32, ctypes.byref(m)))

@@ -48,10 +48,17 @@ def _oracle_loo(oracle, X, Y, A):
     return E
 
 
+@pytest.mark.parametrize("devices", [None, "0,0,0"], ids=["one-device", "three-virtual-members"])
 @pytest.mark.parametrize("fx,fy,A", [("toyX.csv", "toyY.csv", 2), ("nir.csv", "octane.csv", 4)])
-def test_model_api(oracle, po, fx, fy, A):
+def test_model_api(oracle, po, fx, fy, A, devices):
+    """devices = "0,0,0": PLS_HIP_DEVICES spreads the rows of every matrix the Model touches over three members of a
+    pls_hip_group (virtual shards on the one GPU of the test box) -- same public API, same numbers."""
+    env = dict(os.environ)
+    env.pop("PLS_HIP_DEVICES", None)
+    if devices:
+        env["PLS_HIP_DEVICES"] = devices
     r = subprocess.run([API, os.path.join(DATA, fx), os.path.join(DATA, fy), str(A)], capture_output=True, text=True,
-                       timeout=600)
+                       timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _parse_dump(r.stdout)
     X = oracle.z_scores(po.read_csv(os.path.join(DATA, fx)))

@@ -131,3 +131,43 @@ def test_group_upload_download_large_and_strided(groups, oracle):
     assert np.array_equal(g.download(X), Xh)
     assert np.array_equal(g.download(X, 5, 3), Xh[:, 5:8])
     g.free(X)
+
+
+@pytest.mark.parametrize("n", [1, 3])
+@pytest.mark.parametrize("N,K,M,A,dt", [(70000, 96, 2, 8, "f64"), (40001, 200, 1, 6, "f64"), (9000, 1300, 3, 5, "f32"),
+                                        (10, 15, 2, 2, "f64"), (300000, 64, 1, 5, "f64")])
+def test_upload_xy_streamed_gram(groups, oracle, po, n, N, K, M, A, dt):
+    """pls_hip_group_upload_xy: X^T X and X^T Y are accumulated row block by row block on the matrix cores while the
+    blocks cross PCIe (several 32 MB blocks here, a ragged last one, an odd row count, fp32 storage, empty members) and a
+    fit under ALGO_AUTO runs its component loop from them -- same B as the oracle, T = X R, and the same answer as the
+    plain upload + KERNEL plan.  Leave-one-out folds take the products from the pair as well."""
+    import pls_amd
+    g = groups(n)
+    dtype = np.float64 if dt == "f64" else np.float32
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    if dt == "f32":
+        Xh = np.asfortranarray(Xh.astype(np.float32).astype(np.float64)); Yh = np.asfortranarray(Yh.astype(np.float32).astype(np.float64))
+    ref = oracle.plsr(Xh, Yh, A)
+    Bref = oracle.coefficients(ref["R"], ref["Q"])
+    tol = 1e-10 if dt == "f64" else 2e-5
+    g.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_AUTO)
+    try:
+        X, Y = g.upload_xy(Xh, Yh, dtype)
+        assert np.array_equal(g.download(X).astype(np.float64), Xh) and np.array_equal(g.download(Y).astype(np.float64), Yh)
+        out = g.fit(X, Y, A)
+        assert po.rel_fro(out["B"], Bref) < tol
+        T = g.download(out["T"]).astype(np.float64)
+        assert po.rel_fro(T, Xh @ out["R"]) < (1e-11 if dt == "f64" else 1e-6)
+        o2 = g.fit(X, Y, A, method=pls_amd.KERNEL_TYPE2)          # METHOD::KERNEL_TYPE2 from the same products
+        assert po.rel_fro(o2["B"], Bref) < tol
+        g.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_KERNEL)       # an explicit plan ignores them
+        o3 = g.fit(X, Y, A)
+        assert po.rel_fro(o3["B"], out["B"]) < tol
+        if n == 1 and N <= 100:
+            E = g.cv_folds(X, Y, A, np.arange(N)[:, None])
+            c = oracle.plsr(Xh[1:], Yh[1:], A)
+            assert np.abs(E[:, 0, A - 1] - (Yh[0] - Xh[0] @ oracle.coefficients(c["R"], c["Q"]))).max() < 1e-8
+        for m in (X, Y, out["T"], o3["T"]):
+            g.free(m)
+    finally:
+        g.set_option(pls_amd.OPT_ALGO, 0)

@@ -419,7 +419,8 @@ def test_random_shapes_all_plans(handle, oracle, po, mode, N, K, M, A):
     check_against(po, out, ref, Bref, Tref=ref["T"], col_err=cerr, tol_b=TOL_B, tol_inv=1e-6)
 
 
-@pytest.mark.parametrize("N,K,M,A", [(10, 15, 2, 2), (60, 401, 1, 10), (5000, 40, 3, 7), (1 << 18, 64, 2, 20)])
+@pytest.mark.parametrize("N,K,M,A", [(10, 15, 2, 2), (60, 401, 1, 10), (5000, 40, 3, 7), (1 << 18, 64, 2, 20),
+                                     (3000, 400, 3, 400)])   # A*M = 1200 running sums: swept in two component ranges
 def test_sse_by_components(handle, oracle, po, N, K, M, A):
     import pls_amd
     Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
@@ -427,12 +428,12 @@ def test_sse_by_components(handle, oracle, po, N, K, M, A):
     m = pls_amd.Model(X, Y, pls_amd.KERNEL_TYPE1, A, handle=handle)
     ev, sse = m.explained_variance_by_components(X, Y); handle.synchronize()
     ref = oracle.plsr(Xh, Yh, A)
-    for c in range(1, A + 1):
+    for c in (range(1, A + 1) if A <= 20 else (1, 2, 100, 341, 342, 343, A)):
         evr, sser = po.explained_variance(Xh, Yh, ref["R"], ref["Q"], c)
-        assert np.allclose(sse[:, c - 1].cpu().numpy(), sser, rtol=1e-8)
-        assert np.allclose(ev[:, c - 1].cpu().numpy(), evr, rtol=1e-7, atol=1e-10)
+        assert np.allclose(sse[:, c - 1].cpu().numpy(), sser, rtol=1e-8 if A <= 20 else 1e-6)
+        assert np.allclose(ev[:, c - 1].cpu().numpy(), evr, rtol=1e-7 if A <= 20 else 1e-5, atol=1e-10)
         # and it agrees with the reference's route (one X*B_c pass per component count)
-        assert np.allclose(m.SSE(X, Y, c).cpu().numpy(), sser, rtol=1e-8)
+        assert np.allclose(m.SSE(X, Y, c).cpu().numpy(), sser, rtol=1e-8 if A <= 20 else 1e-6)
 
 
 # ------------------------------------------------------------------------------------------
