@@ -17,6 +17,7 @@
 #include "fused_kernels.hpp"
 #include "defer_kernels.hpp"
 #include "small_kernels.hpp"
+#include "coop_update.hpp"
 #include "stream_kernels.hpp"
 #include "syrk_kernels.hpp"
 #include "cv_kernels.hpp"
@@ -50,7 +51,7 @@ struct pls_hip_context {
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
     i64 opt_fused_grid = 0, opt_work_layout = 1, opt_defer = 1;
-    DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
+    DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, coop, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
     std::vector<hipEvent_t> ev_pool;  // grows until pls_hip_get_timing harvests and recycles it
@@ -365,6 +366,27 @@ constexpr i64 ROTATE_SPLIT_MIN = 16384;
 int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, double *P,
                   double *Q, double *R, double *v, int K, int M, int A, int a, int nip) {
     const int n = a + 1;
+    // PLS_HIP_COOP_UPDATE=0 in the environment keeps the single-workgroup kernel (A/B measurements only)
+    static const bool coop_on = !(getenv("PLS_HIP_COOP_UPDATE") && atoi(getenv("PLS_HIP_COOP_UPDATE")) == 0);
+    if (coop_on && plsk::coop_update_covers(K, M) && A <= 4096) {
+        // several workgroups, two in-launch exchanges, r included (coop_update.hpp): one launch per component
+        const size_t need = plsk::coop_scratch_bytes(A);
+        if (c->coop.bytes < need) {  // the exchange counters start from zero
+            CHK(ensure(c, c->coop, need));
+            HIPCHK(c, hipMemsetAsync(c->coop.p, 0, c->coop.bytes, c->stream));
+        }
+        unsigned *cnt = (unsigned *)c->coop.p;
+        double *qraw = (double *)((char *)c->coop.p + 256), *gpart = qraw + plsk::COOP_MAXG * plsk::COOP_QSTRIDE;
+        double *cpart = gpart + plsk::COOP_MAXG * plsk::COOP_GSTRIDE;
+        const dim3 grid((K + plsk::COOP_WG - 1) / plsk::COOP_WG), blk(plsk::COOP_WG);
+        Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * M * 3 + (i64)K * (2 * (a + 2)) + K) * 8);
+#define COOP_CASE(MM_) hipLaunchKernelGGL((plsk::coop_update_kernel<MM_>), grid, blk, (size_t)A * sizeof(double), c->stream, \
+                                          red, XY, W, P, Q, R, v, K, M, A, a, nip, (int)c->opt_power_iters, cnt, qraw, gpart, cpart)
+        if (M <= 2) COOP_CASE(2); else if (M <= 4) COOP_CASE(4); else COOP_CASE(8);
+#undef COOP_CASE
+        LAUNCH_CHECK(c);
+        return PLS_HIP_OK;
+    }
     const bool split = n < A && n > 0 && (i64)n * K >= ROTATE_SPLIT_MIN;
     Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * M * 3 + (i64)K * (2 * (a + 2)) + K) * 8);
     hipLaunchKernelGGL(plsk::component_update_kernel, dim3(1), dim3(plsk::UPD_THREADS),
@@ -896,7 +918,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->tab,
+    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->tab,
                       &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)

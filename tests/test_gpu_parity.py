@@ -493,6 +493,18 @@ def test_wide_matrix(handle, oracle, po, mode, N, K, M, A):
     check_against(po, out, ref, Bref, ref["T"], col_err=cerr)
 
 
+@pytest.mark.parametrize("N,K,M,A", [(300, 2048, 8, 6), (260, 8192, 2, 5), (200, 4100, 4, 7), (130, 16384, 2, 4),
+                                     (400, 4096, 8, 70), (300, 5000, 5, 34), (96, 16384, 8, 3)])
+def test_cooperative_component_update(handle, oracle, po, mode, N, K, M, A):
+    """2 <= M <= 8 with K*M >= 16K values: the component update runs on K/256 workgroups with two in-launch exchanges
+    (coop_update.hpp) -- ragged last workgroup (K = 4100, 5000), the 64-workgroup maximum (K = 16384), more components
+    than one 32-value chunk of c_j = p_j^T w holds (A = 34, 70), every plan, against the oracle."""
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    out = handle.fit_device(to_dev(Xh), to_dev(Yh), A); handle.synchronize()
+    check_against(po, out, ref, Bref, ref["T"], col_err=cerr, tol_inv=1e-7)
+
+
 @pytest.mark.parametrize("N,K,M,A", [(512, 2300, 3, 4), (516, 1536, 1, 5), (260, 4096, 2, 5)])
 def test_wide_matrix_fp32(handle, oracle, po, mode, N, K, M, A):
     torch = _torch()
