@@ -166,12 +166,14 @@ struct XtyGeom {
     int G;    // row groups = number of partial rows (same for every m-tile of one product)
     int nkg;  // column groups of this m-tile
 };
-// G is derived from the widest column group (KC = 32) so that all m-tiles of one X^T Y write
-// the same number of partial rows; narrower tiles simply launch more workgroups.
-XtyGeom xty_geom(i64 N, int K, int KC, int vec, int target_wgs) {
+// All m-tiles of one X^T Y write the same number of partial rows G.  It is derived from the column groups of the
+// product's FIRST tile (kc_first columns each; the first tile is the widest in m, i.e. the one with the most column
+// groups): with G from the 32-column shape instead, the 8-response tile of config 4 ran 16,384 workgroups of 8 row
+// chunks each and spent half its time in their 32 butterfly sums (1.0 ms = 2.1 TB/s, fp32 and fp64 alike).
+XtyGeom xty_geom(i64 N, int K, int KC, int vec, int target_wgs, int kc_first) {
     XtyGeom g;
     g.nkg = (K + KC - 1) / KC;
-    const int nkg32 = (K + XTY_KCMT - 1) / XTY_KCMT;
+    const int nkg32 = (K + kc_first - 1) / kc_first;
     const i64 nch = (N + (i64)plsk::WG * vec - 1) / ((i64)plsk::WG * vec);
     i64 G = std::max<i64>(1, target_wgs / nkg32);
     G = std::min<i64>(G, std::max<i64>(nch, 1));
@@ -298,21 +300,33 @@ int launch_xty(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                double *part, int *nb) {
     constexpr int FV = 16 / sizeof(T);
     const bool wide = vec_ok<T>(X, ldx, FV) && vec_ok<T>(Y, ldy, FV);
-    const int target = 8 * c->num_cu;
+    // workgroups per CU aimed at: 8; 4 with 8-response tiles, whose 32 butterfly sums per workgroup want longer walks
+    // (config 4, fp32: 0.55 ms at 4, 0.59 at 8, 0.77 at 32 -- tools/xty_m8.py)
+    static const int tgt_env = getenv("PLS_HIP_XTY_TGT") ? atoi(getenv("PLS_HIP_XTY_TGT")) : 0;
+    const int target = (tgt_env > 0 ? tgt_env : (M >= 8 ? 4 : 8)) * c->num_cu;
     int m0 = 0;
+    const int kc_first = XTY_KCMT / ((M >= 8) ? 8 : (M >= 4 ? 4 : (M >= 2 ? 2 : 1)));
     while (m0 < M) {
         const int mt = (M - m0 >= 8) ? 8 : (M - m0 >= 4 ? 4 : (M - m0 >= 2 ? 2 : 1));
-        const int kc = XTY_KCMT / mt;
-        const XtyGeom g = xty_geom(N, K, kc, wide ? FV : 1, target);
+        // 8 responses: 8 columns per workgroup (64 accumulators per lane) -- the Y packs of a row chunk are loaded once
+        // per column group, so 4 columns meant twice as many bytes of Y as of X through L2 (1.0 ms = 2.1 TB/s at config 4)
+        static const int kc8 = getenv("PLS_HIP_XTY_KC8") ? atoi(getenv("PLS_HIP_XTY_KC8")) : 4;
+        static const bool xty8 = !(getenv("PLS_HIP_XTY8") && atoi(getenv("PLS_HIP_XTY8")) == 0);
+        const int kc = mt == 8 ? kc8 : XTY_KCMT / mt;
+        const XtyGeom g = xty_geom(N, K, kc, wide ? FV : 1, target, kc_first);
         *nb = g.G;
         const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * mt * sizeof(T) + (i64)K * mt * 8;
         Scope s(c, PLS_HIP_FAM_XTY, bytes);
 #define XTY_CASE(V, KC_, M_) launch_xty_t<T, V, KC_, M_>(c, X, ldx, Y, ldy, N, K, M, m0, part, g)
-        if (wide) {
-            if (mt == 8) XTY_CASE(FV, 4, 8); else if (mt == 4) XTY_CASE(FV, 8, 4);
+        if (wide && mt == 8 && kc == 4 && K % 4 == 0 && xty8) {
+            hipLaunchKernelGGL((plsk::xty8_kernel<T, FV>), dim3(g.G, g.nkg), dim3(plsk::WG), 0, c->stream, X, ldx, Y, ldy, N, K,
+                               M, m0, part);
+        } else if (wide) {
+            if (mt == 8 && kc == 8) XTY_CASE(FV, 8, 8); else if (mt == 8 && kc == 16) XTY_CASE(FV, 16, 8);
+            else if (mt == 8) XTY_CASE(FV, 4, 8); else if (mt == 4) XTY_CASE(FV, 8, 4);
             else if (mt == 2) XTY_CASE(FV, 16, 2); else XTY_CASE(FV, 32, 1);
         } else {
-            if (mt == 8) XTY_CASE(1, 4, 8); else if (mt == 4) XTY_CASE(1, 8, 4);
+            if (mt == 8 && kc != 4) XTY_CASE(1, 8, 8); else if (mt == 8) XTY_CASE(1, 4, 8); else if (mt == 4) XTY_CASE(1, 8, 4);
             else if (mt == 2) XTY_CASE(1, 16, 2); else XTY_CASE(1, 32, 1);
         }
 #undef XTY_CASE

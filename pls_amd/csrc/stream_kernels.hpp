@@ -367,6 +367,82 @@ __global__ __launch_bounds__(WG) void xty_kernel(const T *__restrict__ X, i64 ld
 }
 
 // ------------------------------------------------------------------------------------
+// The 8-response tile of X^T Y with the loads of the NEXT row chunk issued before the FMAs of the current one
+// (register double buffer): xty_kernel<T, V, 4, 8> alternates "12 loads, wait, 128 FMAs" with two waves per SIMD to
+// hide a 1-2 us load latency behind 0.25 us of arithmetic, and runs at 2.1 TB/s whatever the storage type.
+// Same grid, same partial layout, same summation order as xty_kernel<T, VEC, 4, 8> (full 16-byte row packs only).
+// ------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(WG) void xty8_kernel(const T *__restrict__ X, i64 ldx, const T *__restrict__ Y, i64 ldy,
+                                                  i64 N, int K, int M, int m0, double *__restrict__ part) {
+    constexpr int KC = 4, MT = 8;
+    __shared__ double red[WG / WAVE][KC * MT];
+    const int k0 = blockIdx.y * KC;
+    double acc[KC][MT];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[kc][m] = 0.0;
+    constexpr i64 CH = (i64)WG * VEC;
+    const i64 nfull = N / CH;  // chunks in which every lane has a full pack
+    Pack<T, VEC> xa[KC], ya[MT], xb[KC], yb[MT];
+    auto load = [&](i64 c, Pack<T, VEC> (&x)[KC], Pack<T, VEC> (&y)[MT]) {
+        const i64 i0 = c * CH + (i64)threadIdx.x * VEC;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) y[m] = ld_pack<T, VEC>(Y + i0 + (i64)(m0 + m) * ldy);
+#pragma unroll
+        for (int u = 0; u < KC; ++u) x[u] = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + u) * ldx);
+    };
+    auto fmas = [&](const Pack<T, VEC> (&x)[KC], const Pack<T, VEC> (&y)[MT]) {
+#pragma unroll
+        for (int u = 0; u < KC; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[u][m] = fma((double)x[u].v[v], (double)y[m].v[v], acc[u][m]);
+    };
+    i64 c = blockIdx.x;
+    if (c < nfull) load(c, xa, ya);
+    while (c < nfull) {
+        const i64 c1 = c + gridDim.x;
+        if (c1 < nfull) load(c1, xb, yb);
+        fmas(xa, ya);
+        c = c1;
+        if (c >= nfull) break;
+        const i64 c2 = c + gridDim.x;
+        if (c2 < nfull) load(c2, xa, ya);
+        fmas(xb, yb);
+        c = c2;
+    }
+    // the ragged last chunk (N % (256 VEC) rows), element-wise, by the workgroup whose turn it is
+    if (nfull * CH < N && (nfull % gridDim.x) == blockIdx.x) {
+        for (i64 i = nfull * CH + threadIdx.x; i < N; i += WG)
+#pragma unroll
+            for (int u = 0; u < KC; ++u) {
+                const double x = (double)X[i + (i64)(k0 + u) * ldx];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[u][m] = fma(x, (double)Y[i + (i64)(m0 + m) * ldy], acc[u][m]);
+            }
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const double s = wave_sum(acc[kc][m]);
+            if (lane == 0) red[w][kc * MT + m] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < KC * MT) {
+        const int kc = threadIdx.x / MT, m = threadIdx.x % MT;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < WG / WAVE; ++i) s += red[i][threadIdx.x];
+        part[(i64)blockIdx.x * ((i64)K * M) + (k0 + kc) + (i64)(m0 + m) * K] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // dst[i,k] = src[i,k] - t[i] * p[k] on column-major matrices, one-shot workgroups: a workgroup is ONE
 // contiguous 4 KB piece of one column (256 lanes x 16 bytes), one load and one store per lane.
 // grid = (row blocks, K), row blocks fastest.  This is the fastest read+write form on MI355X
