@@ -98,6 +98,11 @@ struct pls_hip_group_s {
     std::vector<hipEvent_t> ready[2], done[2];
     std::vector<int> phase;
     std::string err;
+    // freed blocks of resident matrices, kept for the next allocation of the same size (a Model that is rebuilt on
+    // data of the same shape, cross-validation refits): hipMalloc / hipFree of multi-GB blocks cost 50-250 ms when
+    // the runtime returns the memory to the driver in between
+    struct FreeBlock { void *p; size_t bytes; };
+    std::vector<std::vector<FreeBlock>> freelist;  // per member, oldest first
 };
 
 namespace {
@@ -184,6 +189,42 @@ int run_members(pls_hip_group_s *g, F fn) {
     return PLS_HIP_OK;
 }
 
+constexpr size_t FREELIST_MAX_BLOCKS = 6;
+constexpr size_t FREELIST_MAX_BYTES = (size_t)96 << 30;  // per member; a third of the 288 GB of an MI355X
+
+void *block_alloc(pls_hip_group_s *g, int r, size_t bytes) {
+    std::vector<pls_hip_group_s::FreeBlock> &fl = g->freelist[r];
+    for (size_t i = 0; i < fl.size(); ++i)
+        if (fl[i].bytes == bytes) {
+            void *p = fl[i].p;
+            fl.erase(fl.begin() + (long)i);
+            return p;
+        }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        for (auto &b : fl) (void)hipFree(b.p);  // make room and try once more
+        fl.clear();
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    return p;
+}
+
+void block_free(pls_hip_group_s *g, int r, void *p, size_t bytes) {
+    std::vector<pls_hip_group_s::FreeBlock> &fl = g->freelist[r];
+    fl.push_back({p, bytes});
+    size_t total = 0;
+    for (auto &b : fl) total += b.bytes;
+    while (!fl.empty() && (fl.size() > FREELIST_MAX_BLOCKS || total > FREELIST_MAX_BYTES)) {
+        total -= fl.front().bytes;
+        (void)hipFree(fl.front().p);
+        fl.erase(fl.begin());
+    }
+}
+
 bool same_partition(const pls_hip_group_s *g, const pls_hip_matrix_s *m) { return m && (int)m->data.size() == g->n; }
 
 }  // namespace
@@ -206,6 +247,7 @@ int pls_hip_group_create(pls_hip_group *out, int n, const int *devices) {
     g->scratch.assign(n, nullptr);
     g->scratch_count.assign(n, 0);
     g->phase.assign(n, 0);
+    g->freelist.resize(n);
     for (int p = 0; p < 2; ++p) {
         g->ready[p].assign(n, nullptr);
         g->done[p].assign(n, nullptr);
@@ -251,6 +293,8 @@ int pls_hip_group_destroy(pls_hip_group g) {
         (void)hipSetDevice(g->dev[r]);
         if (g->h[r]) (void)pls_hip_destroy(g->h[r]);  // synchronises the member's stream
         if (g->scratch[r]) (void)hipFree(g->scratch[r]);
+        if (r < (int)g->freelist.size())
+            for (auto &b : g->freelist[r]) (void)hipFree(b.p);
         for (int p = 0; p < 2; ++p) {
             if (g->ready[p][r]) (void)hipEventDestroy(g->ready[p][r]);
             if (g->done[p][r]) (void)hipEventDestroy(g->done[p][r]);
@@ -300,7 +344,7 @@ int pls_hip_group_alloc(pls_hip_group g, int64_t N, int64_t K, int dtype, pls_hi
         row_block(N, g->n, r, &m->row0[r], &m->nrows[r]);
         m->ld[r] = std::max<i64>(4, (m->nrows[r] + 3) & ~(i64)3);
         if (hipSetDevice(g->dev[r]) != hipSuccess ||
-            hipMalloc(&m->data[r], (size_t)m->ld[r] * (size_t)K * es) != hipSuccess) {
+            !(m->data[r] = block_alloc(g, r, (size_t)m->ld[r] * (size_t)K * es))) {
             (void)hipGetLastError();
             pls_hip_group_free(g, m.release());
             return gfail(g, PLS_HIP_ERR_ALLOC, "hipMalloc of a resident matrix block failed");
@@ -316,7 +360,7 @@ int pls_hip_group_free(pls_hip_group g, pls_hip_matrix m) {
     for (int r = 0; r < (int)m->data.size() && r < g->n; ++r) {
         (void)hipSetDevice(g->dev[r]);
         (void)hipStreamSynchronize(g->stream[r]);  // launches of this member may still use the block
-        if (m->data[r]) (void)hipFree(m->data[r]);
+        if (m->data[r]) block_free(g, r, m->data[r], (size_t)m->ld[r] * (size_t)m->K * esize(m->dtype));
         if (r < (int)m->gram_xx.size() && m->gram_xx[r]) (void)hipFree(m->gram_xx[r]);
         if (r < (int)m->gram_xy.size() && m->gram_xy[r]) (void)hipFree(m->gram_xy[r]);
     }

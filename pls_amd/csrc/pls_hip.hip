@@ -2,12 +2,14 @@
 // Host side of the library: argument checks, workspace, launch geometry, the A-loop of
 // Model::plsr (src/pls.cpp:390-437) enqueued on one HIP stream with no host round trip,
 // the injected all-reduce for row-sharded fits, HIP-event profiling.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -141,6 +143,46 @@ struct Scope {  // brackets one launch with events when profiling is on
         if (!on) return;
         (void)hipEventRecord(l.e1, c->stream);
         c->launches.push_back(l);
+    }
+};
+
+// ---- tracing: roctx ranges around the phases of a fit -----------------------------------------------------
+// The reference has no tracing.  With PLS_HIP_ROCTX=1 in the environment every fit is wrapped
+// in roctx ranges -- "pls_hip_fit", "X^T Y", "X^T X (SYRK)", "component a", "upload" -- which `rocprofv3 --marker-trace`
+// shows next to the kernels.  The marker library (librocprofiler-sdk-roctx.so) is looked up at run time: the product
+// has no link-time dependency on it and the ranges cost nothing when the switch is off.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *e = getenv("PLS_HIP_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        void *lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!push || !pop) push = nullptr;
+    }
+};
+inline Roctx &roctx() {
+    static Roctx r;
+    return r;
+}
+struct Range {  // RAII range; `text` must outlive the call only
+    bool on;
+    explicit Range(const char *text) : on(roctx().push != nullptr) {
+        if (on) roctx().push(text);
+    }
+    Range(const char *prefix, int n) : on(roctx().push != nullptr) {
+        if (on) {
+            char buf[64];
+            std::snprintf(buf, sizeof(buf), "%s %d", prefix, n);
+            roctx().push(buf);
+        }
+    }
+    ~Range() {
+        if (on) roctx().pop();
     }
 };
 
@@ -572,6 +614,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     T *work = (T *)c->work.p;
 
     // prologue: XY = X^T Y (src/pls.cpp:396), summed over ranks
+    Range r_fit("pls_hip_fit");
+    std::unique_ptr<Range> r_phase(new Range("X^T Y"));
     const bool use_pre = have_pre && (gram || method == PLS_HIP_KERNEL_TYPE2);
     if (use_pre) {
         hipLaunchKernelGGL(plsk::fill_slices_kernel, dim3((unsigned)((L0 + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
@@ -586,6 +630,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     }
     CHK(do_allreduce(c, red, (i64)plsk::RED_SLICES * L0));
     CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, -1, nip));
+    r_phase.reset();
 
     if (type2) {
         // KERNEL_TYPE2 (src/pls.cpp:398, :422-425): XX = X^T X once, then the A-loop never touches X:
@@ -594,6 +639,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         CHK(ensure(c, c->xx, (size_t)K * K * 8));
         CHK(ensure(c, c->praw, (size_t)K * 8));
         double *XX = (double *)c->xx.p, *praw = (double *)c->praw.p;
+        r_phase.reset(new Range("X^T X (SYRK)"));
         if (use_pre) {  // this member's X^T X came with the upload: present it as slice 0, sum over the members
             const i64 KK = (i64)K * K;
             CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * KK * 8));
@@ -607,7 +653,9 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         } else {
             CHK(compute_xx<T>(c, X, ldx, N, K, XX));
         }
+        r_phase.reset();
         for (int a = 0; a < A; ++a) {
+            Range r_comp("component", a);
             {
                 Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * K + 2 * K) * 8);
                 hipLaunchKernelGGL(plsk::symv_kernel, dim3((K + 3) / 4), dim3(plsk::WG), 0, c->stream,
@@ -625,6 +673,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             LAUNCH_CHECK(c);
         }
         if (gram && N > 0) {  // T = X R (src/pls.cpp:439-442 applied to the training data)
+            Range r_t("T = X R");
             int nss = 0;
             CHK(launch_xb<T>(c, X, ldx, N, K, R, K, A, Tm, ldt, nullptr, &nss));
         }
@@ -637,6 +686,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     bool cur_tiled = false;  // Xc is the row-tile-major working copy
     int defer_b = 0;         // deferred write-back: index of the stored matrix X_b
     for (int a = 0; a < A; ++a) {
+        Range r_comp("component", a);
         if (N > 0) {
             bool done = false;
             if (fused_fit && defer > 1 && a > 0) {
@@ -866,6 +916,7 @@ int upload_accumulate(pls_hip_context *c, T *dX, i64 ldd, const T *hX, i64 ldx, 
     plsh::Stager &st = c->stager;
     double *part = (double *)c->part.p, *red2 = (double *)c->red2.p, *red = (double *)c->red.p;
     bool acc = true;
+    Range r_up("upload + X^T X / X^T Y accumulation");
     for (i64 r0 = 0; r0 < N; r0 += rb) {
         const i64 rbn = std::min(rb, N - r0);
         const int s = st.slot;

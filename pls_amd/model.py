@@ -147,15 +147,18 @@ class Handle:
         else:
             W = colmajor_empty(K, A, f64, dev, ld=K); P = colmajor_empty(K, A, f64, dev, ld=K)
             R = colmajor_empty(K, A, f64, dev, ld=K); Q = colmajor_empty(M, A, f64, dev, ld=M)
-            T = colmajor_empty(N, A, X.dtype, dev)
+            # the scores exist for KERNEL_TYPE1 only (reference src/pls.cpp:394,434): None for KERNEL_TYPE2
+            T = colmajor_empty(N, A, X.dtype, dev) if method == KERNEL_TYPE1 else None
             B = colmajor_empty(K, M, f64, dev, ld=K) if want_B else None
+        if method == KERNEL_TYPE1 and T is None:
+            raise L.PlsHipError(L.ERR_INVALID, "KERNEL_TYPE1 needs a T buffer in `out`")
         rc = self._lib.pls_hip_fit(self.h, X.data_ptr(), _ld(X), Y.data_ptr(), _ld(Y), N, K, M, A,
                                    method, self._dt(X), L.MEM_DEVICE, W.data_ptr(), P.data_ptr(),
-                                   Q.data_ptr(), R.data_ptr(), T.data_ptr(), _ld(T),
-                                   B.data_ptr() if want_B else None)
+                                   Q.data_ptr(), R.data_ptr(), T.data_ptr() if T is not None else None,
+                                   _ld(T) if T is not None else max(N, 1), B.data_ptr() if want_B else None)
         L.check(rc, self.h)
         self._last_inputs = (X, Y)  # keep alive until the stream has consumed them
-        return dict(W=W, P=P, Q=Q, R=R, T=T, B=B)
+        return dict(W=W, P=P, Q=Q, R=R, T=T if method == KERNEL_TYPE1 else None, B=B)
 
     def fit_host(self, X, Y, A: int, method: int = KERNEL_TYPE1, dtype=np.float64):
         X = _np_f(X, dtype); Y = _np_f(Y, dtype)
@@ -170,7 +173,7 @@ class Handle:
                                    L.F64 if dtype == np.float64 else L.F32, L.MEM_HOST,
                                    p(W), p(P), p(Q), p(R), p(T), max(N, 1), p(B))
         L.check(rc, self.h)
-        return dict(W=W, P=P, Q=Q, R=R, T=T, B=B)
+        return dict(W=W, P=P, Q=Q, R=R, T=T if method == KERNEL_TYPE1 else None, B=B)
 
     def xb(self, X, Bm):
         """X (N,K) @ Bm (K,C): fitted_values / scores product."""

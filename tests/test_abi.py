@@ -87,3 +87,26 @@ def test_row_partition():
             assert max(b[1] for b in blocks) - min(b[1] for b in blocks) <= 1
     with pytest.raises(ValueError):
         row_partition(10, 2, 2)
+
+
+REF_MAIN = "/root/reference/src/main.cpp"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="the reference tree is not on this machine (GPU box)")
+def test_reference_main_builds_unchanged_against_this_header(tmp_path):
+    """The strongest boundary check available without the reference's Eigen: its own CSV-driven main
+    (src/main.cpp:1-44), UNCHANGED, compiles against include/PLS/pls.h and links against libpls.so -- every
+    type, free function, enum value, constructor and member it uses exists here with a compatible signature."""
+    host = os.path.join(ROOT, "pls_amd", "host")
+    csrc = os.path.join(ROOT, "pls_amd", "csrc")
+    if not os.path.exists(os.path.join(host, "libpls.so")):
+        pytest.skip("libpls.so not built")
+    exe = str(tmp_path / "ref_main")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), REF_MAIN, "-o", exe,
+                        "-L", host, "-lpls", "-L", csrc, "-lpls_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+                        f"-Wl,-rpath,{host}", f"-Wl,-rpath,{csrc}", "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # same usage behaviour as the reference (exit(100) on a wrong argument count, src/main.cpp:12-16); no GPU needed
+    u = subprocess.run([exe], capture_output=True, text=True)
+    assert u.returncode == 100

@@ -48,7 +48,7 @@ def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0, splits=None)
         attach_reducer(h, K, M)
         out = h.fit_device(X, Y, A, method=method)
         h.synchronize()
-        res = {k: v.cpu().numpy() for k, v in out.items()}
+        res = {k: v.cpu().numpy() for k, v in out.items() if v is not None}   # T is None for KERNEL_TYPE2
         # sharded pre-processing and metrics use the same reducer (column statistics over all rows)
         Z, mean, sd = h.colwise_z_scores(X, n_total=N)
         h.synchronize()

@@ -683,6 +683,31 @@ def test_batched_cv_folds(handle, oracle, po, N, K, M, A, ts, nf):
     assert np.abs(Eh - ref).max() < 1e-8 * max(scale, 1.0)
 
 
+def test_roctx_ranges_switch():
+    """PLS_HIP_ROCTX=1: every fit is wrapped in roctx ranges (marker library resolved at run time); the fit itself is
+    unchanged.  (profiles/r2 holds a rocprofv3 --marker-trace of it.)"""
+    import subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); import torch, pls_amd; h = pls_amd.Handle(); "
+            "X = h.synth_x(0, 4096, 64, 1); Y = h.synth_y(0, 4096, 2, 1); "
+            "a = h.fit_device(X, Y, 5); h.set_option(pls_amd.OPT_ALGO, 2); b = h.fit_device(X, Y, 5); h.synchronize(); "
+            "print(float((a['B'] - b['B']).norm() / a['B'].norm()) < 1e-10)") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PLS_HIP_ROCTX="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("True"), r.stderr[-2000:]
+
+
+def test_kernel_type2_has_no_scores(handle):
+    """T exists for KERNEL_TYPE1 only (reference src/pls.cpp:394,434): the Python mirror returns None, never an
+    uninitialised buffer"""
+    import pls_amd
+    X = handle.synth_x(0, 500, 12, 3); Y = handle.synth_y(0, 500, 1, 3)
+    assert handle.fit_device(X, Y, 3, method=pls_amd.KERNEL_TYPE2)["T"] is None
+    assert handle.fit_host(X.cpu().numpy(), Y.cpu().numpy(), 3, method=pls_amd.KERNEL_TYPE2)["T"] is None
+    m = pls_amd.Model(X, Y, pls_amd.KERNEL_TYPE2, 3, handle=handle)
+    assert m.T is None and m.coefficients().shape == (12, 1)
+
+
 def test_auto_plan_choice(handle):
     """AUTO = GRAM where the cost model says so (tall fp64, many components), KERNEL otherwise; checked
     through which kernel families ran."""

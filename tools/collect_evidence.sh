@@ -1,0 +1,68 @@
+#!/bin/bash
+# Collects the measurement evidence of a round on the GPU box into gpurun_out/evidence/ (copy what is to be judged
+# into profiles/rNN/ afterwards).  rocprofv3: the program goes directly after `--`; counters in their own passes.
+# usage: bash tools/collect_evidence.sh [part ...]   parts: c3 deflate c4 c5 eighth host roctx   (default: all)
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+E=gpurun_out/evidence; mkdir -p $E
+PARTS="${*:-c3 deflate c4 c5 eighth host roctx}"
+stats() {  # name, command...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $E/tmp_$name -o p -- "$@" > $E/${name}_bench_under_rocprof.json 2> $E/tmp_$name.err
+  cp $E/tmp_$name/p_kernel_stats.csv $E/${name}_kernel_stats.csv; rm -rf $E/tmp_$name $E/tmp_$name.err
+}
+pmc() {  # name, command...
+  local name=$1; shift
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $E/tmp_${name}_$ctr -o p -- "$@" > /dev/null 2> $E/tmp_pmc.err
+  done
+  python3 tools/summarize_pmc.py $E/tmp_${name}_FETCH_SIZE/p_counter_collection.csv $E/tmp_${name}_WRITE_SIZE/p_counter_collection.csv $E/pmc_traffic_$name.json > $E/pmc_traffic_$name.txt
+  rm -rf $E/tmp_${name}_FETCH_SIZE $E/tmp_${name}_WRITE_SIZE $E/tmp_pmc.err
+}
+for part in $PARTS; do case $part in
+c3)
+  python3 bench.py --steps 20 --warmup 5 > $E/bench_default_run.json 2> /dev/null
+  stats final_nipals_fused python3 bench.py --steps 5 --warmup 2 --no-alt --no-cpu
+  pmc C3_nipals_fused python3 bench.py --steps 2 --warmup 1 --no-alt --no-cpu
+  stats c3_kernel_fused python3 bench.py --algo kernel --steps 5 --warmup 2 --no-alt --no-cpu
+  pmc C3_kernel_fused python3 bench.py --algo kernel --steps 2 --warmup 1 --no-alt --no-cpu ;;
+deflate)
+  python3 tools/deflate_run.py > $E/deflate_piece_hip_events.txt 2> /dev/null
+  stats deflate_piece python3 tools/deflate_run.py
+  pmc deflate_piece python3 tools/deflate_run.py ;;
+c4)
+  python3 bench.py --workload C4 --steps 10 --warmup 3 --no-cpu > $E/bench_C4_all_plans.json 2> /dev/null
+  python3 bench.py --workload C4 --algo kernel --steps 10 --warmup 3 --no-cpu --no-alt > $E/bench_C4_kernel_plan.json 2> /dev/null
+  stats c4_nipals python3 bench.py --workload C4 --steps 3 --warmup 1 --no-alt --no-cpu
+  pmc C4_nipals_fused python3 bench.py --workload C4 --steps 2 --warmup 1 --no-alt --no-cpu
+  stats c4_kernel python3 bench.py --workload C4 --algo kernel --steps 3 --warmup 1 --no-alt --no-cpu
+  pmc C4_kernel_fused python3 bench.py --workload C4 --algo kernel --steps 2 --warmup 1 --no-alt --no-cpu
+  python3 tools/xty_m8.py > $E/xty_m8.txt 2> /dev/null ;;
+c5)
+  python3 bench.py --workload C5rank --steps 5 --warmup 2 --no-cpu --no-alt > $E/bench_C5_one_shard.json 2> /dev/null
+  python3 bench.py --workload C5rank --algo kernel --steps 5 --warmup 2 --no-cpu --no-alt > $E/bench_C5_one_shard_kernel_plan.json 2> /dev/null
+  stats c5rank_nipals python3 bench.py --workload C5rank --steps 2 --warmup 1 --no-alt --no-cpu
+  pmc C5rank_nipals_fused python3 bench.py --workload C5rank --steps 1 --warmup 1 --no-alt --no-cpu ;;
+eighth)
+  python3 bench.py --workload C3eighth --steps 20 --warmup 5 --no-cpu --no-alt > $E/bench_C3eighth.json 2> /dev/null
+  stats c3eighth python3 bench.py --workload C3eighth --steps 10 --warmup 3 --no-alt --no-cpu ;;
+host)
+  ./tools/host_entry_time 1048576 512 1 20 5 > $E/host_entry_time_C3.txt 2>&1
+  PLS_HIP_ALGO=kernel ./tools/host_entry_time 1048576 512 1 20 3 > $E/host_entry_time_C3_kernel_plan.txt 2>&1
+  ./tools/h2d_probe > $E/h2d_probe.txt 2>&1 ;;
+roctx)
+  PLS_HIP_ROCTX=1 rocprofv3 --marker-trace --kernel-trace --output-format csv -d $E/tmp_roctx -o p -- python3 tools/roctx_demo.py > /dev/null 2> $E/tmp_roctx.err
+  python3 - <<'PY'
+import csv, glob
+E = "gpurun_out/evidence"
+rows = list(csv.DictReader(open(glob.glob(E + "/tmp_roctx/p_marker_api_trace.csv")[0])))
+ker = list(csv.DictReader(open(glob.glob(E + "/tmp_roctx/p_kernel_trace.csv")[0])))
+with open(E + "/roctx_marker_trace.txt", "w") as f:
+    f.write("rocprofv3 --marker-trace --kernel-trace of tools/roctx_demo.py with PLS_HIP_ROCTX=1: %d marker records, %d kernel dispatches\n" % (len(rows), len(ker)))
+    t0 = min(int(r["Start_Timestamp"]) for r in rows)
+    for r in rows[:60]:
+        f.write("%10.1f us  %-8s %s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, r.get("Function", ""), r.get("Message", r.get("Name", ""))))
+PY
+  rm -rf $E/tmp_roctx $E/tmp_roctx.err ;;
+esac; echo "done $part"; done
+ls $E
