@@ -1,0 +1,142 @@
+// Component update for MANY responses (M > 32): the generality path.  The reference solves any M x M eigenproblem
+// (Eigen::EigenSolver on XY^T XY, src/pls.cpp:405-408); the fast kernels of small_kernels.hpp / coop_update.hpp keep
+// the M x M matrix in one workgroup's LDS and stop at M = 32.  Here everything M-sized lives in global memory and every
+// step is a plain multi-workgroup kernel -- a few hundred small launches per component (about a millisecond), which is
+// what "more slowly" costs; nothing on this path is tuned.  Same operation sequence, same sign convention, same
+// repeated-squaring power iteration as dominant_eigvec_lds.
+#pragma once
+#include "small_kernels.hpp"
+
+namespace plsk {
+
+constexpr int LM_MAX = 1024;  // responses supported by the large-M path (M x M fp64 matrices: 3 x 8 MB at the limit)
+
+// p = X^T t / tt -> P[:,a] (:427);  q_m = (r_a^T XY[:,m]) / tt -> Q[m,a], qv[m] (:428).   grid = M + ceil(K/256)
+__global__ __launch_bounds__(WG) void lm_pq_kernel(const double *__restrict__ red, const double *__restrict__ XY,
+                                                   const double *__restrict__ R, double *__restrict__ P,
+                                                   double *__restrict__ Q, double *__restrict__ qv, int K, int M, int a) {
+    __shared__ double sm[WG / WAVE];
+    const double tt = red_sum(red, K + 1, K);
+    const int b = blockIdx.x;
+    if (b < M) {
+        const double *xm = XY + (i64)b * K, *ra = R + (i64)a * K;
+        double s = 0.0;
+        for (int k = threadIdx.x; k < K; k += WG) s = fma(ra[k], xm[k], s);
+        s = block_sum<WG / WAVE>(s, sm);
+        if (threadIdx.x == 0) {
+            Q[b + (i64)a * M] = s / tt;
+            qv[b] = s / tt;
+        }
+    } else {
+        const int k = (b - M) * WG + threadIdx.x;
+        if (k < K) P[k + (i64)a * K] = red_sum(red, K + 1, k) / tt;
+    }
+}
+
+// XY -= (p q^T) tt (:429)
+__global__ __launch_bounds__(WG) void lm_deflate_kernel(const double *__restrict__ red, double *__restrict__ XY,
+                                                        const double *__restrict__ P, const double *__restrict__ qv,
+                                                        int K, int M, int a) {
+    const i64 idx = (i64)blockIdx.x * WG + threadIdx.x;
+    if (idx >= (i64)K * M) return;
+    const double tt = red_sum(red, K + 1, K);
+    const int k = (int)(idx % K), m = (int)(idx / K);
+    XY[idx] -= (P[k + (i64)a * K] * qv[m]) * tt;
+}
+
+// C = A * A for a symmetric M x M matrix, 16 x 16 tiles through LDS.   grid = (ceil(M/16), ceil(M/16)), block = (16, 16)
+__global__ __launch_bounds__(256) void lm_square_kernel(const double *__restrict__ Am, int M, double *__restrict__ Cm) {
+    __shared__ double ta[16][17], tb[16][17];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
+    double s = 0.0;
+    for (int k0 = 0; k0 < M; k0 += 16) {
+        ta[ty][tx] = (row < M && k0 + tx < M) ? Am[row + (i64)(k0 + tx) * M] : 0.0;
+        tb[ty][tx] = (k0 + ty < M && col < M) ? Am[(k0 + ty) + (i64)col * M] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) s = fma(ta[ty][kk], tb[kk][tx], s);
+        __syncthreads();
+    }
+    if (row < M && col < M) Cm[row + (i64)col * M] = s;
+}
+
+// tr[0] = trace(Am)   (one workgroup, fixed order)
+__global__ __launch_bounds__(WG) void lm_trace_kernel(const double *__restrict__ Am, int M, double *__restrict__ tr) {
+    __shared__ double sm[WG / WAVE];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < M; i += WG) s += Am[i + (i64)i * M];
+    s = block_sum<WG / WAVE>(s, sm);
+    if (threadIdx.x == 0) tr[0] = s;
+}
+
+// out = in / tr[0]
+__global__ __launch_bounds__(WG) void lm_scale_kernel(const double *__restrict__ in, const double *__restrict__ tr, i64 n,
+                                                      double *__restrict__ out) {
+    const i64 i = (i64)blockIdx.x * WG + threadIdx.x;
+    if (i < n) out[i] = in[i] / tr[0];
+}
+
+// From Bm ~ v1 v1^T: the column with the largest diagonal entry, two power steps on G, unit norm, largest-|.| entry
+// positive (lowest index on ties) -> qe.   One workgroup of UPD_THREADS; M <= LM_MAX (qe staged in LDS).
+__global__ __launch_bounds__(UPD_THREADS) void lm_eig_finish_kernel(const double *__restrict__ G, const double *__restrict__ Bm,
+                                                                    int M, double *__restrict__ qe) {
+    __shared__ double q[LM_MAX], tmp[LM_MAX], sm[UPD_WAVES];
+    const int tid = threadIdx.x;
+    int best = 0;
+    double bd = Bm[0];
+    for (int c = 1; c < M; ++c) {  // every thread walks the diagonal: the same answer everywhere, no exchange
+        const double d = Bm[c + (i64)c * M];
+        if (d > bd) { bd = d; best = c; }
+    }
+    for (int i = tid; i < M; i += UPD_THREADS) q[i] = Bm[i + (i64)best * M];
+    __syncthreads();
+    for (int pol = 0; pol < 2; ++pol) {
+        for (int i = tid; i < M; i += UPD_THREADS) {
+            double s = 0.0;
+            for (int c = 0; c < M; ++c) s = fma(G[i + (i64)c * M], q[c], s);
+            tmp[i] = s;
+        }
+        __syncthreads();
+        double n2 = 0.0;
+        for (int i = tid; i < M; i += UPD_THREADS) n2 = fma(tmp[i], tmp[i], n2);
+        n2 = block_sum<UPD_WAVES>(n2, sm);
+        const double inv = 1.0 / sqrt(n2);
+        for (int i = tid; i < M; i += UPD_THREADS) q[i] = tmp[i] * inv;
+        __syncthreads();
+    }
+    int big = 0;
+    for (int c = 1; c < M; ++c)
+        if (fabs(q[c]) > fabs(q[big])) big = c;
+    const double sgn = (q[big] < 0.0) ? -1.0 : 1.0;
+    for (int i = tid; i < M; i += UPD_THREADS) qe[i] = q[i] * sgn;
+}
+
+// wraw = XY qe (:408) with per-workgroup partials of |wraw|^2.   grid = ceil(K/256)
+__global__ __launch_bounds__(WG) void lm_w_kernel(const double *__restrict__ XY, const double *__restrict__ qe, int K, int M,
+                                                  double *__restrict__ wraw, double *__restrict__ sspart) {
+    __shared__ double sm[WG / WAVE];
+    const int k = blockIdx.x * WG + threadIdx.x;
+    double s = 0.0;
+    if (k < K)
+        for (int m = 0; m < M; ++m) s = fma(XY[k + (i64)m * K], qe[m], s);
+    if (k < K) wraw[k] = s;
+    const double ss = block_sum<WG / WAVE>(k < K ? s * s : 0.0, sm);
+    if (threadIdx.x == 0) sspart[blockIdx.x] = ss;
+}
+
+// w = wraw / sqrt(sum of the partials) (:411); n == 0 (first component): r_0 = w_0 and the next direction as well
+__global__ __launch_bounds__(WG) void lm_normalize_kernel(const double *__restrict__ wraw, const double *__restrict__ sspart,
+                                                          int nparts, int K, double *__restrict__ wout, double *R0,
+                                                          double *vnext) {
+    double ss = 0.0;
+    for (int i = 0; i < nparts; ++i) ss += sspart[i];  // index order: the same bits in every workgroup
+    const int k = blockIdx.x * WG + threadIdx.x;
+    if (k >= K) return;
+    const double w = wraw[k] / sqrt(ss);
+    wout[k] = w;
+    if (R0) R0[k] = w;
+    if (vnext) vnext[k] = w;
+}
+
+}  // namespace plsk

@@ -20,6 +20,7 @@
 #include "defer_kernels.hpp"
 #include "small_kernels.hpp"
 #include "coop_update.hpp"
+#include "largem_kernels.hpp"
 #include "stream_kernels.hpp"
 #include "syrk_kernels.hpp"
 #include "cv_kernels.hpp"
@@ -53,7 +54,7 @@ struct pls_hip_context {
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
     i64 opt_fused_grid = 0, opt_work_layout = 1, opt_defer = 1;
-    DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, coop, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
+    DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, coop, lm, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
     std::vector<hipEvent_t> ev_pool;  // grows until pls_hip_get_timing harvests and recycles it
@@ -418,10 +419,78 @@ int launch_reduce(pls_hip_context *c, const double *part, int nb, int L, const d
 // n*K (values of P and of R the r update must read) above which it is split over many workgroups
 constexpr i64 ROTATE_SPLIT_MIN = 16384;
 
+// The component update for M > 32 responses (largem_kernels.hpp): M-sized data in global memory, plain multi-workgroup
+// kernels, the eigenvector by `power_iters` squarings without early exit.  Scratch in c->lm.
+int launch_update_large(pls_hip_context *c, const double *red, double *XY, double *W, double *P, double *Q, double *R,
+                        double *v, int K, int M, int A, int a, int nip) {
+    const i64 MM = (i64)M * M;
+    const int nparts = (K + plsk::WG - 1) / plsk::WG;
+    const i64 prows = max_partial_rows(c, K, M);
+    const size_t need = (size_t)(3 * MM + 2 * M + nparts + 8 + K + prows * MM + (i64)plsk::RED_SLICES * MM) * 8;
+    CHK(ensure(c, c->lm, need));
+    double *G = (double *)c->lm.p, *Bm = G + MM, *Cm = Bm + MM, *qe = Cm + MM, *qv = qe + M, *ssp = qv + M;
+    double *tr = ssp + nparts, *wraw = tr + 8, *xpart = wraw + K, *xred = xpart + prows * MM;
+    const dim3 blk(plsk::WG);
+    Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * M * 4 + MM * 3 * c->opt_power_iters) * 8);
+    if (a >= 0) {
+        hipLaunchKernelGGL(plsk::lm_pq_kernel, dim3(M + nparts), blk, 0, c->stream, red, (const double *)XY, (const double *)R, P,
+                           Q, qv, K, M, a);
+        LAUNCH_CHECK(c);
+        hipLaunchKernelGGL(plsk::lm_deflate_kernel, dim3((unsigned)(((i64)K * M + plsk::WG - 1) / plsk::WG)), blk, 0, c->stream,
+                           red, XY, (const double *)P, (const double *)qv, K, M, a);
+        LAUNCH_CHECK(c);
+    } else {
+        hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((unsigned)(((i64)K * M + plsk::WG - 1) / plsk::WG)), blk, 0, c->stream,
+                           red, K * M, XY);
+        LAUNCH_CHECK(c);
+    }
+    const int n = a + 1;
+    if (n >= A) return PLS_HIP_OK;
+    {  // G = XY^T XY (:405) with the column-reduction kernels: "X" = XY (K rows, M columns), "Y" = XY
+        const bool was = s.on;
+        int nb = 0;
+        CHK(launch_xty<double>(c, XY, K, XY, K, K, M, M, xpart, &nb));
+        CHK(launch_reduce(c, xpart, nb, (int)MM, nullptr, 0, xred));
+        hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((unsigned)((MM + plsk::WG - 1) / plsk::WG)), blk, 0, c->stream,
+                           (const double *)xred, (int)MM, G);
+        LAUNCH_CHECK(c);
+        (void)was;
+    }
+    // dominant eigenvector: B_0 = G / tr G, B_{j+1} = B_j^2 / tr(B_j^2)
+    const dim3 sq((M + 15) / 16, (M + 15) / 16), sqb(16, 16);
+    const unsigned nmm = (unsigned)((MM + plsk::WG - 1) / plsk::WG);
+    hipLaunchKernelGGL(plsk::lm_trace_kernel, dim3(1), blk, 0, c->stream, (const double *)G, M, tr);
+    hipLaunchKernelGGL(plsk::lm_scale_kernel, dim3(nmm), blk, 0, c->stream, (const double *)G, (const double *)tr, MM, Bm);
+    for (int it = 0; it < (int)c->opt_power_iters; ++it) {
+        hipLaunchKernelGGL(plsk::lm_square_kernel, sq, sqb, 0, c->stream, (const double *)Bm, M, Cm);
+        hipLaunchKernelGGL(plsk::lm_trace_kernel, dim3(1), blk, 0, c->stream, (const double *)Cm, M, tr);
+        hipLaunchKernelGGL(plsk::lm_scale_kernel, dim3(nmm), blk, 0, c->stream, (const double *)Cm, (const double *)tr, MM, Bm);
+    }
+    LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(plsk::lm_eig_finish_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream, (const double *)G,
+                       (const double *)Bm, M, qe);
+    LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(plsk::lm_w_kernel, dim3(nparts), blk, 0, c->stream, (const double *)XY, (const double *)qe, K, M, wraw, ssp);
+    LAUNCH_CHECK(c);
+    double *wn = W + (i64)n * K;
+    hipLaunchKernelGGL(plsk::lm_normalize_kernel, dim3(nparts), blk, 0, c->stream, (const double *)wraw, (const double *)ssp,
+                       nparts, K, wn, n == 0 ? R : (double *)nullptr, n == 0 ? v : (double *)nullptr);
+    LAUNCH_CHECK(c);
+    if (n > 0) {  // r = w - sum_j (p_j^T w) r_j (:412-416)
+        double *cs = (double *)c->cs.p;
+        hipLaunchKernelGGL(plsk::rotate_dots_kernel, dim3(n), blk, 0, c->stream, P, W, K, n, cs);
+        LAUNCH_CHECK(c);
+        hipLaunchKernelGGL(plsk::rotate_apply_kernel, dim3(nparts), blk, 0, c->stream, W, R, cs, v, K, n, nip);
+        LAUNCH_CHECK(c);
+    }
+    return PLS_HIP_OK;
+}
+
 // nip: 0 = KERNEL algo (next pass is X r), 1 = NIPALS (next pass X_a w)
 int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, double *P,
                   double *Q, double *R, double *v, int K, int M, int A, int a, int nip) {
     const int n = a + 1;
+    if (M > plsk::MMAX) return launch_update_large(c, red, XY, W, P, Q, R, v, K, M, A, a, nip);
     // PLS_HIP_COOP_UPDATE=0 in the environment keeps the single-workgroup kernel (A/B measurements only)
     static const bool coop_on = !(getenv("PLS_HIP_COOP_UPDATE") && atoi(getenv("PLS_HIP_COOP_UPDATE")) == 0);
     if (coop_on && plsk::coop_update_covers(K, M) && A <= 4096) {
@@ -898,7 +967,7 @@ int upload_accumulate(pls_hip_context *c, T *dX, i64 ldd, const T *hX, i64 ldx, 
     i64 rb = (i64)(plsh::STAGE_BYTES / ((size_t)K * es)) & ~(i64)63;
     const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
     const i64 S = std::max<i64>(1, (2 * (i64)c->num_cu) / (nbk * (nbk + 1) / 2));
-    if (N < 1 || K > 4096 || M > plsk::MMAX || rb < 64 || !vec_ok<T>(dX, ldd, FV) || !vec_ok<T>(dY, ldy, FV) ||
+    if (N < 1 || K > 4096 || M > plsk::LM_MAX || rb < 64 || !vec_ok<T>(dX, ldd, FV) || !vec_ok<T>(dY, ldy, FV) ||
         ensure(c, c->red2, (size_t)plsk::RED_SLICES * KK * 8) != PLS_HIP_OK ||
         ensure(c, c->part, std::max<size_t>((size_t)S * KK, (size_t)max_partial_rows(c, rb, K) * L0) * 8) != PLS_HIP_OK ||
         ensure(c, c->red, (size_t)plsk::RED_SLICES * std::max<i64>(L0, K + 1) * 8) != PLS_HIP_OK) {
@@ -983,7 +1052,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->tab,
+    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->tab,
                       &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)
@@ -1110,8 +1179,8 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
     const bool sharded = h->nranks > 1;
     if (N < 0 || (N == 0 && !sharded) || K < 1 || M < 1 || A < 1 || A > K)
         return fail(h, PLS_HIP_ERR_INVALID, "bad shape: need N>=1, K>=1, M>=1, 1<=A<=K");
-    if (K > (1 << 30) || M > (1 << 20) || (M > 1 && M > plsk::MMAX))
-        return fail(h, PLS_HIP_ERR_UNSUPPORTED, "M > 32 responses (or K > 2^30) not supported on the device");
+    if (K > (1 << 30) || M > plsk::LM_MAX)
+        return fail(h, PLS_HIP_ERR_UNSUPPORTED, "more than 1024 responses (or K > 2^30) not supported on the device");
     if (N > 0 && (!X || !Y || (!T && method == PLS_HIP_KERNEL_TYPE1))) return fail(h, PLS_HIP_ERR_INVALID, "null X/Y/T");
     if (A > 4096) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "more than 4096 components not supported");
     if ((method == PLS_HIP_KERNEL_TYPE2 || h->opt_algo == PLS_HIP_ALGO_GRAM) && K > 16384)  // (AUTO never picks GRAM there)

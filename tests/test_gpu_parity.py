@@ -446,8 +446,9 @@ def test_bad_arguments(handle):
     with pytest.raises(pls_amd.PlsHipError) as e:
         handle.fit_device(X, Y, 6)  # A > K
     assert e.value.code == 1
-    with pytest.raises(pls_amd.PlsHipError):
-        handle.fit_device(X, handle.synth_y(0, 50, 40, 1), 2)  # m > 32
+    with pytest.raises(pls_amd.PlsHipError) as e:
+        handle.fit_device(X, handle.synth_y(0, 50, 1025, 1), 2)  # more than 1024 responses
+    assert e.value.code == 4
     # the handle stays usable after an error
     out = handle.fit_device(X, Y, 2); handle.synchronize()
     assert torch.isfinite(out["B"]).all()
@@ -457,6 +458,18 @@ def test_bad_arguments(handle):
 def test_extreme_shapes(handle, oracle, po, mode, N, K, M, A):
     """single row, single predictor, the widest supported response block (m = 32), K > N."""
     Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    out = handle.fit_device(to_dev(Xh), to_dev(Yh), A); handle.synchronize()
+    check_against(po, out, ref, Bref, ref["T"], col_err=cerr, tol_inv=1e-7)
+
+
+@pytest.mark.parametrize("N,K,M,A", [(300, 40, 33, 4), (500, 64, 64, 5), (200, 30, 100, 3), (1000, 513, 40, 6)])
+def test_many_responses(handle, oracle, po, mode, N, K, M, A):
+    """M > 32 responses: the reference solves any M x M eigenproblem (src/pls.cpp:405-408); here the M-sized work of
+    the component update moves to global memory (largem_kernels.hpp) -- slower, same results.  M > K included."""
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    # the generator repeats its 2^-(j mod 16) column scaling every 16 responses: break the ties between the copies
+    Yh = np.asfortranarray(Yh * (1.0 + 0.37 * (np.arange(M) // 16))[None, :])
     ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
     out = handle.fit_device(to_dev(Xh), to_dev(Yh), A); handle.synchronize()
     check_against(po, out, ref, Bref, ref["T"], col_err=cerr, tol_inv=1e-7)
@@ -557,7 +570,7 @@ def test_bad_arguments_every_entry_point(handle):
                                         kw.get("mem", 1), p(W), p(P), p(Q), p(R), p(T), 64, p(B))
     assert fit() == 0
     assert fit(X=nul) == 1 and fit(ldx=10) == 1 and fit(N=0) == 1 and fit(K=0) == 1 and fit(A=0) == 1 and fit(A=7) == 1
-    assert fit(method=5) == 1 and fit(dtype=9) == 1 and fit(mem=3) == 1 and fit(M=33) == 4
+    assert fit(method=5) == 1 and fit(dtype=9) == 1 and fit(mem=3) == 1 and fit(M=1025) == 4
     assert b"" != lib.pls_hip_last_error(h)
     assert lib.pls_hip_xb(h, p(X), 64, 64, 6, nul, 6, 2, 0, 1, p(T), 64) == 1
     assert lib.pls_hip_xb(h, p(X), 10, 64, 6, p(R), 6, 2, 0, 1, p(T), 64) == 1
