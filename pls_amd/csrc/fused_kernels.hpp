@@ -534,7 +534,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     auto al = [](const void *p, i64 ld) { return ((uintptr_t)p % 16 == 0) && (ld % V == 0); };
     if (!al(X, ldx) || !al(tout, V) || (defl && (!al(dst, ldd) || !al(tprev, V)))) return 1;
     if (tsx % V != 0 || (defl && tsd % V != 0)) return 1;
-    if (K > CG * 32 || N < 1 || N % V != 0) return 1;
+    if (K > CG * (CGX == 256 ? 16 : 32) || N < 1 || N % V != 0) return 1;
     // a column group's byte span (its num_records, and every lane offset) must stay below 2^31
     if ((i64)CG * ldx * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
@@ -575,11 +575,11 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         else if (K <= CG * 8) FUSED_CASE(8);
         else if (K <= CG * 16) FUSED_CASE(16);
         else FUSED_CASE(32);
-    } else if constexpr (CGX == 64) {
+    } else if constexpr (CGX == 64 || CGX == 128) {
         if (K <= CG * 16) FUSED_CASE(16);
         else FUSED_CASE(32);
     } else {
-        FUSED_CASE(32);
+        FUSED_CASE(16);  // 256 column groups x 2 row lanes: K <= 4096 at 16 columns per lane
     }
 #undef FUSED_CASE
     *nb = (int)grid;

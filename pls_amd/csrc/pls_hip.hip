@@ -658,14 +658,21 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // is one fused read-only pass instead of two one-product passes -- pays from the third component on.
     bool retile_fit = !nipals && !type2 && c->opt_fuse && !fused_fit && N > 0 && A >= 3 && K <= 128 * 32 &&
                       c->opt_work_layout != 0 && plsk::deflate_score_covers<T>(X, ldx, N, K, Tm, ldt);
+    // column groups of the short tiles of a wide matrix (1024 < K <= 4096): 16 columns per lane in 128 / 256 groups
+    // (8-row fp32 / 4-row fp64 tiles at K <= 4096) -- the register shape of the headline kernel, two workgroups per CU
+    // on read-only passes.  Config 4: read+write pass 0.766 -> 0.710 ms (0.70 -> 0.76 of peak), read-only pass
+    // 0.364 -> 0.324 ms (0.74 -> 0.83) against 32 columns per lane in 64 / 128 groups (PLS_HIP_WIDE16=0, the round-1 shape).
+    static const bool wide16 = !(getenv("PLS_HIP_WIDE16") && atoi(getenv("PLS_HIP_WIDE16")) == 0);
+    const int wide_groups = wide16 ? (K <= 128 * 16 ? 128 : (K <= 256 * 16 ? 256 : 0))
+                                   : (K <= 64 * 32 ? 64 : (K <= 128 * 32 ? 128 : 0));
     if (retile_fit) {  // the copy is optional: without room for it the one-product kernels do the job
-        const i64 wr = (512 / (K <= 64 * 32 ? 64 : 128)) * (i64)(16 / sizeof(T));
+        const i64 wr = (512 / wide_groups) * (i64)(16 / sizeof(T));
         if (ensure(c, c->work, (size_t)((N + wr - 1) / wr) * wr * K * sizeof(T)) != PLS_HIP_OK) {
             retile_fit = false;
             c->err.clear();
         }
     }
-    const int wide_cg = ((semi_fit && tiled_work) || retile_fit) ? (K <= 64 * 32 ? 64 : (K <= 128 * 32 ? 128 : 0)) : 0;
+    const int wide_cg = ((semi_fit && tiled_work) || retile_fit) ? wide_groups : 0;
     // 512 < K <= 1024: the resident tile of the caller's layout needs 32 columns per lane (one 8-wave workgroup per
     // CU, 5.7-5.85 TB/s); on the tiled copy the same K fits half-height tiles at 16 columns per lane (6.0 TB/s).
     // Component 0 reads X with the tall tile, the first deflation reads X tall and writes the short tiles (rdst),
@@ -827,13 +834,10 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 {
                     const i64 bytes = (nipals ? 2 : 1) * ((i64)N * K * sizeof(T) + (i64)N * sizeof(T)) + 3 * (i64)K * 8;
                     Scope s(c, PLS_HIP_FAM_FUSED, bytes);
-                    rc = wide_cg == 64
-                             ? plsk::launch_fused_pass<T, 64>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v,
-                                                              tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
-                                                              &nb, &nss, (int)c->opt_fused_grid)
-                             : plsk::launch_fused_pass<T, 128>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v,
-                                                               tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
-                                                               &nb, &nss, (int)c->opt_fused_grid);
+#define WIDE_PASS(CG_) plsk::launch_fused_pass<T, CG_>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v, tprev, pprev, \
+                                                        Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid)
+                    rc = wide_cg == 64 ? WIDE_PASS(64) : (wide_cg == 128 ? WIDE_PASS(128) : WIDE_PASS(256));
+#undef WIDE_PASS
                     if (rc != 0) s.on = false;
                 }
                 if (rc != 0) return fail(c, PLS_HIP_ERR_DEVICE, "short-tile fused pass launch failed");
@@ -874,6 +878,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     const int xrc =
                         wide_cg == 64    ? plsk::launch_xty_tiled<T, 64>(c->stream, c->num_cu, Xc, ldc, tsc, N, K, ta, part, (int)prow, &nb)
                         : wide_cg == 128 ? plsk::launch_xty_tiled<T, 128>(c->stream, c->num_cu, Xc, ldc, tsc, N, K, ta, part, (int)prow, &nb)
+                        : wide_cg == 256 ? plsk::launch_xty_tiled<T, 256>(c->stream, c->num_cu, Xc, ldc, tsc, N, K, ta, part, (int)prow, &nb)
                                          : plsk::launch_xty_tiled<T, 32>(c->stream, c->num_cu, Xc, ldc, tsc, N, K, ta, part, (int)prow, &nb);
                     if (xrc != 0) {
                         s.on = false;
