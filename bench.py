@@ -192,10 +192,27 @@ def main():
     h = pls_amd.Handle()
     X = h.synth_x(row0, nrows, K, pls_amd.SEED_DEFAULT, dtype=tdt)
     Y = h.synth_y(row0, nrows, M, pls_amd.SEED_DEFAULT, dtype=tdt)
+    reducer_used = None
     if world > 1:
-        if a.reducer == "rccl" and a.backend == "nccl":
+        reducer_used = a.reducer if a.backend == "nccl" else "torch"
+        if reducer_used == "rccl":
+            # the library's own communicator; if it cannot be set up on EVERY rank (the ranks agree on that through
+            # torch.distributed), all of them fall back to the torch reducer -- a scaling run must not die here
             from pls_amd.distributed import attach_rccl_reducer
-            attach_rccl_reducer(h)
+            why = ""
+            try:
+                attach_rccl_reducer(h)
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, repr(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if ok:
+                    from pls_amd.distributed import detach_rccl_reducer
+                    detach_rccl_reducer(h)
+                attach_reducer(h, K, M)
+                reducer_used = "torch (library RCCL communicator unavailable" + (": " + why if why else " on another rank") + ")"
         else:
             attach_reducer(h, K, M)
     algo = {"nipals": pls_amd.ALGO_NIPALS, "kernel": pls_amd.ALGO_KERNEL, "gram": pls_amd.ALGO_GRAM}[a.algo]
@@ -225,7 +242,7 @@ def main():
         "config": {"workload": f"{a.workload}: synthetic tall n={N} x p={K}, m={M}, A={A}, {dt}, resident in HBM",
                    "algo": a.algo, "fuse": a.fuse, "deflation_written_back_every": a.defer, "rows_per_gpu": nrows,
                    "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
-                   "reducer": (a.reducer if a.backend == "nccl" else "torch") if world > 1 else None},
+                   "reducer": reducer_used},
         "roofline": roofline_of(tm),
         # end-to-end effective stream rate: (2A) N K s / t_fit, the fused lower bound
         "effective_gbs": round(2 * A * N * K * es / (el / a.steps) / 1e9, 1),
