@@ -83,6 +83,22 @@ int main(int argc, char **argv) {
                     bytes / 1e6 / t_up, rc, t_fit, now_ms() - t1);
     }
     pls_hip_group_destroy(g);
+    {   // the plain C-ABI entry of INTEGRATION.md section B: pls_hip_fit on host pointers (upload, fit, T read back)
+        pls_hip_handle h = nullptr;
+        if (pls_hip_create(&h, 0, nullptr) == PLS_HIP_OK) {
+            std::vector<double> W(K * 20), P(K * 20), R(K * 20), Q(20);
+            double *T = (double *)malloc((size_t)N * 20 * 8);
+            memset(T, 0, (size_t)N * 20 * 8);
+            for (int r = 0; r < 3; ++r) {
+                t0 = now_ms();
+                const int rc = pls_hip_fit(h, hp, N, Y.data(), N, N, K, 1, 20, PLS_HIP_KERNEL_TYPE1, PLS_HIP_F64, PLS_HIP_MEM_HOST,
+                                           W.data(), P.data(), Q.data(), R.data(), T, N, nullptr);
+                std::printf("pls_hip_fit(MEM_HOST), KERNEL plan, T read back (rc %d): %.2f ms\n", rc, now_ms() - t0);
+            }
+            free(T);
+            pls_hip_destroy(h);
+        }
+    }
     free(hp);
     return 0;
 }
