@@ -160,8 +160,9 @@ PLS_HIP_API int pls_hip_get_timing(pls_hip_handle h, pls_hip_timing *out);
  * may be NULL; otherwise it receives coefficients(A) = R Q^T (src/pls.cpp:444-447).
  * mem == DEVICE: all pointers are device pointers, the call only enqueues work on the
  * stream (pls_hip_synchronize or the caller's own stream sync completes it).
- * mem == HOST: pointers are host memory; the call copies in, fits, copies out and returns
- * with the results in place.
+ * mem == HOST: pointers are host memory; the call copies in (pinned double-buffered staging pipeline), fits, copies
+ * out and returns with the results in place.  Under PLS_HIP_ALGO_AUTO / _GRAM and for PLS_HIP_KERNEL_TYPE2 (single
+ * rank) X^T X and X^T Y are accumulated on the matrix cores while X crosses PCIe and the component loop starts from them.
  * Shapes follow the reference's asserts (src/pls.cpp:345-347): 1 <= A <= K, N >= 1
  * (N may be 0 on a rank of a sharded fit), 1 <= M <= 1024 (beyond 32 responses the M-sized work of the component
  * update runs from global memory: correct, about a millisecond per component slower), A <= 4096.

@@ -54,7 +54,7 @@ struct pls_hip_context {
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
     i64 opt_fused_grid = 0, opt_work_layout = 1, opt_defer = 1;
-    DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, coop, lm, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
+    DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, coop, lm, gxx, gxy, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
     std::vector<hipEvent_t> ev_pool;  // grows until pls_hip_get_timing harvests and recycles it
@@ -1057,7 +1057,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->tab,
+    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
                       &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)
@@ -1211,8 +1211,28 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
         CHK(ensure(h, h->hR, (size_t)K * A * 8));
         CHK(ensure(h, h->hQ, (size_t)M * A * 8));
         CHK(ensure(h, h->hB, (size_t)K * M * 8));
-        CHK(h2d(h, h->hX.p, ldn, X, ldx, N, K, es));
         CHK(h2d(h, h->hY.p, ldn, Y, ldy, N, M, es));
+        // A plan that works from X^T X (AUTO, GRAM, KERNEL_TYPE2) gets it for free: accumulated on the matrix cores
+        // row block by row block while X crosses PCIe (upload_accumulate).  Single rank only: the ranks of a sharded
+        // fit must not differ in their plan.
+        bool pre = false;
+        const bool wants_gram = h->opt_algo == PLS_HIP_ALGO_AUTO || h->opt_algo == PLS_HIP_ALGO_GRAM || method == PLS_HIP_KERNEL_TYPE2;
+        if (wants_gram && !h->reducer && N > 0 && K <= 4096 && ensure(h, h->gxx, (size_t)K * K * 8) == PLS_HIP_OK &&
+            ensure(h, h->gxy, (size_t)K * M * 8) == PLS_HIP_OK) {
+            if (dtype == PLS_HIP_F64)
+                CHK(upload_accumulate<double>(h, (double *)h->hX.p, ldn, (const double *)X, ldx, N, Ki, (const double *)h->hY.p, ldn,
+                                              Mi, (double *)h->gxx.p, (double *)h->gxy.p, &pre));
+            else
+                CHK(upload_accumulate<float>(h, (float *)h->hX.p, ldn, (const float *)X, ldx, N, Ki, (const float *)h->hY.p, ldn, Mi,
+                                             (double *)h->gxx.p, (double *)h->gxy.p, &pre));
+        } else {
+            h->err.clear();
+            CHK(h2d(h, h->hX.p, ldn, X, ldx, N, K, es));
+        }
+        if (pre) {
+            h->pre_xx = (const double *)h->gxx.p;
+            h->pre_xy = (const double *)h->gxy.p;
+        }
         dX = h->hX.p; dY = h->hY.p; dT = h->hT.p;
         dW = (double *)h->hW.p; dP = (double *)h->hP.p; dQ = (double *)h->hQ.p; dR = (double *)h->hR.p;
         dB = B ? (double *)h->hB.p : nullptr;
@@ -1227,6 +1247,7 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
         rc = fit_device<float>(h, (const float *)dX, dldx, (const float *)dY, dldy, N, Ki, Mi, Ai, method, dW,
                                dP, dQ, dR, (float *)dT, dldt, dB);
     end_fit_timing(h);
+    if (mem == PLS_HIP_MEM_HOST) h->pre_xx = h->pre_xy = nullptr;
     if (rc != PLS_HIP_OK) return rc;
     if (mem == PLS_HIP_MEM_HOST) {
         CHK(d2h(h, W, K, dW, K, K, A, 8));

@@ -696,6 +696,40 @@ def test_batched_cv_folds(handle, oracle, po, N, K, M, A, ts, nf):
     assert np.abs(Eh - ref).max() < 1e-8 * max(scale, 1.0)
 
 
+@pytest.mark.parametrize("N,K,M,A,dt", [(700001, 24, 2, 6, "f64"), (90000, 200, 1, 8, "f64"), (90000, 200, 3, 5, "f32"), (50, 12, 1, 3, "f64")])
+def test_host_entry_accumulates_gram_during_upload(handle, oracle, po, N, K, M, A, dt):
+    """pls_hip_fit on HOST pointers under ALGO_AUTO (and for KERNEL_TYPE2): X^T X and X^T Y are accumulated on the matrix
+    cores row block by row block while X crosses PCIe, the component loop never passes over X (no fused / score
+    launches), T = X R follows in one pass.  Several 32 MB blocks, a ragged last block, fp32 storage (no 16-byte columns
+    when N % 4 != 0: plain upload, the fit forms the products itself)."""
+    import pls_amd
+    dtype = np.float64 if dt == "f64" else np.float32
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    if dt == "f32":
+        Xh = np.asfortranarray(Xh.astype(np.float32).astype(np.float64)); Yh = np.asfortranarray(Yh.astype(np.float32).astype(np.float64))
+    ref = oracle.plsr(Xh, Yh, A)
+    Bref = oracle.coefficients(ref["R"], ref["Q"])
+    tol = 1e-10 if dt == "f64" else 2e-5
+    handle.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_AUTO)
+    handle.set_option(pls_amd.OPT_PROFILE, 1)
+    try:
+        handle.timing()
+        out = handle.fit_host(Xh, Yh, A, dtype=dtype)
+        tm = handle.timing()
+        assert po.rel_fro(out["B"], Bref) < tol
+        assert po.rel_fro(out["T"].astype(np.float64), Xh @ out["R"]) < (1e-11 if dt == "f64" else 1e-6)
+        if N >= 4096:
+            assert tm["launches"]["fused"] == 0          # the Gram plan: no pass over X per component
+        o2 = handle.fit_host(Xh, Yh, A, method=pls_amd.KERNEL_TYPE2, dtype=dtype)
+        assert o2["T"] is None and po.rel_fro(o2["B"], Bref) < tol
+        handle.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_KERNEL)
+        o3 = handle.fit_host(Xh, Yh, A, dtype=dtype)
+        assert po.rel_fro(o3["B"], out["B"]) < tol
+    finally:
+        handle.set_option(pls_amd.OPT_ALGO, 0)
+        handle.set_option(pls_amd.OPT_PROFILE, 0)
+
+
 def test_roctx_ranges_switch():
     """PLS_HIP_ROCTX=1: every fit is wrapped in roctx ranges (marker library resolved at run time); the fit itself is
     unchanged.  (profiles/r2 holds a rocprofv3 --marker-trace of it.)"""

@@ -8,7 +8,7 @@ h = pls_amd.Handle()
 X = h.synth_x(0, N, K, pls_amd.SEED_DEFAULT); Y = h.synth_y(0, N, M, pls_amd.SEED_DEFAULT)
 Xh = np.asfortranarray(X.cpu().numpy()); Yh = np.asfortranarray(Y.cpu().numpy())
 del X, Y
-for algo in (pls_amd.ALGO_KERNEL, pls_amd.ALGO_NIPALS):
+for algo in (pls_amd.ALGO_KERNEL, pls_amd.ALGO_NIPALS, pls_amd.ALGO_AUTO):
     h.set_option(pls_amd.OPT_ALGO, algo)
     h.fit_host(Xh, Yh, A)
     t0 = time.perf_counter(); out = h.fit_host(Xh, Yh, A); dt = time.perf_counter() - t0
