@@ -101,3 +101,16 @@ def test_host_utilities_under_asan_ubsan(tmp_path):
     assert d["roundtrip"] == ["1"]
     assert d["print"] == ["    1 -22.5", "  333     4"]              # Eigen default IOFormat: right-aligned to the widest
     assert d["cprint"] == ["(1.5,0)  (-2,0)"]
+
+
+def test_copy_pool_and_repack_under_tsan(tmp_path):
+    """the host threads of the staging pipeline under ThreadSanitizer: the pool's epoch handshake and the repacking of
+    strided tiles in both directions (pls_amd/csrc/host_pipeline.hpp); no HIP call is made."""
+    exe = str(tmp_path / "copy_pool")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
+                        os.path.join(ROOT, "tests", "cpp", "copy_pool.cpp"), "-o", exe, "-L", "/opt/rocm/lib", "-lamdhip64",
+                        "-Wl,-rpath,/opt/rocm/lib", "-pthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1", PLS_HIP_STAGE_MB="32"))
+    assert p.returncode == 0 and p.stdout.startswith("ok"), (p.stdout[-500:], p.stderr[-3000:])
