@@ -512,10 +512,12 @@ int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, 
         LAUNCH_CHECK(c);
         return PLS_HIP_OK;
     }
+    // (the in-kernel r recurrence stages its p_j^T w products in min(A, 4096) doubles of LDS: beyond 4096 components
+    // K > 4096 as well, so the multi-workgroup form below takes over from the fourth component on)
     const bool split = n < A && n > 0 && (i64)n * K >= ROTATE_SPLIT_MIN;
     Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * M * 3 + (i64)K * (2 * (a + 2)) + K) * 8);
     hipLaunchKernelGGL(plsk::component_update_kernel, dim3(1), dim3(plsk::UPD_THREADS),
-                       (size_t)A * sizeof(double), c->stream, red, XY, W, P, Q, R, v, K, M, A, a, nip,
+                       (size_t)std::min(A, 4096) * sizeof(double), c->stream, red, XY, W, P, Q, R, v, K, M, A, a, nip,
                        (int)c->opt_power_iters, (int)split);
     LAUNCH_CHECK(c);
     if (split) {
@@ -1187,7 +1189,6 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
     if (K > (1 << 30) || M > plsk::LM_MAX)
         return fail(h, PLS_HIP_ERR_UNSUPPORTED, "more than 1024 responses (or K > 2^30) not supported on the device");
     if (N > 0 && (!X || !Y || (!T && method == PLS_HIP_KERNEL_TYPE1))) return fail(h, PLS_HIP_ERR_INVALID, "null X/Y/T");
-    if (A > 4096) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "more than 4096 components not supported");
     if ((method == PLS_HIP_KERNEL_TYPE2 || h->opt_algo == PLS_HIP_ALGO_GRAM) && K > 16384)  // (AUTO never picks GRAM there)
         return fail(h, PLS_HIP_ERR_UNSUPPORTED, "KERNEL_TYPE2 keeps a K x K matrix: K <= 16384");
     if (!W || !P || !Q || !R) return fail(h, PLS_HIP_ERR_INVALID, "null W/P/Q/R");

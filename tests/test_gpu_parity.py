@@ -850,6 +850,25 @@ def test_many_components_equals_least_squares(handle, oracle, po, mode):
     assert np.abs(G / np.outer(d, d) - np.eye(20)).max() < 1e-8
 
 
+def test_more_than_4096_components(handle, po):
+    """A > 4096 (hence K > 4096): components are computed strictly in sequence, so the leading ones equal those of a
+    short fit bit for bit, everything stays finite, P^T R = I on the leading block, the leading scores are orthogonal."""
+    torch = _torch()
+    N, K, M, A = 4400, 4200, 1, 4150
+    X = handle.synth_x(0, N, K, 17); Y = handle.synth_y(0, N, M, 17)
+    short = {k: v.clone() for k, v in handle.fit_device(X, Y, 12).items()}; handle.synchronize()
+    out = handle.fit_device(X, Y, A); handle.synchronize()
+    for k in "WPQR":
+        assert torch.equal(out[k][:, :12], short[k]), k
+    assert torch.equal(out["T"][:, :12], short["T"])
+    assert torch.isfinite(out["B"]).all() and torch.isfinite(out["R"][:, :200]).all()
+    P = out["P"][:, :40].cpu().numpy(); R = out["R"][:, :40].cpu().numpy()
+    assert np.allclose(P.T @ R, np.eye(40), atol=1e-7)
+    T = out["T"][:, :40].cpu().numpy()
+    G = T.T @ T; d = np.sqrt(np.diag(G))
+    assert np.abs(G / np.outer(d, d) - np.eye(40)).max() < 1e-8
+
+
 def test_batched_cv_folds_fp32_storage(handle, oracle, po):
     torch = _torch()
     N, K, M, A, ts, nf = 400, 40, 2, 4, 25, 9
