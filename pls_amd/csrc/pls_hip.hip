@@ -447,14 +447,12 @@ int launch_update_large(pls_hip_context *c, const double *red, double *XY, doubl
     const int n = a + 1;
     if (n >= A) return PLS_HIP_OK;
     {  // G = XY^T XY (:405) with the column-reduction kernels: "X" = XY (K rows, M columns), "Y" = XY
-        const bool was = s.on;
         int nb = 0;
         CHK(launch_xty<double>(c, XY, K, XY, K, K, M, M, xpart, &nb));
         CHK(launch_reduce(c, xpart, nb, (int)MM, nullptr, 0, xred));
         hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((unsigned)((MM + plsk::WG - 1) / plsk::WG)), blk, 0, c->stream,
                            (const double *)xred, (int)MM, G);
         LAUNCH_CHECK(c);
-        (void)was;
     }
     // dominant eigenvector: B_0 = G / tr G, B_{j+1} = B_j^2 / tr(B_j^2)
     const dim3 sq((M + 15) / 16, (M + 15) / 16), sqb(16, 16);
@@ -501,6 +499,8 @@ int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, 
             HIPCHK(c, hipMemsetAsync(c->coop.p, 0, c->coop.bytes, c->stream));
         }
         unsigned *cnt = (unsigned *)c->coop.p;
+        // every fit starts from zeroed exchange counters, whatever an earlier (failed) fit left behind
+        if (a < 0) HIPCHK(c, hipMemsetAsync(cnt, 0, 256, c->stream));
         double *qraw = (double *)((char *)c->coop.p + 256), *gpart = qraw + plsk::COOP_MAXG * plsk::COOP_QSTRIDE;
         double *cpart = gpart + plsk::COOP_MAXG * plsk::COOP_GSTRIDE;
         const dim3 grid((K + plsk::COOP_WG - 1) / plsk::COOP_WG), blk(plsk::COOP_WG);
@@ -609,7 +609,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // model (measured rates on MI355X: ~6 TB/s streaming reads, ~60 TFLOP/s executed in the fp64 SYRK of
     // which the symmetric half is computed).  GRAM pays off for A >~ K/50.
     i64 algo = c->opt_algo;
-    const bool have_pre = c->pre_xx && c->pre_xy && K <= 16384;
+    const bool have_pre = c->pre_xx && c->pre_xy && K <= 32768;
     if (algo == PLS_HIP_ALGO_AUTO && have_pre) {
         algo = PLS_HIP_ALGO_GRAM;  // X^T X is already there: the component loop needs no pass over X at all
     } else if (algo == PLS_HIP_ALGO_AUTO) {
@@ -1189,8 +1189,8 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
     if (K > (1 << 30) || M > plsk::LM_MAX)
         return fail(h, PLS_HIP_ERR_UNSUPPORTED, "more than 1024 responses (or K > 2^30) not supported on the device");
     if (N > 0 && (!X || !Y || (!T && method == PLS_HIP_KERNEL_TYPE1))) return fail(h, PLS_HIP_ERR_INVALID, "null X/Y/T");
-    if ((method == PLS_HIP_KERNEL_TYPE2 || h->opt_algo == PLS_HIP_ALGO_GRAM) && K > 16384)  // (AUTO never picks GRAM there)
-        return fail(h, PLS_HIP_ERR_UNSUPPORTED, "KERNEL_TYPE2 keeps a K x K matrix: K <= 16384");
+    if ((method == PLS_HIP_KERNEL_TYPE2 || h->opt_algo == PLS_HIP_ALGO_GRAM) && K > 32768)  // (AUTO never picks GRAM there)
+        return fail(h, PLS_HIP_ERR_UNSUPPORTED, "KERNEL_TYPE2 keeps a K x K matrix and 8 reduction slices of it (77 GB at K = 32768): K <= 32768");
     if (!W || !P || !Q || !R) return fail(h, PLS_HIP_ERR_INVALID, "null W/P/Q/R");
     if (ldx < std::max<i64>(N, 1) || ldy < std::max<i64>(N, 1) || (T && ldt < std::max<i64>(N, 1)))
         return fail(h, PLS_HIP_ERR_INVALID, "leading dimension smaller than N");

@@ -850,6 +850,21 @@ def test_many_components_equals_least_squares(handle, oracle, po, mode):
     assert np.abs(G / np.outer(d, d) - np.eye(20)).max() < 1e-8
 
 
+def test_kernel_type2_beyond_16384_columns(handle, oracle, po):
+    """KERNEL_TYPE2 at K = 20,000 (a 3.2 GB X^T X, 25.6 GB of reduction slices): same B as KERNEL_TYPE1 on the same data
+    and as the oracle's method 1."""
+    import pls_amd
+    N, K, M, A = 96, 20000, 1, 4
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    ref = oracle.plsr(Xh, Yh, A)
+    Bref = oracle.coefficients(ref["R"], ref["Q"])
+    X, Y = to_dev(Xh), to_dev(Yh)
+    o2 = handle.fit_device(X, Y, A, method=pls_amd.KERNEL_TYPE2); handle.synchronize()
+    assert po.rel_fro(o2["B"].cpu().numpy(), Bref) < TOL_B
+    o1 = handle.fit_device(X, Y, A); handle.synchronize()
+    assert po.rel_fro(o1["B"].cpu().numpy(), Bref) < TOL_B
+
+
 def test_more_than_4096_components(handle, po):
     """A > 4096 (hence K > 4096): components are computed strictly in sequence, so the leading ones equal those of a
     short fit bit for bit, everything stays finite, P^T R = I on the leading block, the leading scores are orthogonal."""
