@@ -109,4 +109,41 @@ __global__ __launch_bounds__(UPD_THREADS) void cv_folds_kernel(
     }
 }
 
+// ---- the general form: one refit per fold (pls_hip.hip cv_folds_refit), for shapes the batched kernel declines ----
+// out[i + c*ldo] = X[idx[i] + c*ldx]: the training rows of a fold as a matrix of their own.   grid = (ceil(n/256), <= 1024)
+template <typename T>
+__global__ __launch_bounds__(WG) void gather_rows_kernel(const T *__restrict__ X, i64 ldx, const i64 *__restrict__ idx, i64 n,
+                                                         int cols, T *__restrict__ out, i64 ldo) {
+    const i64 i = (i64)blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const i64 row = idx[i];
+    for (int c = blockIdx.y; c < cols; c += gridDim.y) out[i + (i64)c * ldo] = X[row + (i64)c * ldx];
+}
+
+// Residuals of one fold's test rows under that fold's model (R: K x A, Q: M x A): u_a = x_i . r_a, then the running fit
+// yhat_c = sum_{a<=c} u_a q_a in the order of cv_folds_kernel.   grid = ts workgroups; us = ts*A doubles of scratch.
+__global__ __launch_bounds__(WG) void cv_refit_residuals_kernel(const double *__restrict__ xt, const double *__restrict__ yt,
+                                                                const double *__restrict__ R, const double *__restrict__ Q,
+                                                                int K, int M, int A, int ts, i64 fold, i64 nobs,
+                                                                double *__restrict__ us, double *__restrict__ E) {
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double *x = xt + (i64)i * K;
+    double *u = us + (i64)i * A;
+    for (int a = wv; a < A; a += WG / WAVE) {
+        double s = 0.0;
+        for (int k = lane; k < K; k += WAVE) s = fma(x[k], R[k + (i64)a * K], s);
+        s = wave_sum(s);
+        if (lane == 0) u[a] = s;
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += WG) {
+        double fit = 0.0;
+        const double y = yt[(i64)i * M + m];
+        for (int a = 0; a < A; ++a) {
+            fit = fma(u[a], Q[m + (i64)a * M], fit);
+            E[(i64)m * nobs * A + (fold * ts + i) + (i64)a * nobs] = y - fit;
+        }
+    }
+}
+
 }  // namespace plsk

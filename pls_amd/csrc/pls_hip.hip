@@ -54,7 +54,7 @@ struct pls_hip_context {
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
     i64 opt_fused_grid = 0, opt_work_layout = 1, opt_defer = 1;
-    DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, coop, lm, gxx, gxy, tab, work, cvidx, cvx, cvy, cvws, cve, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
+    DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, coop, lm, gxx, gxy, tab, work, cvidx, cvx, cvy, cvws, cve, cvtx, cvty, cvtt, cvm, cvkeep, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
     std::vector<hipEvent_t> ev_pool;  // grows until pls_hip_get_timing harvests and recycles it
@@ -1060,7 +1060,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
-                      &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->work, &h->hX, &h->hY,
+                      &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->cvtx, &h->cvty, &h->cvtt, &h->cvm, &h->cvkeep, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1513,6 +1513,71 @@ int cv_folds_device(pls_hip_context *h, const T *dX, i64 dldx, const T *dY, i64 
     return PLS_HIP_OK;
 }
 
+// The general form of the same call: one refit per fold on the rows that are not in its test set -- what the reference
+// does (src/pls.cpp:478-488, :524-545), with the training rows gathered on the device and the fit running under the
+// handle's own plan.  Serves the shapes the batched kernel declines (M > 32, A > 4096, K > 16384, a workspace that does
+// not fit); costs num_folds fits.
+template <typename T>
+int cv_folds_refit(pls_hip_context *h, const T *dX, i64 dldx, const T *dY, i64 dldy, i64 N, int Ki, int Mi, int Ai,
+                   const int64_t *test_idx, int ts, i64 num_folds, double *dE) {
+    const i64 nobs = num_folds * ts;
+    const i64 K = Ki, M = Mi, A = Ai;
+    const i64 ldtr = (N + 3) & ~(i64)3;
+    CHK(ensure(h, h->cvidx, (size_t)nobs * 8));
+    CHK(ensure(h, h->cvx, (size_t)nobs * K * 8));
+    CHK(ensure(h, h->cvy, (size_t)nobs * M * 8));
+    CHK(ensure(h, h->cvkeep, (size_t)N * 8));
+    CHK(ensure(h, h->cvtx, (size_t)ldtr * K * sizeof(T)));
+    CHK(ensure(h, h->cvty, (size_t)ldtr * M * sizeof(T)));
+    CHK(ensure(h, h->cvtt, (size_t)ldtr * A * sizeof(T)));
+    CHK(ensure(h, h->cvm, (size_t)(3 * K * A + M * A + (i64)ts * A) * 8));
+    double *Wf = (double *)h->cvm.p, *Pf = Wf + K * A, *Rf = Pf + K * A, *Qf = Rf + K * A, *us = Qf + M * A;
+    HIPCHK(h, hipMemcpyAsync(h->cvidx.p, test_idx, (size_t)nobs * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL((plsk::cv_gather_kernel<T>), dim3((unsigned)nobs), dim3(plsk::WG), 0, h->stream, dX, dldx, dY,
+                       dldy, Ki, Mi, (const i64 *)h->cvidx.p, (double *)h->cvx.p, (double *)h->cvy.p);
+    LAUNCH_CHECK(h);
+    const double *saved_xx = h->pre_xx, *saved_xy = h->pre_xy;  // products of ALL rows: not a fold's
+    h->pre_xx = h->pre_xy = nullptr;
+    std::vector<char> held(N, 0);
+    std::vector<int64_t> keep(N);
+    int rc = PLS_HIP_OK;
+    for (i64 f = 0; f < num_folds && rc == PLS_HIP_OK; ++f) {
+        for (int i = 0; i < ts; ++i) held[test_idx[f * ts + i]] = 1;
+        i64 ntr = 0;
+        for (i64 r = 0; r < N; ++r)
+            if (!held[r]) keep[ntr++] = r;
+        for (int i = 0; i < ts; ++i) held[test_idx[f * ts + i]] = 0;
+        if (ntr < 1 || A > K) { rc = fail(h, PLS_HIP_ERR_INVALID, "cv_folds: a fold leaves no training rows"); break; }
+        if (hipMemcpyAsync(h->cvkeep.p, keep.data(), (size_t)ntr * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+            rc = fail(h, PLS_HIP_ERR_DEVICE, "cv_folds: upload of the training row list failed");
+            break;
+        }
+        const unsigned gx = (unsigned)((ntr + plsk::WG - 1) / plsk::WG);
+        hipLaunchKernelGGL((plsk::gather_rows_kernel<T>), dim3(gx, (unsigned)std::min<i64>(K, 1024)), dim3(plsk::WG), 0, h->stream,
+                           dX, dldx, (const i64 *)h->cvkeep.p, ntr, Ki, (T *)h->cvtx.p, ldtr);
+        hipLaunchKernelGGL((plsk::gather_rows_kernel<T>), dim3(gx, (unsigned)std::min<i64>(M, 1024)), dim3(plsk::WG), 0, h->stream,
+                           dY, dldy, (const i64 *)h->cvkeep.p, ntr, Mi, (T *)h->cvty.p, ldtr);
+        rc = fit_device<T>(h, (const T *)h->cvtx.p, ldtr, (const T *)h->cvty.p, ldtr, ntr, Ki, Mi, Ai, PLS_HIP_KERNEL_TYPE1,
+                           Wf, Pf, Qf, Rf, (T *)h->cvtt.p, ldtr, nullptr);
+        if (rc != PLS_HIP_OK) break;
+        hipLaunchKernelGGL(plsk::cv_refit_residuals_kernel, dim3((unsigned)ts), dim3(plsk::WG), 0, h->stream,
+                           (const double *)h->cvx.p + f * ts * K, (const double *)h->cvy.p + f * ts * M, (const double *)Rf,
+                           (const double *)Qf, Ki, Mi, Ai, ts, f, nobs, us, dE);
+        // `keep` is rewritten for the next fold: its copy must have been consumed
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+            rc = fail(h, PLS_HIP_ERR_DEVICE, "cv_folds: a fold's refit failed on the device");
+    }
+    h->pre_xx = saved_xx;
+    h->pre_xy = saved_xy;
+    return rc;
+}
+
+// the batched kernel's shapes (cv_kernels.hpp): everything M-sized in one workgroup's LDS, X^T X resident
+bool cv_batched_covers(i64 K, i64 M, i64 A) {
+    const bool force_refit = getenv("PLS_HIP_CV_REFIT") && atoi(getenv("PLS_HIP_CV_REFIT")) != 0;
+    return !force_refit && A <= 4096 && K <= 16384 && (M == 1 || M <= plsk::MMAX);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1524,10 +1589,11 @@ int pls_hip_cv_folds(pls_hip_handle h, const void *X, int64_t ldx, const void *Y
     if (dtype != PLS_HIP_F64 && dtype != PLS_HIP_F32) return fail(h, PLS_HIP_ERR_INVALID, "bad dtype");
     if (mem != PLS_HIP_MEM_HOST && mem != PLS_HIP_MEM_DEVICE) return fail(h, PLS_HIP_ERR_INVALID, "bad mem kind");
     if (h->reducer) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "cv_folds: not available on a sharded handle");
-    if (N < 2 || K < 1 || M < 1 || A < 1 || A > K || A > 4096 || K > 16384 || (M > 1 && M > plsk::MMAX) || !X || !Y ||
+    if (N < 2 || K < 1 || M < 1 || A < 1 || A > K || K > (1 << 30) || !X || !Y ||
         !test_idx || !E || test_size < 1 || test_size >= N || num_folds < 1 || ldx < N || ldy < N ||
         num_folds > (1 << 22) || test_size > (1 << 20))
         return fail(h, PLS_HIP_ERR_INVALID, "bad cv_folds arguments");
+    if (M > plsk::LM_MAX) return fail(h, PLS_HIP_ERR_UNSUPPORTED, "more than 1024 responses not supported on the device");
     const i64 nobs = num_folds * test_size;
     for (i64 j = 0; j < nobs; ++j)
         if (test_idx[j] < 0 || test_idx[j] >= N) return fail(h, PLS_HIP_ERR_INVALID, "cv_folds: test index out of range");
@@ -1546,13 +1612,24 @@ int pls_hip_cv_folds(pls_hip_handle h, const void *X, int64_t ldx, const void *Y
     }
     CHK(ensure(h, h->cve, (size_t)nobs * A * M * 8));
     double *dE = (mem == PLS_HIP_MEM_HOST) ? (double *)h->cve.p : E;
-    int rc;
-    if (dtype == PLS_HIP_F64)
-        rc = cv_folds_device<double>(h, (const double *)dX, dldx, (const double *)dY, dldy, N, (int)K, (int)M, (int)A,
-                                     test_idx, (int)test_size, num_folds, dE);
-    else
-        rc = cv_folds_device<float>(h, (const float *)dX, dldx, (const float *)dY, dldy, N, (int)K, (int)M, (int)A,
-                                    test_idx, (int)test_size, num_folds, dE);
+    int rc = PLS_HIP_ERR_ALLOC;
+    if (cv_batched_covers(K, M, A)) {
+        if (dtype == PLS_HIP_F64)
+            rc = cv_folds_device<double>(h, (const double *)dX, dldx, (const double *)dY, dldy, N, (int)K, (int)M, (int)A,
+                                         test_idx, (int)test_size, num_folds, dE);
+        else
+            rc = cv_folds_device<float>(h, (const float *)dX, dldx, (const float *)dY, dldy, N, (int)K, (int)M, (int)A,
+                                        test_idx, (int)test_size, num_folds, dE);
+    }
+    if (rc == PLS_HIP_ERR_ALLOC) {  // declined, or the per-fold workspaces of the batched form do not fit: one refit per fold
+        h->err.clear();
+        if (dtype == PLS_HIP_F64)
+            rc = cv_folds_refit<double>(h, (const double *)dX, dldx, (const double *)dY, dldy, N, (int)K, (int)M, (int)A,
+                                        test_idx, (int)test_size, num_folds, dE);
+        else
+            rc = cv_folds_refit<float>(h, (const float *)dX, dldx, (const float *)dY, dldy, N, (int)K, (int)M, (int)A,
+                                       test_idx, (int)test_size, num_folds, dE);
+    }
     if (rc != PLS_HIP_OK) return rc;
     if (mem == PLS_HIP_MEM_HOST)
         HIPCHK(h, hipMemcpyAsync(E, dE, (size_t)nobs * A * M * 8, hipMemcpyDeviceToHost, h->stream));

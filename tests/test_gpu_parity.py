@@ -884,6 +884,53 @@ def test_more_than_4096_components(handle, po):
     assert np.abs(G / np.outer(d, d) - np.eye(40)).max() < 1e-8
 
 
+def _fold_reference(oracle, Xh, Yh, A, idx):
+    nf, ts = idx.shape
+    ref = np.zeros((Yh.shape[1], nf * ts, A))
+    N = Xh.shape[0]
+    for f in range(nf):
+        train = np.setdiff1d(np.arange(N), idx[f])
+        c = oracle.plsr(Xh[train], Yh[train], A)
+        for nc in range(1, A + 1):
+            ref[:, f * ts:(f + 1) * ts, nc - 1] = (Yh[idx[f]] - Xh[idx[f]] @ oracle.coefficients(c["R"], c["Q"], nc)).T
+    return ref
+
+
+@pytest.mark.parametrize("N,K,M,A,ts,nf,dt", [(60, 24, 1, 6, 1, 60, "f64"), (200, 24, 3, 5, 60, 7, "f64"), (301, 33, 2, 4, 17, 5, "f32")])
+def test_cv_folds_refit_per_fold(handle, oracle, po, monkeypatch, N, K, M, A, ts, nf, dt):
+    """The general form of pls_hip_cv_folds (one device refit per fold, the reference's own procedure,
+    src/pls.cpp:478-488,:524-545) against the oracle and against the batched launch on the same folds."""
+    torch = _torch()
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    if dt == "f32":
+        Xh = np.asfortranarray(Xh.astype(np.float32).astype(np.float64)); Yh = np.asfortranarray(Yh.astype(np.float32).astype(np.float64))
+    dtype = np.float64 if dt == "f64" else np.float32
+    rng = np.random.default_rng(11)
+    idx = np.arange(N)[:, None] if ts == 1 and nf == N else np.stack([rng.permutation(N)[:ts] for _ in range(nf)])
+    Xd, Yd = to_dev(Xh.astype(dtype)), to_dev(Yh.astype(dtype))
+    batched = handle.cv_folds(Xd, Yd, A, idx).cpu().numpy()
+    monkeypatch.setenv("PLS_HIP_CV_REFIT", "1")
+    refit = handle.cv_folds(Xd, Yd, A, idx).cpu().numpy()
+    refit_host = handle.cv_folds(np.asfortranarray(Xh.astype(dtype)), np.asfortranarray(Yh.astype(dtype)), A, idx)
+    monkeypatch.delenv("PLS_HIP_CV_REFIT")
+    ref = _fold_reference(oracle, Xh, Yh, A, idx)
+    tol = (1e-8 if dt == "f64" else 2e-4) * max(np.abs(ref).max(), 1.0)   # fp32: the refit stores its scores in fp32
+    assert np.abs(refit - ref).max() < tol
+    assert np.abs(refit_host - refit).max() < 1e-12
+    assert np.abs(refit - batched).max() < tol
+
+
+def test_cv_folds_many_responses(handle, oracle, po):
+    """M = 40 responses: beyond the batched fold kernel (M <= 32), served by one refit per fold."""
+    N, K, M, A, ts, nf = 150, 50, 40, 3, 30, 4
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    rng = np.random.default_rng(5)
+    idx = np.stack([rng.permutation(N)[:ts] for _ in range(nf)])
+    E = handle.cv_folds(to_dev(Xh), to_dev(Yh), A, idx).cpu().numpy()
+    ref = _fold_reference(oracle, Xh, Yh, A, idx)
+    assert np.abs(E - ref).max() < 1e-8 * max(np.abs(ref).max(), 1.0)
+
+
 def test_batched_cv_folds_fp32_storage(handle, oracle, po):
     torch = _torch()
     N, K, M, A, ts, nf = 400, 40, 2, 4, 25, 9
