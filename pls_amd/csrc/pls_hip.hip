@@ -21,6 +21,7 @@
 #include "small_kernels.hpp"
 #include "coop_update.hpp"
 #include "largem_kernels.hpp"
+#include "tiny_kernels.hpp"
 #include "stream_kernels.hpp"
 #include "syrk_kernels.hpp"
 #include "cv_kernels.hpp"
@@ -626,6 +627,21 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     const bool nipals = !type2 && (algo == PLS_HIP_ALGO_NIPALS);
     const int nip = nipals ? 1 : 0;
     const i64 L0 = (i64)K * M;
+    // A single-response problem small enough for one workgroup's registers: the whole fit in ONE launch (tiny_kernels.hpp) instead of
+    // three launches per component, whose dispatch latency would be the entire cost.  The reference's sequence, so the
+    // KERNEL plan (and AUTO); an explicit NIPALS or GRAM request keeps its own kernels.
+    if (!type2 && !nipals && c->opt_fuse && !c->reducer && plsk::tiny_fit_covers(N, K, M, A, ldx, sizeof(T)) &&
+        !(getenv("PLS_HIP_TINY") && atoi(getenv("PLS_HIP_TINY")) == 0)) {
+        const size_t lds = (size_t)2 * K * A * 8;
+        if (!plsk::raise_dynamic_lds((const void *)plsk::tiny_fit_kernel<T>, lds))
+            return fail(c, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the single-launch fit could not be raised");
+        Range r_fit("pls_hip_fit (single launch)");
+        Scope s(c, PLS_HIP_FAM_SMALL, ((i64)N * K + (i64)N * M + (i64)N * A) * (i64)sizeof(T) + (3 * (i64)K + M) * A * 8);
+        hipLaunchKernelGGL((plsk::tiny_fit_kernel<T>), dim3(1), dim3(plsk::UPD_THREADS), lds, c->stream, X, ldx, Y, (int)N, K, A,
+                           W, P, Q, R, Tm, ldt, B);
+        LAUNCH_CHECK(c);
+        return PLS_HIP_OK;
+    }
     const i64 redn = (i64)plsk::RED_SLICES * std::max<i64>(L0, K + 1);
     const i64 prow = max_partial_rows(c, N, K);
     CHK(ensure(c, c->part, (size_t)prow * (size_t)std::max<i64>(L0, K) * 8));

@@ -1,0 +1,198 @@
+// The whole fit of a SMALL single-response problem in one launch (BASELINE config 2: 60 x 401, one response).  The
+// regular plan spends three launches per component; below a few hundred kilobytes of X their dispatch latency is the
+// entire cost (config 2: 185 us for ten components, one CPU core does the fit in 103 us).  Here ONE workgroup of 1024
+// threads keeps X in REGISTERS for the life of the fit and everything K-sized (XY, w, and the P and R columns the
+// r recurrence walks) in LDS, and runs the reference's loop (src/pls.cpp:396-434) without leaving the kernel.
+// M = 1 only: the direction is w = XY / |XY| (:404), no eigenproblem.  (A first form that called component_update_body
+// for any M <= 32 spent 20 us per component in the scratch spills of that body next to the resident X.)
+//
+// Layout: lane = row inside a 64-row block, a wave = (row block rb, column slice s); the thread of row i and slice s
+// holds X[i, s + j*S], j < TINY_RC.  With wps = ceil(N/64) waves per slice there are S = 16 / wps slices, so the
+// kernel takes N <= 1024 and K <= S * TINY_RC (N <= 64: K <= 448; N <= 128: K <= 224; ...).
+//   t_i   = sum over the S slices of the per-thread partial sum_j x[j] r[s + j*S]           (LDS, fixed order)
+//   p_raw = column sums of x[j] * t_i over the rows: wave_multi_sum inside the wave, then the wps waves of a slice in order
+// Every sum has a fixed order: equal inputs give equal bits.
+#pragma once
+#include "fused_kernels.hpp"  // raw buffer descriptors
+#include "small_kernels.hpp"
+
+namespace plsk {
+
+constexpr int TINY_RC = 26;       // X values a thread keeps (52 VGPRs of the 128 a 1024-thread workgroup leaves per lane)
+constexpr int TINY_HALF = TINY_RC / 2;
+constexpr int TINY_KMAX = UPD_WAVES * TINY_RC;
+
+struct TinyShape {
+    int wps, S;  // waves per column slice, column slices
+    __host__ __device__ explicit TinyShape(int N) : wps((N + WAVE - 1) / WAVE), S(wps > 0 && wps <= UPD_WAVES ? UPD_WAVES / wps : 0) {}
+};
+
+// one X value through the buffer descriptor: a lane offset that never changes plus a wave-uniform column offset, so the
+// TINY_RC loads in flight cost no address registers; out of range (rows beyond N, columns beyond K) reads as 0
+template <typename T>
+__device__ __forceinline__ double tiny_ld(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    if constexpr (sizeof(T) == 8) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        double d;
+        __builtin_memcpy(&d, &raw, 8);
+        return d;
+    } else {
+        const unsigned raw = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+        float f;
+        __builtin_memcpy(&f, &raw, 4);
+        return (double)f;
+    }
+}
+
+constexpr size_t TINY_LDS_MAX = 96 * 1024;  // dynamic LDS: the P and R columns, 2 * K * A doubles
+inline bool tiny_fit_covers(i64 N, int K, int M, int A, i64 ldx, size_t es) {
+    if (M != 1 || N < 1 || N > UPD_THREADS || A > K || (i64)TINY_KMAX * ldx * (i64)es >= (1 << 30)) return false;  // 32-bit byte offsets
+    const TinyShape sh((int)N);
+    return sh.S >= 1 && K <= sh.S * TINY_RC && (size_t)2 * K * A * 8 <= TINY_LDS_MAX;
+}
+
+// Workgroup barrier for data exchanged through LDS ONLY.  __syncthreads() is a workgroup-scope fence as well: the
+// compiler puts s_waitcnt vmcnt(0) in front of it, i.e. every barrier that follows a global store (T, P, W, R, Q are
+// stored as they are produced) waits for the store's acknowledgement from L2 -- 1-2 us each, five times per
+// component.  Nothing this kernel stores to global memory is read back, so the barrier only has to order LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// block_sum (common.hpp) on lds_barrier
+__device__ __forceinline__ double tiny_block_sum(double v, double *smem) {
+    v = wave_sum(v);
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+    lds_barrier();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < UPD_WAVES; ++w) t += smem[w];
+    return t;
+}
+
+// out[k] = sum over the rows of x[.] * f for the column k of every (slice, j); all threads of the workgroup call it
+__device__ __forceinline__ void tiny_column_sums(const double (&x)[TINY_RC], double f, double (*colp)[TINY_RC], int K,
+                                                 const TinyShape &shp, double *out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    lds_barrier();  // the previous use of colp has been read
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        double vals[TINY_HALF];
+#pragma unroll
+        for (int j = 0; j < TINY_HALF; ++j) vals[j] = x[c * TINY_HALF + j] * f;
+        bool valid = true;
+        const int idx = wave_multi_sum<TINY_HALF, 32>(vals, lane, valid);
+        if (valid) colp[wv][c * TINY_HALF + idx] = vals[0];
+    }
+    lds_barrier();
+    for (int k = threadIdx.x; k < K; k += UPD_THREADS) {
+        const int s = k % shp.S, j = k / shp.S;
+        double t = 0.0;
+        for (int w = 0; w < shp.wps; ++w) t += colp[s * shp.wps + w][j];
+        out[k] = t;
+    }
+}
+
+// X: N x K (ld ldx), Y: N x 1; W, P, R: K x A; Q: 1 x A; Tm: N x A (ld ldt); B: K x 1 or null.
+// Dynamic LDS: 2 * K * A doubles.  grid = 1.
+template <typename T>
+__global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restrict__ X, i64 ldx, const T *__restrict__ Y, int N,
+                                                               int K, int A, double *__restrict__ W, double *__restrict__ P,
+                                                               double *__restrict__ Q, double *__restrict__ R,
+                                                               T *__restrict__ Tm, i64 ldt, double *__restrict__ B) {
+    extern __shared__ double dyn[];
+    double *Pl = dyn, *Rl = dyn + (i64)K * A;  // P[:, j], R[:, j] as they are produced
+    __shared__ double tp[UPD_THREADS], colp[UPD_WAVES][TINY_RC], praw[TINY_KMAX], xy[TINY_KMAX], wl[TINY_KMAX], vsl[TINY_KMAX];
+    __shared__ double cs[TINY_KMAX], ql[TINY_KMAX], sred[UPD_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const TinyShape shp(N);
+    const int s = wv / shp.wps, rb = wv % shp.wps, i = rb * WAVE + lane;
+    const bool act = s < shp.S && i < N;
+    const int k = tid;  // the column this thread owns in everything K-sized (K <= 448)
+    const bool kok = k < K;
+    // r in slice-major order, vsl[s*TINY_RC + j] = r[s + j*S]: one LDS base address per thread and immediate
+    // offsets (indexed as r[s + j*S] the compiler keeps 28 addresses per lane -- and spills them)
+    const int slot = (k % shp.S) * TINY_RC + k / shp.S;
+
+    const uint32_t nrec = (uint32_t)(((i64)(K - 1) * ldx + N) * (i64)sizeof(T));  // < 2^30 (tiny_fit_covers)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X), (short)0, (int)nrec, BUF_WORD3);
+    const uint32_t voff = act ? (uint32_t)((i + (i64)s * ldx) * (i64)sizeof(T)) : 0x80000000u;
+    const uint32_t cstep = (uint32_t)((i64)shp.S * ldx * (i64)sizeof(T));
+    double x[TINY_RC];
+#pragma unroll
+    for (int j = 0; j < TINY_RC; ++j) x[j] = tiny_ld<T>(rs, voff, (uint32_t)j * cstep);
+    for (int c = tid; c < TINY_KMAX; c += UPD_THREADS) vsl[c] = 0.0;  // read (times x = 0) beyond K
+
+    tiny_column_sums(x, act ? (double)Y[i] : 0.0, colp, K, shp, xy);  // XY = X^T Y (:396)
+    lds_barrier();
+    double xyk = kok ? xy[k] : 0.0;
+    {  // w_0 = XY / |XY| (:404, :411), r_0 = w_0
+        const double w = xyk / sqrt(tiny_block_sum(xyk * xyk, sred));
+        if (kok) {
+            W[k] = w;
+            R[k] = w;
+            Rl[k] = w;
+            vsl[slot] = w;
+        }
+    }
+    const double *vs = vsl + s * TINY_RC;
+    for (int a = 0; a < A; ++a) {
+        lds_barrier();  // r_a complete
+        double acc = 0.0;  // t = X r (:419)
+#pragma unroll
+        for (int j = 0; j < TINY_RC; ++j) {
+            acc = fma(x[j], vs[j], acc);
+            if (j % 8 == 7) asm volatile("" ::: "memory");  // at most 8 values of r in registers next to the 26 of X
+        }
+        tp[tid] = acc;
+        lds_barrier();
+        double ti = 0.0;
+        if (act)
+            for (int q = 0; q < shp.S; ++q) ti += tp[(q * shp.wps + rb) * WAVE + lane];
+        if (act && s == 0) Tm[i + (i64)a * ldt] = (T)ti;
+        const double tt = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // (:420)
+        tiny_column_sums(x, ti, colp, K, shp, praw);                                    // X^T t (:427)
+        lds_barrier();
+        const double p = kok ? praw[k] / tt : 0.0;                                                        // (:427)
+        const double q = tiny_block_sum(kok ? Rl[k + (i64)a * K] * xyk : 0.0, sred) / tt;          // q = r^T XY / tt (:428)
+        if (kok) {
+            P[k + (i64)a * K] = p;
+            Pl[k + (i64)a * K] = p;
+        }
+        if (tid == 0) {
+            Q[a] = q;
+            ql[a] = q;
+        }
+        xyk -= (p * q) * tt;  // XY -= (p q^T) tt (:429)
+        const int n = a + 1;
+        if (n >= A) break;
+        const double w = xyk / sqrt(tiny_block_sum(xyk * xyk, sred));  // (:404, :411)
+        if (kok) {
+            W[k + (i64)n * K] = w;
+            wl[k] = w;
+        }
+        lds_barrier();
+        for (int j = wv; j < n; j += UPD_WAVES) {  // c_j = p_j^T w, against the ORIGINAL w (:415)
+            double c = 0.0;
+            for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
+            c = wave_sum(c);
+            if (lane == 0) cs[j] = c;
+        }
+        lds_barrier();
+        double r = w;
+        for (int j = 0; j < n; ++j) r -= cs[j] * Rl[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
+        if (kok) {
+            R[k + (i64)n * K] = r;
+            Rl[k + (i64)n * K] = r;
+            vsl[slot] = r;
+        }
+    }
+    lds_barrier();
+    if (B && kok) {  // B = R Q^T (:444-451)
+        double b = 0.0;
+        for (int a = 0; a < A; ++a) b = fma(Rl[k + (i64)a * K], ql[a], b);
+        B[k] = b;
+    }
+}
+
+}  // namespace plsk

@@ -884,6 +884,48 @@ def test_more_than_4096_components(handle, po):
     assert np.abs(G / np.outer(d, d) - np.eye(40)).max() < 1e-8
 
 
+@pytest.mark.parametrize("N,K,A,dt,pad", [(60, 401, 10, "f64", 0), (64, 416, 12, "f64", 3), (10, 15, 3, "f64", 0), (65, 200, 8, "f64", 1),
+                                          (130, 120, 9, "f64", 0), (1024, 26, 6, "f64", 0), (1000, 20, 6, "f32", 8), (1, 5, 1, "f64", 0)])
+def test_single_launch_fit(handle, oracle, po, N, K, A, dt, pad):
+    """Small single-response fits run as ONE launch (tiny_kernels.hpp): X in registers, everything K-sized in LDS.
+    Every row-block / column-slice shape of that kernel (N <= 64 ... 1024), a padded leading dimension, fp32 storage;
+    results against the oracle, and against the three-launches-per-component plan (PLS_HIP_TINY=0)."""
+    import pls_amd
+    torch = _torch()
+    if K == 401:
+        Xh = oracle.z_scores(po.read_csv(os.path.join(DATA, "nir.csv"))); Yh = oracle.z_scores(po.read_csv(os.path.join(DATA, "octane.csv")))
+    else:
+        Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, 1)
+    dtype = np.float64 if dt == "f64" else np.float32
+    if dt == "f32":
+        Xh = np.asfortranarray(Xh.astype(np.float32).astype(np.float64)); Yh = np.asfortranarray(Yh.astype(np.float32).astype(np.float64))
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    Xbig = torch.zeros((K, N + pad), dtype=torch.float64 if dt == "f64" else torch.float32, device="cuda")
+    Xbig[:, :N] = torch.from_numpy(np.ascontiguousarray(Xh.T.astype(dtype))).cuda()
+    Xd = Xbig.T[:N]                                   # column-major view, ld = N + pad
+    Yd = to_dev(Yh.astype(dtype))
+    handle.set_option(pls_amd.OPT_PROFILE, 2)
+    try:
+        handle.timing()
+        out = handle.fit_device(Xd, Yd, A)
+        torch.cuda.synchronize()
+        t = handle.timing()
+        assert sum(t["launches"].values()) == 1, t["launches"]
+        os.environ["PLS_HIP_TINY"] = "0"
+        try:
+            plain = handle.fit_device(Xd, Yd, A)
+            torch.cuda.synchronize()
+            assert sum(handle.timing()["launches"].values()) > 1
+        finally:
+            del os.environ["PLS_HIP_TINY"]
+    finally:
+        handle.set_option(pls_amd.OPT_PROFILE, 0)
+    tol = dict(tol_b=1e-10, tol_col=1e-9) if dt == "f64" else dict(tol_b=2e-5, tol_col=2e-4, tol_inv=1e-3)
+    check_against(po, out, ref, Bref, Tref=ref["T"], col_err=cerr, **tol)
+    for k in "WPQRB":
+        assert np.abs(out[k].cpu().numpy() - plain[k].cpu().numpy()).max() < (1e-9 if dt == "f64" else 1e-4)
+
+
 def _fold_reference(oracle, Xh, Yh, A, idx):
     nf, ts = idx.shape
     ref = np.zeros((Yh.shape[1], nf * ts, A))
