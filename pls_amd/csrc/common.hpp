@@ -61,11 +61,48 @@ __device__ __forceinline__ double shfl_xor_f64(double x, int mask) {
     return __hiloint2double(hi, lo);
 }
 
-// butterfly sum over the 64 lanes of a wave: every lane ends with the same bits
+// ---- cross-lane exchanges on the VALU (gfx950): DPP moves inside a row of 16 lanes, v_permlane{16,32}_swap across rows.
+// __shfl_xor compiles to ds_bpermute_b32 -- an LDS-crossbar round trip of ~100 cycles per 32-bit half; the forms below are
+// ordinary vector instructions.  dpp_ctrl: 0xB1 / 0x4E quad_perm [1,0,3,2] / [2,3,0,1] (lane ^ 1, lane ^ 2),
+// 0x141 row_half_mirror (l <-> 7-l inside 8 lanes), 0x140 row_mirror (l <-> 15-l inside a row).  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// a, b -> (a', b'): ROWS16 = false: a' = [a.lanes 0-31, b.lanes 0-31], b' = [a.lanes 32-63, b.lanes 32-63] (v_permlane32_swap);
+// ROWS16 = true: the same with the odd 16-lane rows of a and the even rows of b (v_permlane16_swap).  Either way
+// a' + b' = (a + a's partner across the split) in the lanes below the split, (b + b's partner) in the lanes above it.
+template <bool ROWS16>
+__device__ __forceinline__ void permlane_swap_f64(double &a, double &b) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    u32x2 l, h;
+    if constexpr (ROWS16) {
+        l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    } else {
+        l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    }
+    a = __hiloint2double((int)h.x, (int)l.x);
+    b = __hiloint2double((int)h.y, (int)l.y);
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+// Sum over the 64 lanes, every lane (and the scalar unit) ends with the same bits: four DPP levels give every row of 16 its
+// total, the four row totals are read as scalars and added in row order.  (The ds_bpermute butterfly this replaces cost
+// six dependent LDS round trips: config 2's single-launch fit 93 -> 63 us, profiles/r2/small_fits.json.)
 __device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) x += shfl_xor_f64(x, m);
-    return x;
+    x += dpp_mov_f64<0xB1>(x);
+    x += dpp_mov_f64<0x4E>(x);
+    x += dpp_mov_f64<0x141>(x);
+    x += dpp_mov_f64<0x140>(x);
+    return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
 }
 
 // Sum over a workgroup of NW waves (blockDim.x = 64*NW); result valid in every thread.

@@ -182,26 +182,41 @@ __device__ __forceinline__ void dominant_eigvec_wave(const double *G, double *Bm
 // at every level the two partner lanes split the remaining values between them, each keeping the sum of
 // its half.  Returns the index of the value whose total ends in g[0] of this lane (valid == false: none).
 // Every total is a fixed butterfly tree over the lanes, so equal inputs give equal bits.
-template <int N, int MASK>
-__device__ __forceinline__ int wave_multi_sum(double *g, int lane, bool &valid) {
-    if constexpr (MASK == 0) {
+// All exchanges are VALU operations (common.hpp; no LDS crossbar).  Levels: lanes 32 apart (v_permlane32_swap), 16 apart
+// (v_permlane16_swap), then row_mirror, row_half_mirror, lane ^ 2, lane ^ 1 -- the two mirrors pair lanes that differ in
+// SEVERAL low bits, which is only legal while those bits have not been used to split the values yet, hence this order.
+// The two swap levels need no select at all: the swap itself hands the kept half and the received half to the adder.
+template <int N, int LEVEL>
+__device__ __forceinline__ int wave_multi_sum_levels(double *g, int lane, bool &valid) {
+    if constexpr (LEVEL == 6) {
         return 0;
-    } else if constexpr (N == 1) {
-        g[0] += shfl_xor_f64(g[0], MASK);
-        return wave_multi_sum<1, MASK / 2>(g, lane, valid);
     } else {
         constexpr int H = (N + 1) / 2;
-        const bool up = (lane & MASK) != 0;
+        constexpr int BIT = LEVEL == 0 ? 32 : LEVEL == 1 ? 16 : LEVEL == 2 ? 8 : LEVEL == 3 ? 4 : LEVEL == 4 ? 2 : 1;
+        const bool up = (lane & BIT) != 0;
 #pragma unroll
         for (int i = 0; i < H; ++i) {
-            const double lo = g[i], hi = (i + H < N) ? g[i + H] : 0.0;
-            const double keep = up ? hi : lo, send = up ? lo : hi;
-            g[i] = keep + shfl_xor_f64(send, MASK);
+            double lo = g[i], hi = (N > 1) ? ((i + H < N) ? g[i + H] : 0.0) : g[i];
+            if constexpr (LEVEL <= 1) {
+                permlane_swap_f64<LEVEL == 1>(lo, hi);
+                g[i] = lo + hi;
+            } else {
+                const double keep = (N > 1 && up) ? hi : lo, send = (N > 1 && up) ? lo : hi;
+                constexpr int CTRL = LEVEL == 2 ? 0x140 : LEVEL == 3 ? 0x141 : LEVEL == 4 ? 0x4E : 0xB1;
+                g[i] = keep + dpp_mov_f64<CTRL>(send);
+            }
         }
-        const int idx = wave_multi_sum<H, MASK / 2>(g, lane, valid) + (up ? H : 0);
+        const int idx = wave_multi_sum_levels<H, LEVEL + 1>(g, lane, valid) + ((N > 1 && up) ? H : 0);
         valid = valid && (idx < N);
         return idx;
     }
+}
+
+// MASK: kept from the first form of this function (the lane distance of the first level); always 32
+template <int N, int MASK>
+__device__ __forceinline__ int wave_multi_sum(double *g, int lane, bool &valid) {
+    static_assert(MASK == 32, "whole-wave sums");
+    return wave_multi_sum_levels<N, 0>(g, lane, valid);
 }
 
 // g[pair(i,j)] += x[i] x[j] for i <= j, pairs numbered row by row (compile-time indices: g stays in registers)
