@@ -54,13 +54,6 @@ __device__ __forceinline__ void st_pack_nt(T *p, const Pack<T, V> &x) {
     __builtin_nontemporal_store(r, reinterpret_cast<VT *>(p));
 }
 
-__device__ __forceinline__ double shfl_xor_f64(double x, int mask) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __shfl_xor(lo, mask, WAVE);
-    hi = __shfl_xor(hi, mask, WAVE);
-    return __hiloint2double(hi, lo);
-}
-
 // ---- cross-lane exchanges on the VALU (gfx950): DPP moves inside a row of 16 lanes, v_permlane{16,32}_swap across rows.
 // __shfl_xor compiles to ds_bpermute_b32 -- an LDS-crossbar round trip of ~100 cycles per 32-bit half; the forms below are
 // ordinary vector instructions.  dpp_ctrl: 0xB1 / 0x4E quad_perm [1,0,3,2] / [2,3,0,1] (lane ^ 1, lane ^ 2),
@@ -94,6 +87,35 @@ __device__ __forceinline__ void permlane_swap_f64(double &a, double &b) {
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
 }
+// x + (x of lane ^ MASK): one level of a butterfly.  MASK 32 / 16: the permlane swap of (x, x); 8: row_ror:8; 4: row_shl:4 for
+// the lanes with bit 2 clear (banks 0, 2) and row_shr:4 for the others; 2 / 1: quad_perm.
+template <int MASK>
+__device__ __forceinline__ double xor_add_f64(double x) {
+    static_assert(MASK == 32 || MASK == 16 || MASK == 8 || MASK == 4 || MASK == 2 || MASK == 1, "lane distance");
+    if constexpr (MASK >= 16) {
+        double a = x, b = x;
+        permlane_swap_f64<MASK == 16>(a, b);
+        return a + b;
+    } else if constexpr (MASK == 4) {
+        const int lo = __double2loint(x), hi = __double2hiint(x);
+        int rl = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xf, 0x5, false), rh = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xf, 0x5, false);
+        rl = __builtin_amdgcn_update_dpp(rl, lo, 0x114, 0xf, 0xa, false);
+        rh = __builtin_amdgcn_update_dpp(rh, hi, 0x114, 0xf, 0xa, false);
+        return x + __hiloint2double(rh, rl);
+    } else {
+        return x + dpp_mov_f64<MASK == 8 ? 0x128 : (MASK == 2 ? 0x4E : 0xB1)>(x);
+    }
+}
+// sum over the lanes that differ in the bits LO, 2 LO, ... below HI (powers of two), every lane of the group ends with it
+template <int LO, int HI>
+__device__ __forceinline__ double xor_range_sum(double x) {
+    if constexpr (LO >= HI) {
+        return x;
+    } else {
+        return xor_range_sum<LO * 2, HI>(xor_add_f64<LO>(x));
+    }
+}
+
 // Sum over the 64 lanes, every lane (and the scalar unit) ends with the same bits: four DPP levels give every row of 16 its
 // total, the four row totals are read as scalars and added in row order.  (The ds_bpermute butterfly this replaces cost
 // six dependent LDS round trips: config 2's single-launch fit 93 -> 63 us, profiles/r2/small_fits.json.)

@@ -106,8 +106,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (ST ? 1 : 2)) void fused_defer_ker
         }
 #pragma unroll
         for (int e = 0; e < V; ++e)
-#pragma unroll
-            for (int m = RP; m < WAVE; m <<= 1) tp2[e] += shfl_xor_f64(tp2[e], m);
+            tp2[e] = xor_range_sum<RP, WAVE>(tp2[e]);
         if (lane < RP)
 #pragma unroll
             for (int e = 0; e < V; ++e) tred[buf][wv][rp * V + e] = tp2[e];
@@ -141,9 +140,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (ST ? 1 : 2)) void fused_defer_ker
     }
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        double s = pacc[j];
-#pragma unroll
-        for (int m = 1; m < RP; m <<= 1) s += shfl_xor_f64(s, m);
+        const double s = xor_range_sum<1, RP>(pacc[j]);
         const int k = cg + CG * j;
         if (rp == 0 && k < K) part[(i64)blockIdx.x * K + k] = s;
     }

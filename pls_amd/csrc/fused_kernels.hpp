@@ -178,8 +178,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
         }
 #pragma unroll
         for (int e = 0; e < V; ++e)
-#pragma unroll
-            for (int m = RP; m < WAVE; m <<= 1) tp2[e] += shfl_xor_f64(tp2[e], m);
+            tp2[e] = xor_range_sum<RP, WAVE>(tp2[e]);
         if (lane < RP)
 #pragma unroll
             for (int e = 0; e < V; ++e) tred[buf][wv][rp * V + e] = tp2[e];
@@ -220,9 +219,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
     // per column group writes this workgroup's partial row
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        double s = pacc[j];
-#pragma unroll
-        for (int m = 1; m < RP; m <<= 1) s += shfl_xor_f64(s, m);
+        const double s = xor_range_sum<1, RP>(pacc[j]);
         const int k = cg + CG * j;
         if (rp == 0 && k < K) part[(i64)blockIdx.x * K + k] = s;
     }
@@ -306,8 +303,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
         }
 #pragma unroll
         for (int e = 0; e < V; ++e)
-#pragma unroll
-            for (int m = RP; m < WAVE; m <<= 1) tacc[e] += shfl_xor_f64(tacc[e], m);
+            tacc[e] = xor_range_sum<RP, WAVE>(tacc[e]);
         if (lane < RP)
 #pragma unroll
             for (int e = 0; e < V; ++e) tred[buf][wv][rp * V + e] = tacc[e];
@@ -470,9 +466,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void xty_tiled_kernel(const T *
     }
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        double s = pacc[j];
-#pragma unroll
-        for (int m = 1; m < RP; m <<= 1) s += shfl_xor_f64(s, m);
+        const double s = xor_range_sum<1, RP>(pacc[j]);
         const int k = cg + CG * (g0 + j);
         if (rp == 0 && k < K) part[(i64)blockIdx.x * K + k] = s;
     }
