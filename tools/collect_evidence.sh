@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collects the measurement evidence of a round on the GPU box into gpurun_out/evidence/ (copy what is to be judged
 # into profiles/rNN/ afterwards).  rocprofv3: the program goes directly after `--`; counters in their own passes.
-# usage: bash tools/collect_evidence.sh [part ...]   parts: c3 deflate c4 c5 eighth host roctx   (default: all)
+# usage: bash tools/collect_evidence.sh [part ...]   parts: c3 deflate c4 c5 eighth host roctx small   (default: all)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 E=gpurun_out/evidence; mkdir -p $E
-PARTS="${*:-c3 deflate c4 c5 eighth host roctx}"
+PARTS="${*:-c3 deflate c4 c5 eighth host roctx small}"
 stats() {  # name, command...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $E/tmp_$name -o p -- "$@" > $E/${name}_bench_under_rocprof.json 2> $E/tmp_$name.err
@@ -50,6 +50,10 @@ host)
   ./tools/host_entry_time 1048576 512 1 20 5 > $E/host_entry_time_C3.txt 2>&1
   PLS_HIP_ALGO=kernel ./tools/host_entry_time 1048576 512 1 20 3 > $E/host_entry_time_C3_kernel_plan.txt 2>&1
   ./tools/h2d_probe > $E/h2d_probe.txt 2>&1 ;;
+small)
+  python3 tools/small_fit_time.py $E/small_fits.json > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $E/tmp_small -o p -- python3 tools/small_fit_time.py /dev/null > /dev/null 2> $E/tmp_small.err
+  cp $E/tmp_small/p_kernel_stats.csv $E/small_fits_kernel_stats.csv; rm -rf $E/tmp_small $E/tmp_small.err ;;
 roctx)
   PLS_HIP_ROCTX=1 rocprofv3 --marker-trace --kernel-trace --output-format csv -d $E/tmp_roctx -o p -- python3 tools/roctx_demo.py > /dev/null 2> $E/tmp_roctx.err
   python3 - <<'PY'
