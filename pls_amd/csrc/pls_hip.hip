@@ -286,8 +286,22 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
             const int mtc = (use + 3) & ~3;
             const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
             Scope s(c, PLS_HIP_FAM_XB, bytes);
-            const i64 per = (i64)plsk::WG * (wide ? FV : 1);
+            // fp64, 13..20 columns on a large matrix: two row packs per lane (one LDS read of a B value feeds 4 FMAs)
+            static const int np_env = getenv("PLS_HIP_XB_NP") ? atoi(getenv("PLS_HIP_XB_NP")) : 2;
+            const bool two = wide && FV == 2 && mtc >= 16 && mtc <= 20 && np_env == 2 && N >= (i64)c->num_cu * 4 * plsk::WG * FV * 2;
+            const i64 per = (i64)plsk::WG * (wide ? FV : 1) * (two ? 2 : 1);
             const dim3 grid((unsigned)((N + per - 1) / per)), blk(plsk::WG);
+            if (two) {
+                if constexpr (FV == 2) {
+                    switch (mtc) {
+                        case 16: hipLaunchKernelGGL((plsk::xb_wide_kernel<T, 2, 16, 2>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo); break;
+                        default: hipLaunchKernelGGL((plsk::xb_wide_kernel<T, 2, 20, 2>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo); break;
+                    }
+                }
+                LAUNCH_CHECK(c);
+                c0 += use;
+                continue;
+            }
 #define XW_CASE(V, M_) hipLaunchKernelGGL((plsk::xb_wide_kernel<T, V, M_>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo)
 #define XW_SWITCH(V)                                   \
     switch (mtc) {                                     \

@@ -207,19 +207,26 @@ __global__ __launch_bounds__(WG) void xb_mfma_kernel(const T *__restrict__ X, i6
 // through LDS in chunks of KB rows, stored [k][MT] so that one k's columns are contiguous and every
 // lane reads the same address (LDS broadcast, conflict-free), two columns per ds_read_b128.
 // ------------------------------------------------------------------------------------
-template <typename T, int VEC, int MT>
+template <typename T, int VEC, int MT, int NP = 1>
 __global__ __launch_bounds__(WG) void xb_wide_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K,
                                                      const double *__restrict__ Bm, i64 ldb, int ncols,
                                                      T *__restrict__ out, i64 ldo) {
+    // NP row packs per lane (WG*VEC rows apart: every load stays a coalesced 4 KB piece): one LDS read of a B value
+    // feeds NP*VEC FMAs.  The broadcast reads of B are the bound at 20 fp64 columns (10 ds_read_b128 per X pack).
     constexpr int KB = 64;
     __shared__ __attribute__((aligned(16))) double bs[2][KB * MT];
-    const i64 i0 = ((i64)blockIdx.x * WG + threadIdx.x) * VEC;
-    const bool full = (i0 + VEC <= N);
-    double acc[VEC][MT];
+    const i64 i0 = (i64)blockIdx.x * (WG * VEC * NP) + (i64)threadIdx.x * VEC;
+    constexpr i64 PS = (i64)WG * VEC;  // rows between the packs of a lane
+    bool full = true;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v)
+    for (int p = 0; p < NP; ++p) full = full && (i0 + p * PS + VEC <= N);
+    double acc[NP][VEC][MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[v][m] = 0.0;
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[p][v][m] = 0.0;
 
     auto stage = [&](int buf, int k0) {  // Bm[k0 .. k0+KB) x ncols -> bs[buf][k][m], zero padded
         for (int j = threadIdx.x; j < KB * MT; j += WG) {
@@ -233,17 +240,20 @@ __global__ __launch_bounds__(WG) void xb_wide_kernel(const T *__restrict__ X, i6
     for (int k0 = 0; k0 < K; k0 += KB, buf ^= 1) {
         if (k0 + KB < K) stage(buf ^ 1, k0 + KB);
         const int kn = min(KB, K - k0);
-        constexpr int U = 8;
+        constexpr int U = 8 / NP;
         for (int kb = 0; kb < kn; kb += U) {
-            Pack<T, VEC> x[U];
+            Pack<T, VEC> x[U][NP];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (full && kb + u < kn) x[u] = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + kb + u) * ldx);
-                else
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v)
-                        x[u].v[v] = (kb + u < kn && i0 + v < N) ? X[i0 + v + (i64)(k0 + kb + u) * ldx] : (T)0;
-            }
+                for (int p = 0; p < NP; ++p) {
+                    const i64 ip = i0 + p * PS;
+                    if (full && kb + u < kn) x[u][p] = ld_pack_nt<T, VEC>(X + ip + (i64)(k0 + kb + u) * ldx);
+                    else
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v)
+                            x[u][p].v[v] = (kb + u < kn && ip + v < N) ? X[ip + v + (i64)(k0 + kb + u) * ldx] : (T)0;
+                }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const double *brow = &bs[buf][(kb + u) * MT];  // rows beyond kn hold zeros or stale data x 0
@@ -251,26 +261,32 @@ __global__ __launch_bounds__(WG) void xb_wide_kernel(const T *__restrict__ X, i6
                 for (int m = 0; m < MT; ++m) {
                     const double b = brow[m];
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[v][m] = fma((double)x[u].v[v], b, acc[v][m]);
+                    for (int p = 0; p < NP; ++p)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[p][v][m] = fma((double)x[u][p].v[v], b, acc[p][v][m]);
                 }
             }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-        if (m < ncols) {
-            if (full) {
-                Pack<T, VEC> o;
+    for (int p = 0; p < NP; ++p) {
+        const i64 ip = i0 + p * PS;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) o.v[v] = (T)acc[v][m];
-                st_pack<T, VEC>(out + i0 + (i64)m * ldo, o);
-            } else {
+        for (int m = 0; m < MT; ++m)
+            if (m < ncols) {
+                if (ip + VEC <= N) {
+                    Pack<T, VEC> o;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    if (i0 + v < N) out[i0 + v + (i64)m * ldo] = (T)acc[v][m];
+                    for (int v = 0; v < VEC; ++v) o.v[v] = (T)acc[p][v][m];
+                    st_pack<T, VEC>(out + ip + (i64)m * ldo, o);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        if (ip + v < N) out[ip + v + (i64)m * ldo] = (T)acc[p][v][m];
+                }
             }
-        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
