@@ -223,7 +223,8 @@ PLS_HIP_API int pls_hip_model_sse(pls_hip_handle h, const void *X, int64_t ldx, 
  * num_folds N, test_idx = 0..N-1.  test_idx is HOST memory (distinct indices within a fold); X, Y, E follow
  * `mem`.  All folds share XX = X^T X and XY = X^T Y formed once; a fold works on
  * XX - X_test^T X_test applied on the fly (the KERNEL_TYPE2 recurrence, src/pls.cpp:422-425): no per-fold
- * pass over X.  Shapes that launch declines (M > 32, A > 4096, K > 16384, workspaces that do not fit) run as one
+ * pass over X.  Small single-response data (N <= 1024, K <= 26 * floor(16 / ceil(N/64)), M = 1) run as one single-launch fit per
+ * fold on the masked X instead (no X^T X at all).  Shapes that launch declines (M > 32, A > 4096, K > 16384, workspaces that do not fit) run as one
  * device refit per fold instead -- same results, num_folds fits.  Single rank.  The call returns after the work
  * has completed.
  */

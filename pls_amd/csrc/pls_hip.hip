@@ -652,7 +652,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         Range r_fit("pls_hip_fit (single launch)");
         Scope s(c, PLS_HIP_FAM_SMALL, ((i64)N * K + (i64)N * M + (i64)N * A) * (i64)sizeof(T) + (3 * (i64)K + M) * A * 8);
         hipLaunchKernelGGL((plsk::tiny_fit_kernel<T>), dim3(1), dim3(plsk::UPD_THREADS), lds, c->stream, X, ldx, Y, (int)N, K, A,
-                           W, P, Q, R, Tm, ldt, B);
+                           W, P, Q, R, Tm, ldt, B, (const i64 *)nullptr, 0, (i64)0, (double *)nullptr);
         LAUNCH_CHECK(c);
         return PLS_HIP_OK;
     }
@@ -1543,6 +1543,25 @@ int cv_folds_device(pls_hip_context *h, const T *dX, i64 dldx, const T *dY, i64 
     return PLS_HIP_OK;
 }
 
+// Small single-response data (the reference's examples): every fold is a single-launch fit (tiny_kernels.hpp) on the whole X
+// with its held-out rows masked, one workgroup per fold -- no X^T X at all, which for N < K is the smaller object anyway.
+template <typename T>
+int cv_folds_tiny(pls_hip_context *h, const T *dX, i64 dldx, const T *dY, i64 N, int Ki, int Ai, const int64_t *test_idx, int ts,
+                  i64 num_folds, double *dE) {
+    const i64 nobs = num_folds * ts;
+    CHK(ensure(h, h->cvidx, (size_t)nobs * 8));
+    HIPCHK(h, hipMemcpyAsync(h->cvidx.p, test_idx, (size_t)nobs * 8, hipMemcpyHostToDevice, h->stream));
+    const size_t lds = (size_t)2 * Ki * Ai * 8;
+    if (!plsk::raise_dynamic_lds((const void *)plsk::tiny_fit_kernel<T>, lds))
+        return fail(h, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the single-launch fit could not be raised");
+    Scope s(h, PLS_HIP_FAM_SMALL, (i64)num_folds * N * Ki * (i64)sizeof(T));
+    hipLaunchKernelGGL((plsk::tiny_fit_kernel<T>), dim3((unsigned)num_folds), dim3(plsk::UPD_THREADS), lds, h->stream, dX, dldx, dY,
+                       (int)N, Ki, Ai, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (T *)nullptr,
+                       (i64)0, (double *)nullptr, (const i64 *)h->cvidx.p, ts, nobs, dE);
+    LAUNCH_CHECK(h);
+    return PLS_HIP_OK;
+}
+
 // The general form of the same call: one refit per fold on the rows that are not in its test set -- what the reference
 // does (src/pls.cpp:478-488, :524-545), with the training rows gathered on the device and the fit running under the
 // handle's own plan.  Serves the shapes the batched kernel declines (M > 32, A > 4096, K > 16384, a workspace that does
@@ -1643,7 +1662,14 @@ int pls_hip_cv_folds(pls_hip_handle h, const void *X, int64_t ldx, const void *Y
     CHK(ensure(h, h->cve, (size_t)nobs * A * M * 8));
     double *dE = (mem == PLS_HIP_MEM_HOST) ? (double *)h->cve.p : E;
     int rc = PLS_HIP_ERR_ALLOC;
-    if (cv_batched_covers(K, M, A)) {
+    const bool tiny = M == 1 && plsk::tiny_fit_covers(N, (int)K, 1, (int)A, dldx, es) && !getenv("PLS_HIP_CV_REFIT") &&
+                      !(getenv("PLS_HIP_TINY") && atoi(getenv("PLS_HIP_TINY")) == 0);
+    if (tiny) {
+        if (dtype == PLS_HIP_F64)
+            rc = cv_folds_tiny<double>(h, (const double *)dX, dldx, (const double *)dY, N, (int)K, (int)A, test_idx, (int)test_size, num_folds, dE);
+        else
+            rc = cv_folds_tiny<float>(h, (const float *)dX, dldx, (const float *)dY, N, (int)K, (int)A, test_idx, (int)test_size, num_folds, dE);
+    } else if (cv_batched_covers(K, M, A)) {
         if (dtype == PLS_HIP_F64)
             rc = cv_folds_device<double>(h, (const double *)dX, dldx, (const double *)dY, dldy, N, (int)K, (int)M, (int)A,
                                          test_idx, (int)test_size, num_folds, dE);

@@ -95,11 +95,18 @@ __device__ __forceinline__ void tiny_column_sums(const double (&x)[TINY_RC], dou
 
 // X: N x K (ld ldx), Y: N x 1; W, P, R: K x A; Q: 1 x A; Tm: N x A (ld ldt); B: K x 1 or null.
 // Dynamic LDS: 2 * K * A doubles.  grid = 1.
+// FOLD MODE (fold_idx != null; grid = number of cross-validation folds, Model::cv_LOO / cv_LSO, src/pls.cpp:469-549):
+// workgroup f fits the rows that are NOT in fold_idx[f*ts .. +ts) -- a held-out row takes part with y = 0 and t = 0,
+// which is the fit without it -- and, because X stays whole in the registers, the score pass hands over x_i . r_a of the
+// held-out rows for free: their residuals y_i - sum_{c<=a} (x_i . r_c) q_c go to E[(f*ts + j) + a*nobs] (the layout of
+// pls_hip_cv_folds, M = 1).  W, P, Q, R, Tm, B are not written.
 template <typename T>
 __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restrict__ X, i64 ldx, const T *__restrict__ Y, int N,
                                                                int K, int A, double *__restrict__ W, double *__restrict__ P,
                                                                double *__restrict__ Q, double *__restrict__ R,
-                                                               T *__restrict__ Tm, i64 ldt, double *__restrict__ B) {
+                                                               T *__restrict__ Tm, i64 ldt, double *__restrict__ B,
+                                                               const i64 *__restrict__ fold_idx, int ts, i64 nobs,
+                                                               double *__restrict__ E) {
     extern __shared__ double dyn[];
     double *Pl = dyn, *Rl = dyn + (i64)K * A;  // P[:, j], R[:, j] as they are produced
     __shared__ double tp[UPD_THREADS], colp[UPD_WAVES][TINY_RC], praw[TINY_KMAX], xy[TINY_KMAX], wl[TINY_KMAX], vsl[TINY_KMAX];
@@ -123,14 +130,24 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
     for (int j = 0; j < TINY_RC; ++j) x[j] = tiny_ld<T>(rs, voff, (uint32_t)j * cstep);
     for (int c = tid; c < TINY_KMAX; c += UPD_THREADS) vsl[c] = 0.0;  // read (times x = 0) beyond K
 
-    tiny_column_sums(x, act ? (double)Y[i] : 0.0, colp, K, shp, xy);  // XY = X^T Y (:396)
+    const bool fold = fold_idx != nullptr;
+    int hpos = -1;  // position of this thread's row in the fold's held-out list
+    if (fold && act)
+        for (int j = 0; j < ts; ++j)
+            if (fold_idx[(i64)blockIdx.x * ts + j] == i) hpos = j;
+    const bool held = hpos >= 0;
+    const double yv = act ? (double)Y[i] : 0.0;
+    double yhat = 0.0;
+    tiny_column_sums(x, held ? 0.0 : yv, colp, K, shp, xy);  // XY = X^T Y (:396)
     lds_barrier();
     double xyk = kok ? xy[k] : 0.0;
     {  // w_0 = XY / |XY| (:404, :411), r_0 = w_0
         const double w = xyk / sqrt(tiny_block_sum(xyk * xyk, sred));
         if (kok) {
-            W[k] = w;
-            R[k] = w;
+            if (!fold) {
+                W[k] = w;
+                R[k] = w;
+            }
             Rl[k] = w;
             vsl[slot] = w;
         }
@@ -149,26 +166,32 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
         double ti = 0.0;
         if (act)
             for (int q = 0; q < shp.S; ++q) ti += tp[(q * shp.wps + rb) * WAVE + lane];
-        if (act && s == 0) Tm[i + (i64)a * ldt] = (T)ti;
+        const double ui = ti;     // x_i . r_a, also for a held-out row
+        if (held) ti = 0.0;       // ... which has no score in its fold's fit
+        if (act && s == 0 && !fold) Tm[i + (i64)a * ldt] = (T)ti;
         const double tt = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // (:420)
         tiny_column_sums(x, ti, colp, K, shp, praw);                                    // X^T t (:427)
         lds_barrier();
         const double p = kok ? praw[k] / tt : 0.0;                                                        // (:427)
         const double q = tiny_block_sum(kok ? Rl[k + (i64)a * K] * xyk : 0.0, sred) / tt;          // q = r^T XY / tt (:428)
         if (kok) {
-            P[k + (i64)a * K] = p;
+            if (!fold) P[k + (i64)a * K] = p;
             Pl[k + (i64)a * K] = p;
         }
         if (tid == 0) {
-            Q[a] = q;
+            if (!fold) Q[a] = q;
             ql[a] = q;
+        }
+        if (held && s == 0) {  // residual of a held-out row with a+1 components
+            yhat = fma(ui, q, yhat);
+            E[((i64)blockIdx.x * ts + hpos) + (i64)a * nobs] = yv - yhat;
         }
         xyk -= (p * q) * tt;  // XY -= (p q^T) tt (:429)
         const int n = a + 1;
         if (n >= A) break;
         const double w = xyk / sqrt(tiny_block_sum(xyk * xyk, sred));  // (:404, :411)
         if (kok) {
-            W[k + (i64)n * K] = w;
+            if (!fold) W[k + (i64)n * K] = w;
             wl[k] = w;
         }
         lds_barrier();
@@ -182,13 +205,13 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
         double r = w;
         for (int j = 0; j < n; ++j) r -= cs[j] * Rl[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
         if (kok) {
-            R[k + (i64)n * K] = r;
+            if (!fold) R[k + (i64)n * K] = r;
             Rl[k + (i64)n * K] = r;
             vsl[slot] = r;
         }
     }
     lds_barrier();
-    if (B && kok) {  // B = R Q^T (:444-451)
+    if (B && kok && !fold) {  // B = R Q^T (:444-451)
         double b = 0.0;
         for (int a = 0; a < A; ++a) b = fma(Rl[k + (i64)a * K], ql[a], b);
         B[k] = b;
