@@ -298,15 +298,17 @@ def main():
                 t2 = h.timing()
                 n2 = max(t2["launches"]["xty"], 1)
                 syrk_ms = t2["ms"]["xty"] / t2["fits"] - tm["ms"]["xty"] / max(tm["fits"], 1)
-                nbk = (K + 127) // 128                      # 128 x 128 blocks, upper triangle incl. diagonal
-                executed = 2.0 * N * 128 * 128 * (nbk * (nbk + 1) // 2)
+                nbk = (K + 127) // 128                      # 128 x 128 blocks = 64 tiles of 16 x 16: the blocks above the diagonal
+                tiles = 64 * (nbk * (nbk - 1) // 2) + 40 * nbk   # in full, 40 tiles (4 waves x 10) of every diagonal block
+                executed = 2.0 * N * 16 * 16 * tiles
                 alt["type2_mfma_syrk"] = {"components_per_s": round(A * st / e2, 2), "ms_per_fit": round(e2 / st * 1e3, 3),
                                           "syrk_ms": round(syrk_ms, 3),
                                           "syrk_tflops_executed": round(executed / (syrk_ms * 1e-3) / 1e12, 2) if syrk_ms > 0 else None,
                                           "syrk_tflops_nominal_2NK2_symmetry_counted": round(2.0 * N * K * K / (syrk_ms * 1e-3) / 1e12, 2) if syrk_ms > 0 else None,
                                           "fp64_mfma_peak_tflops": 78.6,
-                                          "note": "T (scores) not computed by this method; 'executed' counts the upper-triangle blocks "
-                                                  "the kernel computes, 'nominal' the full 2 N K^2 (can exceed the MFMA peak)"}
+                                          "note": "T (scores) not computed by this method; 'executed' counts the 16 x 16 tiles the kernel "
+                                                  "computes (blocks above the diagonal in full, 40 of 64 tiles of a diagonal block), "
+                                                  "'nominal' the full 2 N K^2 (can exceed the MFMA peak)"}
             # the stand-alone rank-1 deflation (the north star's "deflation step"), X -= t p^T in place
             h.set_option(pls_amd.OPT_ALGO, algo)
             h.set_option(pls_amd.OPT_FUSE, a.fuse)

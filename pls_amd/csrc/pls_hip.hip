@@ -621,8 +621,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // GRAM plan for a KERNEL_TYPE1 request: the K-sized loop runs on XX = X^T X exactly as KERNEL_TYPE2
     // does (no pass over X per component), then the scores are formed in one pass, T = X R.
     // AUTO: pick between the read-only pass plan and the Gram plan from a bandwidth / matrix-core cost
-    // model (measured rates on MI355X: ~6 TB/s streaming reads, ~60 TFLOP/s executed in the fp64 SYRK of
-    // which the symmetric half is computed).  GRAM pays off for A >~ K/50.
+    // model (measured rates on MI355X: ~6 TB/s streaming reads, ~59 TFLOP/s executed in the fp64 SYRK of
+    // which the symmetric half is computed).  GRAM pays off for A >~ K/60.
     i64 algo = c->opt_algo;
     const bool have_pre = c->pre_xx && c->pre_xy && K <= 32768;
     if (algo == PLS_HIP_ALGO_AUTO && have_pre) {
@@ -630,7 +630,9 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     } else if (algo == PLS_HIP_ALGO_AUTO) {
         const double pass_s = (double)N * K * sizeof(T) / 6.0e12;
         const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
-        const double syrk_s = 2.0 * N * (double)K * K * (nbk + 1) / (2.0 * nbk) / 60.0e12;
+        // tiles of 16 x 16 the SYRK executes: the blocks above the diagonal in full, 40 of 64 in a diagonal block (syrk_kernels.hpp)
+        const double tile_frac = (32.0 * nbk * (nbk - 1) + 40.0 * nbk) / (64.0 * nbk * nbk);
+        const double syrk_s = 2.0 * N * (double)K * K * tile_frac / 59.0e12;
         // ranks of a sharded fit see different N: they must not disagree on the plan -> KERNEL there
         const bool gram_ok = K <= 2048 && N >= 4096 && !c->reducer;
         algo = (gram_ok && (1 + A) * pass_s > syrk_s + 2.5 * pass_s + A * 25e-6) ? PLS_HIP_ALGO_GRAM

@@ -163,24 +163,56 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_base) {
 // address of the DMA and to the READ address alike.
 // Columns >= K read column K-1 again (their products are never written); the launcher requires N % V == 0
 // and sends rows beyond N to a zero block.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void syrk_glds_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
-                                                           const T *__restrict__ zeros, double *__restrict__ part) {
+// Tiles (m, n) of a wave's 4 x 4 set as a 16-bit mask, bit 4 m + n.
+constexpr unsigned SYRK_ALL = 0xFFFFu;
+constexpr unsigned SYRK_UPPER = 0x8CEFu;   // m <= n: rows 0xF, 0xE, 0xC, 0x8
+
+// the MFMAs of one slab for the tiles in MASK (operands of unused rows / columns are never read)
+template <typename T, unsigned MASK, int V, int RB, int CS>
+__device__ __forceinline__ void syrk_slab_mfma(const T *As, const T *Bs, int a0, int b0, int li, int lq, int fl, f64x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int kk = 0; kk < RB; kk += 4) {
+        const int r = kk + lq;
+        const int off = (((r / V) ^ fl) * V) + (r % V);
+        double a[4], b[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if ((MASK >> (4 * m)) & 0xFu) a[m] = (double)As[(a0 + 16 * m + li) * CS + off];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if (MASK & (0x1111u << n)) b[n] = (double)Bs[(b0 + 16 * n + li) * CS + off];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if ((MASK >> (4 * m + n)) & 1u) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+}
+
+// Diagonal blocks: every wave does only the tiles on or above the diagonal of ITS quadrant (10 of 16).  For the quadrants
+// (0,0) and (1,1) that is all the block needs of them; the quadrants (0,1) and (1,0) are mirror images of each other, so
+// the upper tiles of the one plus the mirrored upper tiles of the other give both in full (their four diagonal tiles are
+// computed twice -- the same products in the same order, the same bits).  Same wave-to-quadrant map and ONE tile pattern
+// for all four waves (a per-wave choice between patterns costs the register allocator 400 spills).  A diagonal workgroup
+// needs 10/16 of the time per slab and gets 16/10 of the rows (sd row splits instead of gridDim.y; the workgroups
+// beyond sd only zero their slot of the partial buffer): 8.5 instead of 10 block-times at K = 512.
+// One workgroup's share of a block for the tile set MASK: slabs s0, s0 + nsplit, ... of the panels bi (A) and bj (B).
+// Out of line: the two instantiations then get a register allocation each (inlined side by side in one kernel they spill).
+template <typename T, unsigned MASK>
+__device__ __noinline__ void syrk_glds_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, int bj, i64 s0, int nsplit,
+                                            const T *__restrict__ zeros, double *__restrict__ out) {
+    // (declared here, not passed in: a pointer argument of an out-of-line function is a generic pointer, and LDS reads
+    // through it become flat loads)
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];  // [2 buffers][A panel, B panel]
+    T *lds = reinterpret_cast<T *>(slab_raw);
     constexpr int V = 16 / sizeof(T);   // rows per 16-byte position
     constexpr int RB = 8 * V;           // rows per slab
     constexpr int CS = 8 * V;           // elements per column in LDS (128 bytes)
     constexpr int PANEL = SYRK_TB * CS; // elements per panel buffer
-    extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];  // [2 buffers][A panel, B panel]
-    T *lds = reinterpret_cast<T *>(slab_raw);
-
-    int bi = 0, rem = blockIdx.x;
-    while (rem >= nbk - bi) { rem -= nbk - bi; ++bi; }
-    const int bj = bi + rem;
     const bool diag = (bi == bj);
-
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int a0 = (wv >> 1) * 64, b0 = (wv & 1) * 64;
     const int li = lane & 15, lq = lane >> 4;
+    const int a0 = (wv >> 1) * 64, b0 = (wv & 1) * 64;  // this wave's quadrant of the block
     const int fl = li >> 1;  // swizzle key of this lane's operand columns: ((a0 + 16 m + li) >> 1) & 7
 
     // staging map of the DMA: wave-instruction i covers columns 8 i .. 8 i + 7; lane = (column, position)
@@ -213,35 +245,23 @@ __global__ __launch_bounds__(256, 2) void syrk_glds_kernel(const T *__restrict__
         }
     };
 
-    i64 s = blockIdx.y;
+    i64 s = s0;
     int buf = 0;
     if (s < nslabs) issue(s, 0);
-    for (; s < nslabs; s += gridDim.y, buf ^= 1) {
+    for (; s < nslabs; s += nsplit, buf ^= 1) {
         __syncthreads();  // vmcnt(0) + barrier: slab s has landed for every wave; the other buffer is free again
-        if (s + gridDim.y < nslabs) issue(s + gridDim.y, buf ^ 1);
+        if (s + nsplit < nslabs) issue(s + nsplit, buf ^ 1);
         const T *As = lds + (size_t)buf * 2 * PANEL, *Bs = diag ? As : As + PANEL;
-#pragma unroll
-        for (int kk = 0; kk < RB; kk += 4) {
-            const int r = kk + lq;
-            const int off = (((r / V) ^ fl) * V) + (r % V);
-            double a[4], b[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = (double)As[(a0 + 16 * m + li) * CS + off];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = (double)Bs[(b0 + 16 * n + li) * CS + off];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
-        }
+        syrk_slab_mfma<T, MASK, V, RB, CS>(As, Bs, a0, b0, li, lq, fl, acc);
     }
 
-    double *out = part + (i64)blockIdx.y * ((i64)K * K);
+    // f64 C/D layout: lane holds D[row = (lane>>4) + 4*reg][col = lane&15]; row <-> a, col <-> b.  Every computed tile is
+    // written with its mirror image.
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < 4; ++n) {
+            if (!((MASK >> (4 * m + n)) & 1u)) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ga_ = bi * SYRK_TB + a0 + 16 * m + lq + 4 * r;
@@ -249,9 +269,54 @@ __global__ __launch_bounds__(256, 2) void syrk_glds_kernel(const T *__restrict__
                 if (ga_ < K && gb_ < K) {
                     const double v = acc[m][n][r];
                     out[ga_ + (i64)gb_ * K] = v;
-                    if (!diag) out[gb_ + (i64)ga_ * K] = v;
+                    out[gb_ + (i64)ga_ * K] = v;
                 }
             }
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void syrk_glds_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
+                                                           const T *__restrict__ zeros, double *__restrict__ part, int so, int sd) {
+    // 1-D grid, exactly the workgroups that have rows: first so splits of every off-diagonal block, then sd of every
+    // diagonal block (workgroups that only exit still take a dispatch slot: a 2-D grid with idle members ran 7.8 ms
+    // instead of 6.1).  A diagonal block has fewer partials than the so the reduction sums: its workgroup j also zeroes
+    // the slots j + sd, j + 2 sd, ... < so.
+    const int ndiag = nbk, noff = nbk * (nbk + 1) / 2 - nbk;
+    int id = blockIdx.x, split, blk;
+    bool diag;
+    if (id < noff * so) {
+        diag = false;
+        blk = id % noff;
+        split = id / noff;
+    } else {
+        diag = true;
+        id -= noff * so;
+        blk = id % ndiag;
+        split = id / ndiag;
+    }
+    int bi, bj;
+    if (diag) {
+        bi = bj = blk;
+    } else {  // off-diagonal blocks numbered row by row: (0,1), (0,2), ..., (1,2), ...
+        bi = 0;
+        int rem = blk;
+        while (rem >= nbk - 1 - bi) { rem -= nbk - 1 - bi; ++bi; }
+        bj = bi + 1 + rem;
+    }
+    double *out = part + (i64)split * ((i64)K * K);
+    if (diag) {
+        for (int z = split + sd; z < so; z += sd) {
+            double *zo = part + (i64)z * ((i64)K * K);
+            for (int e = threadIdx.x; e < SYRK_TB * SYRK_TB; e += 256) {
+                const int ga_ = bi * SYRK_TB + (e & (SYRK_TB - 1)), gb_ = bj * SYRK_TB + e / SYRK_TB;
+                if (ga_ < K && gb_ < K) zo[ga_ + (i64)gb_ * K] = 0.0;
+            }
+        }
+        syrk_glds_body<T, SYRK_UPPER>(X, ldx, N, K, bi, bj, split, sd, zeros, out);
+    } else {
+        syrk_glds_body<T, SYRK_ALL>(X, ldx, N, K, bi, bj, split, so, zeros, out);
+    }
 }
 
 // rc: 0 launched (part holds *nb partial K x K matrices), 1 shape not covered
@@ -279,12 +344,23 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         constexpr size_t LDS_G = 2 * 2 * (size_t)SYRK_TB * 128;
         const i64 nslabs_g = (N + RBG - 1) / RBG;
         i64 Sg = nblocks <= slots ? slots / nblocks : (8 * slots + nblocks - 1) / nblocks;
+        i64 Sd = 0;  // row splits of the diagonal blocks; 0 = as the others (several residency waves balance themselves)
+        static const bool tri = !(getenv("PLS_HIP_SYRK_TRI") && atoi(getenv("PLS_HIP_SYRK_TRI")) == 0);
+        if (tri && nblocks <= slots) {  // one residency wave: a diagonal workgroup costs 10/16 per slab and takes 16/10 of the rows
+            const double units = (nblocks - nbk) + 0.625 * nbk;
+            Sg = (i64)(slots / units);
+            Sd = std::max<i64>(1, (i64)(0.625 * Sg));
+            while ((nblocks - nbk) * Sg + nbk * Sd > slots && Sg > 1) { --Sg; Sd = std::max<i64>(1, (i64)(0.625 * Sg)); }
+        }
         Sg = std::max<i64>(1, std::min<i64>(Sg, nslabs_g));
         Sg = std::min<i64>(Sg, part_capacity_doubles / ((i64)K * K));
         if (Sg < 1) return 1;
+        Sd = Sd ? std::min<i64>(Sd, Sg) : Sg;
+        if (!tri) Sd = Sg;
         if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_glds_kernel<T>), (int)LDS_G)) return 1;
-        hipLaunchKernelGGL(syrk_glds_kernel<T>, dim3(nblocks, (unsigned)Sg), dim3(256), LDS_G, stream, X, ldx, N, K, nbk,
-                           static_cast<const T *>(zeros), part);
+        const i64 nwg = (i64)(nblocks - nbk) * Sg + (i64)nbk * Sd;
+        hipLaunchKernelGGL(syrk_glds_kernel<T>, dim3((unsigned)nwg), dim3(256), LDS_G, stream, X, ldx, N, K, nbk,
+                           static_cast<const T *>(zeros), part, (int)Sg, (int)Sd);
         *nb = (int)Sg;
         return 0;
     }
