@@ -110,20 +110,34 @@ def attach_rccl_reducer(handle, group=None):
 
     import torch.distributed as dist
 
-    lib = ctypes.CDLL(os.path.join(os.path.dirname(L.LIB_PATH), "libpls_hip_rccl.so"), mode=ctypes.RTLD_GLOBAL)
-    lib.pls_hip_rccl_unique_id.argtypes = [ctypes.c_void_p]
-    lib.pls_hip_rccl_attach.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                        ctypes.POINTER(ctypes.c_void_p)]
-    lib.pls_hip_rccl_detach.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    ident = ctypes.create_string_buffer(128)
-    if rank == 0:
-        L.check(lib.pls_hip_rccl_unique_id(ident))
+    # Phase 1 (local, may fail on one rank only): load the helper library, rank 0 draws the unique id.  The ranks agree
+    # on the outcome BEFORE the first collective that depends on it, so a local failure raises on every rank instead of
+    # leaving the others in a broadcast nobody serves.
+    lib, ident, err = None, ctypes.create_string_buffer(128), None
+    try:
+        lib = ctypes.CDLL(os.path.join(os.path.dirname(L.LIB_PATH), "libpls_hip_rccl.so"), mode=ctypes.RTLD_GLOBAL)
+        lib.pls_hip_rccl_unique_id.argtypes = [ctypes.c_void_p]
+        lib.pls_hip_rccl_attach.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                            ctypes.POINTER(ctypes.c_void_p)]
+        lib.pls_hip_rccl_detach.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        if rank == 0:
+            L.check(lib.pls_hip_rccl_unique_id(ident))
+    except Exception as e:  # noqa: BLE001
+        err = e
     if world > 1:
+        import torch
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            raise RuntimeError("RCCL helper unavailable on " + ("this rank: " + repr(err) if err else "another rank"))
         box = [bytes(ident.raw)]
         dist.broadcast_object_list(box, src=0, group=group)
         ident = ctypes.create_string_buffer(box[0], 128)
+    elif err:
+        raise err
     comm = ctypes.c_void_p()
     L.check(lib.pls_hip_rccl_attach(handle.h, handle.device, ident, rank, world, ctypes.byref(comm)), handle.h)
     handle._keep += [lib]
