@@ -852,12 +852,12 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 } else {
                     return fail(c, PLS_HIP_ERR_DEVICE, "fused pass launch failed");
                 }
-            } else if (wide_cg && (nipals ? a >= 2 : a >= 1)) {
+            } else if (wide_cg && (nipals ? a >= 2 : true)) {
                 // short-tile fused pass on the working copy: NIPALS deflates it in place, KERNEL only reads it
                 int nb = 0, nss = 0, rc;
                 const T *tprev = nipals ? Tm + (i64)(a - 1) * ldt : nullptr;
                 const double *pprev = nipals ? P + (i64)(a - 1) * K : nullptr;
-                if (!nipals && a == 1) {  // the one-time copy into short tiles
+                if (!nipals && a == 0) {  // the one-time copy into short tiles (before the first component: it runs fused, too)
                     Scope s(c, PLS_HIP_FAM_DEFLATE, 2 * (i64)N * K * sizeof(T));
                     if (plsk::launch_retile<T>(c->stream, c->num_cu, X, ldx, work, ldw, tsw, (int)WR, N, K) != 0) {
                         s.on = false;
