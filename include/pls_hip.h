@@ -165,7 +165,8 @@ PLS_HIP_API int pls_hip_get_timing(pls_hip_handle h, pls_hip_timing *out);
  * rank) X^T X and X^T Y are accumulated on the matrix cores while X crosses PCIe and the component loop starts from them.
  * Shapes follow the reference's asserts (src/pls.cpp:345-347): 1 <= A <= K, N >= 1
  * (N may be 0 on a rank of a sharded fit), 1 <= M <= 1024 (beyond 32 responses the M-sized work of the component
- * update runs from global memory: correct, about a millisecond per component slower), A <= 4096.
+ * update runs from global memory: correct, about a millisecond per component slower).  Single-response problems that fit
+ * one workgroup's registers (N <= 1024, K <= 26 * floor(16 / ceil(N/64))) run as ONE launch under the KERNEL / AUTO plans.
  * A > rank(X) yields inf/NaN in the surplus columns, as in the reference (:427-428).
  */
 PLS_HIP_API int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int64_t ldy,
