@@ -95,8 +95,12 @@ typedef enum {
     PLS_HIP_OPT_POWER_ITERS = 4, /* squarings of the S^T S power iteration (m > 1); default 48 */
     PLS_HIP_OPT_FUSED_GRID = 5,  /* workgroups of the fused pass; 0 (default) = 2 per CU */
     PLS_HIP_OPT_WORK_LAYOUT = 6, /* NIPALS work buffer (the deflated copy of X) of a fused fit: 1 (default) row-tile-major, 0 column-major */
-    PLS_HIP_OPT_DEFER = 7        /* NIPALS plan, K <= 512: write the deflated matrix back every D-th component only (1..4); the
+    PLS_HIP_OPT_DEFER = 7,       /* NIPALS plan, K <= 512: write the deflated matrix back every D-th component only (1..4); the
                                     D - 1 pending rank-1 updates are re-applied in registers.  1 (default) = explicit deflation */
+    PLS_HIP_OPT_GRAPH = 8        /* 1: a device-memory pls_hip_fit that repeats an earlier call (same pointers, shapes, options) is
+                                    captured into a hipGraph on its second occurrence and replayed as ONE graph launch from the
+                                    third on.  Single rank, profiling off, a stream of its own (not the default stream).  0 (default): every
+                                    call enqueues its kernels */
 } pls_hip_option;
 
 /*

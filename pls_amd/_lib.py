@@ -18,7 +18,7 @@ KERNEL_TYPE1, KERNEL_TYPE2 = 0, 1          # PLS::METHOD, reference include/PLS/
 F64, F32 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 ALGO_KERNEL, ALGO_NIPALS, ALGO_GRAM, ALGO_AUTO = 0, 1, 2, 3
-OPT_ALGO, OPT_FUSE, OPT_PROFILE, OPT_POWER_ITERS, OPT_FUSED_GRID, OPT_WORK_LAYOUT, OPT_DEFER = 1, 2, 3, 4, 5, 6, 7
+OPT_ALGO, OPT_FUSE, OPT_PROFILE, OPT_POWER_ITERS, OPT_FUSED_GRID, OPT_WORK_LAYOUT, OPT_DEFER, OPT_GRAPH = 1, 2, 3, 4, 5, 6, 7, 8
 REDUCE_SLICES = 8
 FAM_XTY, FAM_XB, FAM_DEFLATE, FAM_FUSED, FAM_SMALL, FAM_COUNT = 0, 1, 2, 3, 4, 5
 FAM_NAMES = ("xty", "xb", "deflate", "fused", "small")

@@ -54,7 +54,10 @@ struct pls_hip_context {
     double *user_red = nullptr;
     i64 user_red_count = 0;
     i64 opt_algo = PLS_HIP_ALGO_KERNEL, opt_fuse = 1, opt_profile = 0, opt_power_iters = 48;
-    i64 opt_fused_grid = 0, opt_work_layout = 1, opt_defer = 1;
+    i64 opt_fused_grid = 0, opt_work_layout = 1, opt_defer = 1, opt_graph = 0;
+    // PLS_HIP_OPT_GRAPH: the last repeated device-memory fit as an executable graph (one entry: a loop of identical fits)
+    std::vector<uint64_t> graph_key, graph_seen;
+    hipGraphExec_t graph_exec = nullptr;
     DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, coop, lm, gxx, gxy, tab, work, cvidx, cvx, cvy, cvws, cve, cvtx, cvty, cvtt, cvm, cvkeep, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
@@ -1097,6 +1100,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     h->stager.release();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     delete h;
@@ -1135,6 +1139,7 @@ int pls_hip_set_option(pls_hip_handle h, int option, int64_t value) {
             if (value < 1 || value > plsk::DEFER_MAX) return fail(h, PLS_HIP_ERR_INVALID, "defer out of range");
             h->opt_defer = value;
             return PLS_HIP_OK;
+        case PLS_HIP_OPT_GRAPH: h->opt_graph = value ? 1 : 0; return PLS_HIP_OK;
         default: return fail(h, PLS_HIP_ERR_INVALID, "unknown option");
     }
 }
@@ -1148,6 +1153,7 @@ int pls_hip_get_option(pls_hip_handle h, int option, int64_t *value) {
         case PLS_HIP_OPT_PROFILE: *value = h->opt_profile; return PLS_HIP_OK;
         case PLS_HIP_OPT_POWER_ITERS: *value = h->opt_power_iters; return PLS_HIP_OK;
         case PLS_HIP_OPT_FUSED_GRID: *value = h->opt_fused_grid; return PLS_HIP_OK;
+        case PLS_HIP_OPT_GRAPH: *value = h->opt_graph; return PLS_HIP_OK;
         case PLS_HIP_OPT_WORK_LAYOUT: *value = h->opt_work_layout; return PLS_HIP_OK;
         case PLS_HIP_OPT_DEFER: *value = h->opt_defer; return PLS_HIP_OK;
         default: return fail(h, PLS_HIP_ERR_INVALID, "unknown option");
@@ -1271,6 +1277,29 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
         dB = B ? (double *)h->hB.p : nullptr;
         dldx = dldy = dldt = ldn;
     }
+    // PLS_HIP_OPT_GRAPH: a repeated device-memory fit is replayed as one graph launch.  First occurrence of a call: eager (it
+    // also sizes every workspace); second: the same enqueue sequence under stream capture (nothing allocates any more),
+    // instantiated and launched; from the third on: hipGraphLaunch.  The kernel arguments are baked into the graph, so the key
+    // is everything they derive from.
+    const bool graphable = h->opt_graph && mem == PLS_HIP_MEM_DEVICE && !h->reducer && h->opt_profile == 0 && !h->user_red &&
+                           h->stream != nullptr;  // (the legacy default stream cannot be captured)
+    std::vector<uint64_t> key;
+    if (graphable) {
+        key = {(uint64_t)(uintptr_t)X, (uint64_t)ldx, (uint64_t)(uintptr_t)Y, (uint64_t)ldy, (uint64_t)N, (uint64_t)K, (uint64_t)M,
+               (uint64_t)A, (uint64_t)method, (uint64_t)dtype, (uint64_t)(uintptr_t)W, (uint64_t)(uintptr_t)P, (uint64_t)(uintptr_t)Q,
+               (uint64_t)(uintptr_t)R, (uint64_t)(uintptr_t)T, (uint64_t)ldt, (uint64_t)(uintptr_t)B, (uint64_t)h->opt_algo,
+               (uint64_t)h->opt_fuse, (uint64_t)h->opt_power_iters, (uint64_t)h->opt_fused_grid, (uint64_t)h->opt_work_layout,
+               (uint64_t)h->opt_defer, (uint64_t)(uintptr_t)h->stream, (uint64_t)(uintptr_t)h->pre_xx, (uint64_t)(uintptr_t)h->pre_xy};
+        if (h->graph_exec && key == h->graph_key) {
+            HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+            return PLS_HIP_OK;
+        }
+    }
+    const bool capture = graphable && key == h->graph_seen;
+    if (capture) {
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_key.clear(); }
+        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    }
     begin_fit_timing(h);
     int rc;
     if (dtype == PLS_HIP_F64)
@@ -1280,6 +1309,24 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
         rc = fit_device<float>(h, (const float *)dX, dldx, (const float *)dY, dldy, N, Ki, Mi, Ai, method, dW,
                                dP, dQ, dR, (float *)dT, dldt, dB);
     end_fit_timing(h);
+    if (capture) {
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+        if (rc == PLS_HIP_OK && ce == hipSuccess && graph && hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            h->graph_key = key;
+            (void)hipGraphDestroy(graph);
+            HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));  // this call's work
+        } else {
+            if (graph) (void)hipGraphDestroy(graph);
+            h->graph_exec = nullptr;
+            h->graph_seen.clear();
+            (void)hipGetLastError();
+            if (rc != PLS_HIP_OK) return rc;
+            return fail(h, PLS_HIP_ERR_DEVICE, "stream capture of the fit failed");
+        }
+    } else if (graphable) {
+        h->graph_seen = key;
+    }
     if (mem == PLS_HIP_MEM_HOST) h->pre_xx = h->pre_xy = nullptr;
     if (rc != PLS_HIP_OK) return rc;
     if (mem == PLS_HIP_MEM_HOST) {

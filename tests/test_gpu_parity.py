@@ -926,6 +926,41 @@ def test_single_launch_fit(handle, oracle, po, N, K, A, dt, pad):
         assert np.abs(out[k].cpu().numpy() - plain[k].cpu().numpy()).max() < (1e-9 if dt == "f64" else 1e-4)
 
 
+def test_graph_replay_of_repeated_fits(oracle, po):
+    """PLS_HIP_OPT_GRAPH: the second identical device-memory fit is captured, later ones are one hipGraphLaunch.  Results are
+    the eager ones bit for bit; different inputs at the same addresses are picked up (the graph holds pointers, not data);
+    a changed shape falls back to capture again."""
+    import pls_amd
+    torch = _torch()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        h = pls_amd.Handle()
+        N, K, M, A = 3000, 96, 2, 5
+        X = h.synth_x(0, N, K, 11); Y = h.synth_y(0, N, M, 11)
+        for algo in (pls_amd.ALGO_KERNEL, pls_amd.ALGO_NIPALS):
+            h.set_option(pls_amd.OPT_ALGO, algo)
+            h.set_option(pls_amd.OPT_GRAPH, 0)
+            eager = h.fit_device(X, Y, A); side.synchronize()
+            want = {k: eager[k].clone() for k in "WPQRTB"}
+            h.set_option(pls_amd.OPT_GRAPH, 1)
+            o = h.fit_device(X, Y, A)
+            for rep in range(4):                      # eager, capture + launch, replay, replay
+                for k in "WPQRTB": o[k].zero_()
+                h.fit_device(X, Y, A, out=o); side.synchronize()
+                for k in "WPQRTB": assert torch.equal(o[k], want[k]), (algo, rep, k)
+            X2 = h.synth_x(0, N, K, 12)
+            X.copy_(X2)                               # new data, same addresses: the replayed graph fits it
+            h.fit_device(X, Y, A, out=o); side.synchronize()
+            ref = oracle.plsr(X.cpu().numpy(), Y.cpu().numpy(), A)
+            assert po.rel_fro(o["B"].cpu().numpy(), oracle.coefficients(ref["R"], ref["Q"])) < 1e-10
+            X.copy_(h.synth_x(0, N, K, 11))
+        o3 = h.fit_device(X[:2000], Y[:2000], A); side.synchronize()   # another shape: eager again
+        ref = oracle.plsr(X[:2000].cpu().numpy(), Y[:2000].cpu().numpy(), A)
+        assert po.rel_fro(o3["B"].cpu().numpy(), oracle.coefficients(ref["R"], ref["Q"])) < 1e-10
+        h.set_option(pls_amd.OPT_GRAPH, 0)
+        h.close()
+
+
 def _fold_reference(oracle, Xh, Yh, A, idx):
     nf, ts = idx.shape
     ref = np.zeros((Yh.shape[1], nf * ts, A))
