@@ -297,12 +297,17 @@ def main():
                 e2 = time.perf_counter() - t0
                 t2 = h.timing()
                 n2 = max(t2["launches"]["xty"], 1)
-                syrk_ms = t2["ms"]["xty"] / t2["fits"] - tm["ms"]["xty"] / max(tm["fits"], 1)
+                # the xty family of a KERNEL_TYPE2 fit: the SYRK launch alone when X^T Y rides along in its diagonal
+                # workgroups (one launch per fit), otherwise SYRK + the separate X^T Y pass the main plan also has
+                syrk_ms = t2["ms"]["xty"] / t2["fits"]
+                xy_on_board = t2["launches"]["xty"] <= t2["fits"]
+                if not xy_on_board:
+                    syrk_ms -= tm["ms"]["xty"] / max(tm["fits"], 1)
                 nbk = (K + 127) // 128                      # 128 x 128 blocks = 64 tiles of 16 x 16: the blocks above the diagonal
                 tiles = 64 * (nbk * (nbk - 1) // 2) + 40 * nbk   # in full, 40 tiles (4 waves x 10) of every diagonal block
                 executed = 2.0 * N * 16 * 16 * tiles
                 alt["type2_mfma_syrk"] = {"components_per_s": round(A * st / e2, 2), "ms_per_fit": round(e2 / st * 1e3, 3),
-                                          "syrk_ms": round(syrk_ms, 3),
+                                          "syrk_ms": round(syrk_ms, 3), "syrk_launch_also_forms_xty": bool(xy_on_board),
                                           "syrk_tflops_executed": round(executed / (syrk_ms * 1e-3) / 1e12, 2) if syrk_ms > 0 else None,
                                           "syrk_tflops_nominal_2NK2_symmetry_counted": round(2.0 * N * K * K / (syrk_ms * 1e-3) / 1e12, 2) if syrk_ms > 0 else None,
                                           "fp64_mfma_peak_tflops": 78.6,

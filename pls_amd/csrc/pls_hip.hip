@@ -58,7 +58,7 @@ struct pls_hip_context {
     // PLS_HIP_OPT_GRAPH: the last repeated device-memory fit as an executable graph (one entry: a loop of identical fits)
     std::vector<uint64_t> graph_key, graph_seen;
     hipGraphExec_t graph_exec = nullptr;
-    DevBuf zeros, part, sspart, red, red2, xx, praw, xy, v, cs, coop, lm, gxx, gxy, tab, work, cvidx, cvx, cvy, cvws, cve, cvtx, cvty, cvtt, cvm, cvkeep, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
+    DevBuf zeros, part, sspart, red, red2, xx, xyp, praw, xy, v, cs, coop, lm, gxx, gxy, tab, work, cvidx, cvx, cvy, cvws, cve, cvtx, cvty, cvtt, cvm, cvkeep, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
     std::vector<hipEvent_t> ev_pool;  // grows until pls_hip_get_timing harvests and recycles it
@@ -561,10 +561,16 @@ int do_allreduce(pls_hip_context *c, double *buf, i64 count) {
 // Whichever kernels the LOCAL shard takes (its row count, alignment and leading dimension decide, and an
 // empty shard runs none), the exchange is always ONE all-reduce of RED_SLICES*K*K values in the same layout:
 // the ranks of a sharded fit can never disagree on the sequence of collectives.
+// compute_xx_local: this rank's X^T X into the slices of c->red2 (no collective).  With Y and xy_red given, the matrix-core
+// path forms X^T Y in the same sweep (its diagonal workgroups, syrk_kernels.hpp) and leaves it, reduced into slices, in
+// xy_red; *xy_done says whether it did (the caller runs the separate X^T Y kernel otherwise).
+// compute_xx_finish: the one all-reduce of the slices and their sum -> XX.
 template <typename T>
-int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX) {
+int compute_xx_local(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const T *Y = nullptr, i64 ldy = 0, int M = 0,
+                     double *xy_red = nullptr, bool *xy_done = nullptr) {
     constexpr int CB = 32;
     const i64 KK = (i64)K * K;
+    if (xy_done) *xy_done = false;
     CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * KK * 8));
     double *red2 = (double *)c->red2.p;
     bool have = false;
@@ -574,7 +580,7 @@ int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX
         const i64 S = std::max<i64>(1, (16 * (i64)c->num_cu + nbk * (nbk + 1) / 2 - 1) / (nbk * (nbk + 1) / 2));  // capacity bound
         if (ensure(c, c->part, (size_t)S * KK * 8) == PLS_HIP_OK) {
             double *part = (double *)c->part.p;
-            int nb = 0;
+            int nb = 0, nb_xy = 0;
             int rc;
             {
                 Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) * ((nbk + 1)) + KK * 8);
@@ -584,14 +590,24 @@ int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX
                 }
                 // PLS_HIP_SYRK_GLDS=0 in the environment selects the register-staged kernel (A/B measurements only)
                 static const bool glds = !(getenv("PLS_HIP_SYRK_GLDS") && atoi(getenv("PLS_HIP_SYRK_GLDS")) == 0);
+                static const bool fuse_xy = !(getenv("PLS_HIP_SYRK_XY") && atoi(getenv("PLS_HIP_SYRK_XY")) == 0);
+                const i64 xycap = 64 * (i64)K * std::max(M, 1);  // at most 64 row splits of a diagonal block
+                const bool want_xy = fuse_xy && glds && Y && xy_red && M >= 1 && M <= 8 &&
+                                     ensure(c, c->xyp, (size_t)xycap * 8) == PLS_HIP_OK;
+                if (!want_xy) c->err.clear();
                 rc = plsk::launch_syrk<T>(c->stream, c->num_cu, X, ldx, N, K, part, S * KK, &nb,
-                                          glds ? c->zeros.p : nullptr);
+                                          glds ? c->zeros.p : nullptr, want_xy ? Y : nullptr, ldy, M,
+                                          want_xy ? (double *)c->xyp.p : nullptr, xycap, want_xy ? &nb_xy : nullptr);
                 if (rc != 0) s.on = false;
             }
             if (rc == 0) {
                 LAUNCH_CHECK(c);
                 CHK(launch_reduce(c, part, nb, (int)KK, nullptr, 0, red2));
                 have = true;
+                if (nb_xy > 0) {
+                    CHK(launch_reduce(c, (const double *)c->xyp.p, nb_xy, K * M, nullptr, 0, xy_red));
+                    *xy_done = true;
+                }
             }
         } else {
             c->err.clear();  // no room for the partial blocks: the column-block path needs far less
@@ -610,11 +626,23 @@ int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX
     } else {
         HIPCHK(c, hipMemsetAsync(red2, 0, (size_t)plsk::RED_SLICES * KK * 8, c->stream));
     }
+    return PLS_HIP_OK;
+}
+
+int compute_xx_finish(pls_hip_context *c, int K, double *XX) {
+    const i64 KK = (i64)K * K;
+    double *red2 = (double *)c->red2.p;
     CHK(do_allreduce(c, red2, (i64)plsk::RED_SLICES * KK));
     hipLaunchKernelGGL(plsk::sum_slices_kernel, dim3((unsigned)((KK + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
                        c->stream, (const double *)red2, (int)KK, XX);
     LAUNCH_CHECK(c);
     return PLS_HIP_OK;
+}
+
+template <typename T>
+int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX) {
+    CHK(compute_xx_local<T>(c, X, ldx, N, K));
+    return compute_xx_finish(c, K, XX);
 }
 
 // ---- the fit on device pointers -----------------------------------------------------------
@@ -730,14 +758,24 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     Range r_fit("pls_hip_fit");
     std::unique_ptr<Range> r_phase(new Range("X^T Y"));
     const bool use_pre = have_pre && (gram || method == PLS_HIP_KERNEL_TYPE2);
+    bool xy_from_syrk = false, xx_local_done = false;
     if (use_pre) {
         hipLaunchKernelGGL(plsk::fill_slices_kernel, dim3((unsigned)((L0 + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
                            c->stream, c->pre_xy, (int)L0, red);
         LAUNCH_CHECK(c);
     } else if (N > 0) {
-        int nb = 0;
-        CHK(launch_xty<T>(c, X, ldx, Y, ldy, N, K, M, part, &nb));
-        CHK(launch_reduce(c, part, nb, (int)L0, nullptr, 0, red));
+        // KERNEL_TYPE2 / GRAM: the SYRK's diagonal workgroups form X^T Y on the way (no pass over X of its own); its
+        // partial blocks take c->part, so it runs first and `part` is read again afterwards
+        if (type2) {
+            CHK(compute_xx_local<T>(c, X, ldx, N, K, Y, ldy, M, red, &xy_from_syrk));
+            xx_local_done = true;
+            part = (double *)c->part.p;
+        }
+        if (!xy_from_syrk) {
+            int nb = 0;
+            CHK(launch_xty<T>(c, X, ldx, Y, ldy, N, K, M, part, &nb));
+            CHK(launch_reduce(c, part, nb, (int)L0, nullptr, 0, red));
+        }
     } else {
         HIPCHK(c, hipMemsetAsync(red, 0, (size_t)plsk::RED_SLICES * L0 * 8, c->stream));
     }
@@ -764,7 +802,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                                c->stream, (const double *)c->red2.p, (int)KK, XX);
             LAUNCH_CHECK(c);
         } else {
-            CHK(compute_xx<T>(c, X, ldx, N, K, XX));
+            if (!xx_local_done) CHK(compute_xx_local<T>(c, X, ldx, N, K));  // (an empty shard: zero slices)
+            CHK(compute_xx_finish(c, K, XX));
         }
         r_phase.reset();
         for (int a = 0; a < A; ++a) {
@@ -1094,7 +1133,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
+    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->xyp, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
                       &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->cvtx, &h->cvty, &h->cvtt, &h->cvm, &h->cvkeep, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)

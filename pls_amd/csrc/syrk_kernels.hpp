@@ -198,9 +198,13 @@ __device__ __forceinline__ void syrk_slab_mfma(const T *As, const T *Bs, int a0,
 // beyond sd only zero their slot of the partial buffer): 8.5 instead of 10 block-times at K = 512.
 // One workgroup's share of a block for the tile set MASK: slabs s0, s0 + nsplit, ... of the panels bi (A) and bj (B).
 // Out of line: the two instantiations then get a register allocation each (inlined side by side in one kernel they spill).
-template <typename T, unsigned MASK>
+// WITH_Y (diagonal blocks only): the workgroup also forms X^T Y (src/pls.cpp:396) for the 128 columns of its panel from the
+// slabs as they lie in LDS -- thread = (column, half of the slab's rows), M <= 8 accumulators; the slab's rows of Y arrive by one
+// more LDS-DMA instruction -- so that a KERNEL_TYPE2 / GRAM fit needs no separate pass over X for it.  xy_out: this row split's partial, K x M (ld K).
+template <typename T, unsigned MASK, bool WITH_Y>
 __device__ __noinline__ void syrk_glds_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, int bj, i64 s0, int nsplit,
-                                            const T *__restrict__ zeros, double *__restrict__ out) {
+                                            const T *__restrict__ zeros, double *__restrict__ out, const T *__restrict__ Y, i64 ldy,
+                                            int M, double *__restrict__ xy_out) {
     // (declared here, not passed in: a pointer argument of an out-of-line function is a generic pointer, and LDS reads
     // through it become flat loads)
     extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];  // [2 buffers][A panel, B panel]
@@ -223,6 +227,14 @@ __device__ __noinline__ void syrk_glds_body(const T *__restrict__ X, i64 ldx, i6
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
+    double accy[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) accy[m] = 0.0;
+    // X^T Y: column of the panel, half of the slab's 8 row positions.  Neighbouring lanes = the two halves of a column and
+    // columns with different swizzle keys: the 16-byte reads of a group of 8 lanes land on 4 different bank groups (with
+    // lane = column they all collide: 8-way conflicts, 0.8 instead of 0.7 of a full block's time per slab)
+    const int yc = tid >> 1, yh = tid & 1;
+    const int ykey = (yc >> 1) & 7;
 
     const i64 nslabs = (N + RB - 1) / RB;
     auto issue = [&](i64 s, int buf) {
@@ -243,6 +255,14 @@ __device__ __noinline__ void syrk_glds_body(const T *__restrict__ X, i64 ldx, i6
                 glds16(gb, Bb + i * (8 * CS));
             }
         }
+        if constexpr (WITH_Y) {  // the slab's rows of Y, [response][8 positions of 16 bytes]: one DMA instruction of wave 0
+            if (wv == 0) {
+                const int m = lane >> 3, pos = lane & 7;
+                const i64 row = s * RB + (i64)pos * V;
+                const T *gy = (row < N && m < M) ? Y + row + (i64)m * ldy : zeros;
+                glds16(gy, lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS));
+            }
+        }
     };
 
     i64 s = s0;
@@ -250,9 +270,36 @@ __device__ __noinline__ void syrk_glds_body(const T *__restrict__ X, i64 ldx, i6
     if (s < nslabs) issue(s, 0);
     for (; s < nslabs; s += nsplit, buf ^= 1) {
         __syncthreads();  // vmcnt(0) + barrier: slab s has landed for every wave; the other buffer is free again
-        if (s + nsplit < nslabs) issue(s + nsplit, buf ^ 1);
         const T *As = lds + (size_t)buf * 2 * PANEL, *Bs = diag ? As : As + PANEL;
+        // (X^T Y before the next slab's DMA is issued: the compiler puts s_waitcnt vmcnt(0) in front of these LDS reads, which
+        // behind the issue would wait for the slab that was just requested)
+        if constexpr (WITH_Y) {
+            const T *Ys = lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pos = 4 * yh + q;
+                const Pack<T, V> xv = *reinterpret_cast<const Pack<T, V> *>(As + yc * CS + ((pos ^ ykey) * V));
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    if (m < M) {
+                        const Pack<T, V> yv = *reinterpret_cast<const Pack<T, V> *>(Ys + (m * 8 + pos) * V);  // every lane of a wave: the same address
+#pragma unroll
+                        for (int e = 0; e < V; ++e) accy[m] = fma((double)xv.v[e], (double)yv.v[e], accy[m]);
+                    }
+            }
+        }
+        if (s + nsplit < nslabs) issue(s + nsplit, buf ^ 1);
         syrk_slab_mfma<T, MASK, V, RB, CS>(As, Bs, a0, b0, li, lq, fl, acc);
+    }
+    if constexpr (WITH_Y) {  // the two row halves of a column, then one partial row of X^T Y per row split
+        __syncthreads();     // the panels have been read
+        double *ysh = reinterpret_cast<double *>(slab_raw);  // [2][128][8]
+#pragma unroll
+        for (int m = 0; m < 8; ++m) ysh[(yh * SYRK_TB + yc) * 8 + m] = accy[m];
+        __syncthreads();
+        const int col = bi * SYRK_TB + yc;
+        if (yh == 0 && col < K)
+            for (int m = 0; m < M; ++m) xy_out[col + (i64)m * K] = ysh[yc * 8 + m] + ysh[(SYRK_TB + yc) * 8 + m];
     }
 
     // f64 C/D layout: lane holds D[row = (lane>>4) + 4*reg][col = lane&15]; row <-> a, col <-> b.  Every computed tile is
@@ -277,7 +324,8 @@ __device__ __noinline__ void syrk_glds_body(const T *__restrict__ X, i64 ldx, i6
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void syrk_glds_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
-                                                           const T *__restrict__ zeros, double *__restrict__ part, int so, int sd) {
+                                                           const T *__restrict__ zeros, double *__restrict__ part, int so, int sd,
+                                                           const T *__restrict__ Y, i64 ldy, int M, double *__restrict__ xypart) {
     // 1-D grid, exactly the workgroups that have rows: first so splits of every off-diagonal block, then sd of every
     // diagonal block (workgroups that only exit still take a dispatch slot: a 2-D grid with idle members ran 7.8 ms
     // instead of 6.1).  A diagonal block has fewer partials than the so the reduction sums: its workgroup j also zeroes
@@ -313,9 +361,12 @@ __global__ __launch_bounds__(256, 2) void syrk_glds_kernel(const T *__restrict__
                 if (ga_ < K && gb_ < K) zo[ga_ + (i64)gb_ * K] = 0.0;
             }
         }
-        syrk_glds_body<T, SYRK_UPPER>(X, ldx, N, K, bi, bj, split, sd, zeros, out);
+        if (Y)
+            syrk_glds_body<T, SYRK_UPPER, true>(X, ldx, N, K, bi, bj, split, sd, zeros, out, Y, ldy, M, xypart + (i64)split * ((i64)K * M));
+        else
+            syrk_glds_body<T, SYRK_UPPER, false>(X, ldx, N, K, bi, bj, split, sd, zeros, out, nullptr, 0, 0, nullptr);
     } else {
-        syrk_glds_body<T, SYRK_ALL>(X, ldx, N, K, bi, bj, split, so, zeros, out);
+        syrk_glds_body<T, SYRK_ALL, false>(X, ldx, N, K, bi, bj, split, so, zeros, out, nullptr, 0, 0, nullptr);
     }
 }
 
@@ -323,7 +374,9 @@ __global__ __launch_bounds__(256, 2) void syrk_glds_kernel(const T *__restrict__
 // zeros: >= 16 bytes of device zeros (source of the rows beyond N in the LDS-DMA variant); nullptr = register-staged kernel
 template <typename T>
 int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int K, double *part,
-                i64 part_capacity_doubles, int *nb, const void *zeros = nullptr) {
+                i64 part_capacity_doubles, int *nb, const void *zeros = nullptr, const T *Y = nullptr, i64 ldy = 0, int M = 0,
+                double *xypart = nullptr, i64 xypart_capacity_doubles = 0, int *nb_xy = nullptr) {
+    if (nb_xy) *nb_xy = 0;
     constexpr int SYRK_RB = SyrkCfg<T>::RB;
     const size_t SYRK_LDS_BYTES = SyrkCfg<T>::LDS_BYTES;
     if (((uintptr_t)X % 16) != 0 || (ldx % SyrkCfg<T>::V) != 0 || N < 1) return 1;
@@ -341,16 +394,20 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
     constexpr int V = SyrkCfg<T>::V;
     if (zeros && N % V == 0 && K >= 1) {  // LDS-DMA variant: slabs of 8 V rows, two LDS buffers of two panels
         constexpr int RBG = 8 * V;
-        constexpr size_t LDS_G = 2 * 2 * (size_t)SYRK_TB * 128;
+        constexpr size_t LDS_G = 2 * 2 * (size_t)SYRK_TB * 128 + 2 * 1024;  // two buffers of two panels + two slabs of Y
         const i64 nslabs_g = (N + RBG - 1) / RBG;
         i64 Sg = nblocks <= slots ? slots / nblocks : (8 * slots + nblocks - 1) / nblocks;
         i64 Sd = 0;  // row splits of the diagonal blocks; 0 = as the others (several residency waves balance themselves)
         static const bool tri = !(getenv("PLS_HIP_SYRK_TRI") && atoi(getenv("PLS_HIP_SYRK_TRI")) == 0);
-        if (tri && nblocks <= slots) {  // one residency wave: a diagonal workgroup costs 10/16 per slab and takes 16/10 of the rows
-            const double units = (nblocks - nbk) + 0.625 * nbk;
+        // X^T Y rides along in the diagonal workgroups (one partial row per row split of a diagonal block)
+        const bool fuse_y0 = Y && xypart && nb_xy && M >= 1 && M <= 8 && ((uintptr_t)Y % 16) == 0 && (ldy % V) == 0;
+        if (tri && nblocks <= slots) {  // one residency wave: a diagonal workgroup costs 10/16 per slab (more with X^T Y on board)
+            static const double wenv = getenv("PLS_HIP_SYRK_DIAGW") ? atof(getenv("PLS_HIP_SYRK_DIAGW")) : 0.0;
+            const double dw = wenv > 0.0 ? wenv : (fuse_y0 ? 0.78 : 0.625);  // measured optimum with X^T Y on board: 0.78-0.80
+            const double units = (nblocks - nbk) + dw * nbk;
             Sg = (i64)(slots / units);
-            Sd = std::max<i64>(1, (i64)(0.625 * Sg));
-            while ((nblocks - nbk) * Sg + nbk * Sd > slots && Sg > 1) { --Sg; Sd = std::max<i64>(1, (i64)(0.625 * Sg)); }
+            Sd = std::max<i64>(1, (i64)(dw * Sg));
+            while ((nblocks - nbk) * Sg + nbk * Sd > slots && Sg > 1) { --Sg; Sd = std::max<i64>(1, (i64)(dw * Sg)); }
         }
         Sg = std::max<i64>(1, std::min<i64>(Sg, nslabs_g));
         Sg = std::min<i64>(Sg, part_capacity_doubles / ((i64)K * K));
@@ -359,8 +416,10 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         if (!tri) Sd = Sg;
         if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_glds_kernel<T>), (int)LDS_G)) return 1;
         const i64 nwg = (i64)(nblocks - nbk) * Sg + (i64)nbk * Sd;
+        const bool fuse_y = fuse_y0 && Sd * (i64)K * M <= xypart_capacity_doubles;
         hipLaunchKernelGGL(syrk_glds_kernel<T>, dim3((unsigned)nwg), dim3(256), LDS_G, stream, X, ldx, N, K, nbk,
-                           static_cast<const T *>(zeros), part, (int)Sg, (int)Sd);
+                           static_cast<const T *>(zeros), part, (int)Sg, (int)Sd, fuse_y ? Y : nullptr, ldy, M, xypart);
+        if (fuse_y) *nb_xy = (int)Sd;
         *nb = (int)Sg;
         return 0;
     }
