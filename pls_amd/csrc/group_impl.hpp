@@ -424,9 +424,11 @@ int pls_hip_group_upload_xy(pls_hip_group g, const void *hostX, int64_t ldx, con
     X->gram_xy.assign(g->n, nullptr);
     const size_t es = esize(dtype);
     std::vector<char> okv(g->n, 0);
+    // data small enough for the single-launch fit (tiny_kernels.hpp; any A that fits its LDS): X^T X would never be read
+    const bool single_launch_data = g->n == 1 && plsk::tiny_fit_covers(N, (int)K, (int)M, 1, X->ld[0], es);
     rc = run_members(g, [&](int r) -> int {
         pls_hip_context *c = g->h[r];
-        if (hipMalloc((void **)&X->gram_xx[r], (size_t)K * K * 8) != hipSuccess ||
+        if (single_launch_data || hipMalloc((void **)&X->gram_xx[r], (size_t)K * K * 8) != hipSuccess ||
             hipMalloc((void **)&X->gram_xy[r], (size_t)K * M * 8) != hipSuccess) {
             (void)hipGetLastError();  // no room for the products: a plain upload
             CHK(h2d(c, Y->data[r], Y->ld[r], (const char *)hostY + (size_t)Y->row0[r] * es, ldy, Y->nrows[r], M, es));

@@ -654,6 +654,23 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // AUTO: pick between the read-only pass plan and the Gram plan from a bandwidth / matrix-core cost
     // model (measured rates on MI355X: ~6 TB/s streaming reads, ~59 TFLOP/s executed in the fp64 SYRK of
     // which the symmetric half is computed).  GRAM pays off for A >~ K/60.
+    // A single-response problem small enough for one workgroup's registers: the whole fit in ONE launch (tiny_kernels.hpp) instead of
+    // three launches per component, whose dispatch latency would be the entire cost.  The reference's sequence, so the
+    // KERNEL plan and AUTO (also when X^T X came with the upload: one launch beats the K x K loop's sixty);
+    // an explicit NIPALS or GRAM request keeps its own kernels.
+    if (method == PLS_HIP_KERNEL_TYPE1 && (c->opt_algo == PLS_HIP_ALGO_KERNEL || c->opt_algo == PLS_HIP_ALGO_AUTO) && c->opt_fuse &&
+        !c->reducer && plsk::tiny_fit_covers(N, K, M, A, ldx, sizeof(T)) &&
+        !(getenv("PLS_HIP_TINY") && atoi(getenv("PLS_HIP_TINY")) == 0)) {
+        const size_t lds = (size_t)2 * K * A * 8;
+        if (!plsk::raise_dynamic_lds((const void *)plsk::tiny_fit_kernel<T>, (int)plsk::TINY_LDS_MAX)  /* raised once per device: to the most any fit asks for */)
+            return fail(c, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the single-launch fit could not be raised");
+        Range r_fit("pls_hip_fit (single launch)");
+        Scope s(c, PLS_HIP_FAM_SMALL, ((i64)N * K + (i64)N * M + (i64)N * A) * (i64)sizeof(T) + (3 * (i64)K + M) * A * 8);
+        hipLaunchKernelGGL((plsk::tiny_fit_kernel<T>), dim3(1), dim3(plsk::UPD_THREADS), lds, c->stream, X, ldx, Y, (int)N, K, A,
+                           W, P, Q, R, Tm, ldt, B, (const i64 *)nullptr, 0, (i64)0, (double *)nullptr);
+        LAUNCH_CHECK(c);
+        return PLS_HIP_OK;
+    }
     i64 algo = c->opt_algo;
     const bool have_pre = c->pre_xx && c->pre_xy && K <= 32768;
     if (algo == PLS_HIP_ALGO_AUTO && have_pre) {
@@ -674,21 +691,6 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     const bool nipals = !type2 && (algo == PLS_HIP_ALGO_NIPALS);
     const int nip = nipals ? 1 : 0;
     const i64 L0 = (i64)K * M;
-    // A single-response problem small enough for one workgroup's registers: the whole fit in ONE launch (tiny_kernels.hpp) instead of
-    // three launches per component, whose dispatch latency would be the entire cost.  The reference's sequence, so the
-    // KERNEL plan (and AUTO); an explicit NIPALS or GRAM request keeps its own kernels.
-    if (!type2 && !nipals && c->opt_fuse && !c->reducer && plsk::tiny_fit_covers(N, K, M, A, ldx, sizeof(T)) &&
-        !(getenv("PLS_HIP_TINY") && atoi(getenv("PLS_HIP_TINY")) == 0)) {
-        const size_t lds = (size_t)2 * K * A * 8;
-        if (!plsk::raise_dynamic_lds((const void *)plsk::tiny_fit_kernel<T>, lds))
-            return fail(c, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the single-launch fit could not be raised");
-        Range r_fit("pls_hip_fit (single launch)");
-        Scope s(c, PLS_HIP_FAM_SMALL, ((i64)N * K + (i64)N * M + (i64)N * A) * (i64)sizeof(T) + (3 * (i64)K + M) * A * 8);
-        hipLaunchKernelGGL((plsk::tiny_fit_kernel<T>), dim3(1), dim3(plsk::UPD_THREADS), lds, c->stream, X, ldx, Y, (int)N, K, A,
-                           W, P, Q, R, Tm, ldt, B, (const i64 *)nullptr, 0, (i64)0, (double *)nullptr);
-        LAUNCH_CHECK(c);
-        return PLS_HIP_OK;
-    }
     const i64 redn = (i64)plsk::RED_SLICES * std::max<i64>(L0, K + 1);
     const i64 prow = max_partial_rows(c, N, K);
     CHK(ensure(c, c->part, (size_t)prow * (size_t)std::max<i64>(L0, K) * 8));
@@ -1295,7 +1297,9 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
         // fit must not differ in their plan.
         bool pre = false;
         const bool wants_gram = h->opt_algo == PLS_HIP_ALGO_AUTO || h->opt_algo == PLS_HIP_ALGO_GRAM || method == PLS_HIP_KERNEL_TYPE2;
-        if (wants_gram && !h->reducer && N > 0 && K <= 4096 && ensure(h, h->gxx, (size_t)K * K * 8) == PLS_HIP_OK &&
+        const bool single_launch = method == PLS_HIP_KERNEL_TYPE1 && h->opt_algo == PLS_HIP_ALGO_AUTO && h->opt_fuse &&
+                                   plsk::tiny_fit_covers(N, Ki, Mi, Ai, ldn, es);  // (no use for X^T X there)
+        if (wants_gram && !single_launch && !h->reducer && N > 0 && K <= 4096 && ensure(h, h->gxx, (size_t)K * K * 8) == PLS_HIP_OK &&
             ensure(h, h->gxy, (size_t)K * M * 8) == PLS_HIP_OK) {
             if (dtype == PLS_HIP_F64)
                 CHK(upload_accumulate<double>(h, (double *)h->hX.p, ldn, (const double *)X, ldx, N, Ki, (const double *)h->hY.p, ldn,
@@ -1640,7 +1644,7 @@ int cv_folds_tiny(pls_hip_context *h, const T *dX, i64 dldx, const T *dY, i64 N,
     CHK(ensure(h, h->cvidx, (size_t)nobs * 8));
     HIPCHK(h, hipMemcpyAsync(h->cvidx.p, test_idx, (size_t)nobs * 8, hipMemcpyHostToDevice, h->stream));
     const size_t lds = (size_t)2 * Ki * Ai * 8;
-    if (!plsk::raise_dynamic_lds((const void *)plsk::tiny_fit_kernel<T>, lds))
+    if (!plsk::raise_dynamic_lds((const void *)plsk::tiny_fit_kernel<T>, (int)plsk::TINY_LDS_MAX)  /* raised once per device: to the most any fit asks for */)
         return fail(h, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the single-launch fit could not be raised");
     Scope s(h, PLS_HIP_FAM_SMALL, (i64)num_folds * N * Ki * (i64)sizeof(T));
     hipLaunchKernelGGL((plsk::tiny_fit_kernel<T>), dim3((unsigned)num_folds), dim3(plsk::UPD_THREADS), lds, h->stream, dX, dldx, dY,
