@@ -275,16 +275,27 @@ __device__ __noinline__ void syrk_glds_body(const T *__restrict__ X, i64 ldx, i6
         // behind the issue would wait for the slab that was just requested)
         if constexpr (WITH_Y) {
             const T *Ys = lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS);
+            Pack<T, V> xv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int pos = 4 * yh + q;
-                const Pack<T, V> xv = *reinterpret_cast<const Pack<T, V> *>(As + yc * CS + ((pos ^ ykey) * V));
+            for (int q = 0; q < 4; ++q)
+                xv[q] = *reinterpret_cast<const Pack<T, V> *>(As + yc * CS + (((4 * yh + q) ^ ykey) * V));
+            if (M == 1) {  // the usual case, without the per-response branches
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const Pack<T, V> yv = *reinterpret_cast<const Pack<T, V> *>(Ys + (4 * yh + q) * V);  // every lane of a wave: the same address
+#pragma unroll
+                    for (int e = 0; e < V; ++e) accy[0] = fma((double)xv[q].v[e], (double)yv.v[e], accy[0]);
+                }
+            } else {
 #pragma unroll
                 for (int m = 0; m < 8; ++m)
                     if (m < M) {
-                        const Pack<T, V> yv = *reinterpret_cast<const Pack<T, V> *>(Ys + (m * 8 + pos) * V);  // every lane of a wave: the same address
 #pragma unroll
-                        for (int e = 0; e < V; ++e) accy[m] = fma((double)xv.v[e], (double)yv.v[e], accy[m]);
+                        for (int q = 0; q < 4; ++q) {
+                            const Pack<T, V> yv = *reinterpret_cast<const Pack<T, V> *>(Ys + (m * 8 + 4 * yh + q) * V);
+#pragma unroll
+                            for (int e = 0; e < V; ++e) accy[m] = fma((double)xv[q].v[e], (double)yv.v[e], accy[m]);
+                        }
                     }
             }
         }
@@ -403,7 +414,8 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         const bool fuse_y0 = Y && xypart && nb_xy && M >= 1 && M <= 8 && ((uintptr_t)Y % 16) == 0 && (ldy % V) == 0;
         if (tri && nblocks <= slots) {  // one residency wave: a diagonal workgroup costs 10/16 per slab (more with X^T Y on board)
             static const double wenv = getenv("PLS_HIP_SYRK_DIAGW") ? atof(getenv("PLS_HIP_SYRK_DIAGW")) : 0.0;
-            const double dw = wenv > 0.0 ? wenv : (fuse_y0 ? 0.78 : 0.625);  // measured optimum with X^T Y on board: 0.78-0.80
+            // measured optima with X^T Y on board: 0.70 for one response (branch-free step), 0.78-0.80 for several
+            const double dw = wenv > 0.0 ? wenv : (fuse_y0 ? (M == 1 ? 0.70 : 0.78) : 0.625);
             const double units = (nblocks - nbk) + dw * nbk;
             Sg = (i64)(slots / units);
             Sd = std::max<i64>(1, (i64)(dw * Sg));
