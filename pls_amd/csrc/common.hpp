@@ -127,6 +127,12 @@ __device__ __forceinline__ double wave_sum(double x) {
     return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
 }
 
+// Workgroup barrier for data exchanged through LDS ONLY.  __syncthreads() is a workgroup-scope fence as well: the
+// compiler puts s_waitcnt vmcnt(0) in front of it, i.e. every barrier that follows a global store waits for the store's
+// acknowledgement from memory.  Where nothing the workgroup stores to global memory is read back by it, the barrier only
+// has to order LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Sum over a workgroup of NW waves (blockDim.x = 64*NW); result valid in every thread.
 // smem: >= NW doubles.  Fixed order: butterfly inside the wave, then waves 0..NW-1.
 template <int NW>

@@ -52,12 +52,6 @@ inline bool tiny_fit_covers(i64 N, int K, int M, int A, i64 ldx, size_t es) {
     return sh.S >= 1 && K <= sh.S * TINY_RC && (size_t)2 * K * A * 8 <= TINY_LDS_MAX;
 }
 
-// Workgroup barrier for data exchanged through LDS ONLY.  __syncthreads() is a workgroup-scope fence as well: the
-// compiler puts s_waitcnt vmcnt(0) in front of it, i.e. every barrier that follows a global store (T, P, W, R, Q are
-// stored as they are produced) waits for the store's acknowledgement from L2 -- 1-2 us each, five times per
-// component.  Nothing this kernel stores to global memory is read back, so the barrier only has to order LDS.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // block_sum (common.hpp) on lds_barrier
 __device__ __forceinline__ double tiny_block_sum(double v, double *smem) {
     v = wave_sum(v);
