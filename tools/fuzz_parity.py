@@ -27,6 +27,7 @@ for case in range(ncases):
     else:
         N = int(rng.integers(5, 400)); K = int(rng.integers(1, 120))
     A = int(rng.integers(1, min(K, 12) + 1))
+    A = max(1, min(A, N - 1))  # beyond the rank of X the reference's results are inf / NaN (src/pls.cpp:427-428): nothing to compare
     f32 = bool(rng.integers(0, 4) == 0)
     X = one.synth_x(case * 7919, N, K); Y = one.synth_y(case * 7919, N, M)
     if f32:
@@ -37,6 +38,7 @@ for case in range(ncases):
     try:
         if kind == "cv":
             ts = int(rng.integers(1, max(2, N // 3))); nf = int(rng.integers(1, 6))
+            A = max(1, min(A, N - ts - 1))
             idx = np.stack([rng.permutation(N)[:ts] for _ in range(nf)])
             E = h.cv_folds(Xd, Yd, A, idx).cpu().numpy()
             err = 0.0
