@@ -49,6 +49,19 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
     __builtin_amdgcn_raw_buffer_store_b128(raw, r, voff, 0, AUX);
 }
 
+// 16-byte access to a score column (t_prev in, t out): the caller's T may have any leading dimension, so its columns are
+// only element-aligned; global memory accesses need dword alignment, nothing more.
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> ld_pack_u(const T *p) {
+    Pack<T, V> o;
+    __builtin_memcpy(&o, p, sizeof(o));
+    return o;
+}
+template <typename T, int V>
+__device__ __forceinline__ void st_pack_u(T *p, const Pack<T, V> &x) {
+    __builtin_memcpy(p, &x, sizeof(x));
+}
+
 // Matrix layouts: element (i, k) of a matrix with column stride ld and tile stride ts lives at
 //   (i / R) * ts + (i % R) + k * ld.
 // The caller's column-major matrices are (ld, ts = R): a tile is K separate 256-byte segments.  The
@@ -68,9 +81,50 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
 // read+write pass 1.81 -> 1.70 ms (profiles/r1/tune_fused_cache_policy.txt).
 constexpr int AUX_NT = 2;
 
+// Which tiles a workgroup visits.  Cyclic: blockIdx.x, blockIdx.x + gridDim.x, ...  XCD-contiguous (EDGE = 2, below):
+// workgroup b runs on XCD b % 8 under round-robin dispatch; every XCD takes one contiguous eighth of the tiles and its
+// workgroups walk it cyclically (grids that are a multiple of 8; cyclic otherwise).
+template <bool XCD, int R>
+struct TileWalk {
+    __device__ __forceinline__ explicit TileWalk(i64) {}
+    __device__ __forceinline__ unsigned first() const { return blockIdx.x; }
+    __device__ __forceinline__ unsigned step() const { return gridDim.x; }
+    __device__ __forceinline__ i64 nlim(i64 N) const { return N; }
+};
+template <int R>
+struct TileWalk<true, R> {
+    i64 first_, step_, nlim_;
+    __device__ __forceinline__ explicit TileWalk(i64 N) : first_(blockIdx.x), step_(gridDim.x), nlim_(N) {
+        if ((gridDim.x & 7) == 0) {
+            const i64 per = ((N + R - 1) / R + 7) / 8;
+            first_ = (i64)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+            step_ = gridDim.x >> 3;
+            nlim_ = min(N, (i64)((blockIdx.x & 7) + 1) * per * R);
+        }
+    }
+    __device__ __forceinline__ i64 first() const { return first_; }
+    __device__ __forceinline__ i64 step() const { return step_; }
+    __device__ __forceinline__ i64 nlim(i64) const { return nlim_; }
+};
+
 // RDST: the destination is stored in tiles of rdst rows, rdst dividing R (the first deflation of a fit whose working
 // copy uses shorter tiles than the R rows read at a time from the caller's column-major X); otherwise rdst is ignored.
-template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX = AUX_NT, int STAUX = AUX_NT, bool RDST = false>
+// N is a multiple of V here: the last N % V rows of a matrix (fewer than one row pack) are the tail kernel's
+// (tail_rows_kernel below), so that no instantiation carries code for partial packs.
+// EDGE -- the layouts of the caller's matrix that the plain addressing does not reach (src/pls.cpp:419-421 takes any
+// Eigen map):
+//   1: leading dimensions beyond 2^31 / (CG s) bytes: the descriptor of a load is built per WAVE (its base includes the
+//      wave's first column group), so a lane offset spans the WAVE / RP column groups of one wave, not all CG;
+//   2: columns that are not 16-byte aligned (odd ld, an X pointer at 8 mod 16).  Buffer loads only need dword alignment,
+//      but the 256-byte segment of a tile then shares a 128-byte line with the tile above and the tile below it, and every
+//      shared line is fetched twice: 4.7 instead of 6.7 TB/s however the loads are formed (two 8-byte loads, aligned
+//      supersets + lane shuffles, one row per lane: pls_amd/csrc/tune/unaligned_probe.hip).  Two changes bring most of it
+//      back (5.9 TB/s in the probe): the tiles are dealt out XCD-contiguously -- workgroup b runs on XCD b % 8 under
+//      round-robin dispatch, every XCD takes one contiguous eighth of the tiles and its workgroups walk it cyclically, so
+//      the two tiles that share a line are read at about the same time behind the SAME L2 -- and the loads drop the
+//      streaming (nt) policy, so that the line is still there.  Per-wave descriptors as in 1.
+template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX_ = AUX_NT, int STAUX = AUX_NT, bool RDST = false,
+          int EDGE = 0>
 __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pass_kernel(
     const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd, i64 N, int K,  // dst may alias X (in-place deflation)
     const double *__restrict__ v, const T *__restrict__ tprev, const double *__restrict__ pprev,
@@ -78,6 +132,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
     constexpr int RP = R / V;    // lanes along the rows of a tile
     constexpr int CG = NT / RP;  // column groups
     constexpr int NW = NT / WAVE;
+    constexpr int LDAUX = (EDGE == 2) ? 0 : LDAUX_;
     static_assert(RP <= WAVE && WAVE % RP == 0 && NT % RP == 0, "tile shape");
     // LDS: the operand vectors v [CG*CPT] and, when DEFL, p_prev [CG*CPT], the score exchange, the block-sum
     // scratch.  One static block with a fixed layout (p_prev first): the instruction schedule of the headline
@@ -110,7 +165,10 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
     for (int j = 0; j < CPT; ++j) pacc[j] = 0.0;
     double ss = 0.0;
     int buf = 0;
-    const uint32_t xoff = (uint32_t)(((i64)rp * V + (i64)cg * ldx) * (i64)sizeof(T));
+    // EDGE: one descriptor spans the CGD column groups of a wave (first group cgw), otherwise all CG of the workgroup
+    constexpr int CGD = EDGE ? WAVE / RP : CG;
+    const int cgw = EDGE ? __builtin_amdgcn_readfirstlane(cg) : 0;
+    const uint32_t xoff = (uint32_t)(((i64)rp * V + (i64)(cg - cgw) * ldx) * (i64)sizeof(T));
     uint32_t doff = DEFL ? (uint32_t)(((i64)rp * V + (i64)cg * ldd) * (i64)sizeof(T)) : 0u;
     i64 dtile = tsd;  // destination elements per source tile
     if constexpr (RDST && DEFL) {
@@ -120,7 +178,10 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
     }
     constexpr uint32_t OOR = 0x80000000u;  // beyond every num_records the launcher allows
 
-    for (i64 tile = blockIdx.x; tile * R < N; tile += gridDim.x, buf ^= 1) {
+    // EDGE = 2: XCD-contiguous tiles (grids that are a multiple of 8; cyclic otherwise).  The other instantiations fold
+    // the three values below to blockIdx.x, gridDim.x and N at compile time.
+    TileWalk<EDGE == 2, R> walk(N);
+    for (i64 tile = walk.first(); tile * R < walk.nlim(N); tile += walk.step(), buf ^= 1) {
         const i64 i0 = tile * R + (i64)rp * V;
         const bool rowok = (i0 < N);  // N % V == 0 (launcher): a pack is all-valid or all-invalid
         const uint32_t xo = rowok ? xoff : OOR, dof = rowok ? doff : OOR;
@@ -131,17 +192,17 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
         Pack<T, V> x[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const int cols = min(CG, K - CG * j);  // columns of this group that exist (may be <= 0)
+            const int cols = min(CGD, K - CG * j - cgw);  // columns of this group that exist (may be <= 0)
             const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldx * (i64)sizeof(T)) : 0u;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<T *>(X + tile * tsx + (i64)j * CG * ldx), (short)0, (int)nrec, BUF_WORD3);
+                const_cast<T *>(X + tile * tsx + (i64)(j * CG + cgw) * ldx), (short)0, (int)nrec, BUF_WORD3);
             x[j] = buf_ld<T, V, LDAUX>(rs, xo);
             __builtin_amdgcn_sched_barrier(0);  // build one descriptor, issue its load, repeat
         }
         if (DEFL) {
             double tp[V];
             if (rowok) {
-                const Pack<T, V> tpk = ld_pack<T, V>(tprev + i0);
+                const Pack<T, V> tpk = ld_pack_u<T, V>(tprev + i0);
 #pragma unroll
                 for (int e = 0; e < V; ++e) tp[e] = -(double)tpk.v[e];
             } else {
@@ -195,7 +256,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
             Pack<T, V> o;
 #pragma unroll
             for (int e = 0; e < V; ++e) o.v[e] = (T)t[e];
-            st_pack<T, V>(tout + i0, o);
+            st_pack_u<T, V>(tout + i0, o);
 #pragma unroll
             for (int e = 0; e < V; ++e) ss = fma(t[e], t[e], ss);
         }
@@ -233,7 +294,8 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
 // Same tile access pattern as the fused pass; the column groups of a tile are streamed CPT at
 // a time (nothing stays resident), the per-lane partial scores are combined once per tile.
 // Dynamic LDS: 2*K doubles (w and p_prev).
-template <typename T, int V, int R, int NT, int CPT>
+// EDGE as in fused_pass_kernel.
+template <typename T, int V, int R, int NT, int CPT, int EDGE = 0>
 __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
     const T *src, i64 lds_, i64 tss, T *dst, i64 ldd, i64 tsd, int rdst, i64 N, int K, const T *__restrict__ tprev,
     const double *__restrict__ pprev, const double *__restrict__ w, T *__restrict__ tout,
@@ -250,7 +312,10 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
         ps[k] = pprev[k];
     }
     __syncthreads();
-    const uint32_t soff = (uint32_t)(((i64)rp * V + (i64)cg * lds_) * (i64)sizeof(T));
+    constexpr int CGD = EDGE ? WAVE / RP : CG;
+    constexpr int LDAUX = (EDGE == 2) ? 0 : AUX_NT;
+    const int cgw = EDGE ? __builtin_amdgcn_readfirstlane(cg) : 0;
+    const uint32_t soff = (uint32_t)(((i64)rp * V + (i64)(cg - cgw) * lds_) * (i64)sizeof(T));
     // destination tiles may be shorter than the R rows read at a time (rdst divides R; rdst == R otherwise): the
     // lane's rows rp*V.. fall into sub-tile (rp*V)/rdst of the R/rdst destination tiles this source tile covers
     const int dsub = (rp * V) / rdst, dwithin = (rp * V) % rdst, dtiles = R / rdst;
@@ -259,13 +324,14 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
     const int ngroups = (K + CG - 1) / CG;
     double ss = 0.0;
     int buf = 0;
-    for (i64 tile = blockIdx.x; tile * R < N; tile += gridDim.x, buf ^= 1) {
+    TileWalk<EDGE == 2, R> walk(N);
+    for (i64 tile = walk.first(); tile * R < walk.nlim(N); tile += walk.step(), buf ^= 1) {
         const i64 i0 = tile * R + (i64)rp * V;
         const bool rowok = (i0 < N);
         const uint32_t so = rowok ? soff : OOR, dof = rowok ? doff : OOR;
         double tp[V], tacc[V];
         if (rowok) {
-            const Pack<T, V> tpk = ld_pack<T, V>(tprev + i0);
+            const Pack<T, V> tpk = ld_pack_u<T, V>(tprev + i0);
 #pragma unroll
             for (int e = 0; e < V; ++e) tp[e] = -(double)tpk.v[e];
         } else {
@@ -278,11 +344,11 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
             Pack<T, V> x[CPT];
 #pragma unroll
             for (int j = 0; j < CPT; ++j) {
-                const int cols = min(CG, K - CG * (g0 + j));
+                const int cols = min(CGD, K - CG * (g0 + j) - cgw);
                 const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * lds_ * (i64)sizeof(T)) : 0u;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<T *>(src + tile * tss + (i64)(g0 + j) * CG * lds_), (short)0, (int)nrec, BUF_WORD3);
-                x[j] = buf_ld<T, V, AUX_NT>(rs, so);
+                    const_cast<T *>(src + tile * tss + (i64)((g0 + j) * CG + cgw) * lds_), (short)0, (int)nrec, BUF_WORD3);
+                x[j] = buf_ld<T, V, LDAUX>(rs, so);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -319,11 +385,263 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
                 const double ts = (double)o.v[e];
                 ss = fma(ts, ts, ss);
             }
-            st_pack<T, V>(tout + i0, o);
+            st_pack_u<T, V>(tout + i0, o);
         }
     }
     ss = block_sum<NW>(ss, sred);
     if (tid == 0) sspart[blockIdx.x] = ss;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The last N % V rows of a matrix (fewer than one 16-byte row pack: at most 1 row in fp64, 3 in fp32 storage).  Every
+// kernel of this file works on whole row packs; its launcher hands these rows to ONE small workgroup that does the same
+// step element by element and contributes one more partial row -- so the reference's "any row count" (src/pls.cpp:419-421)
+// costs the hot loops nothing.  Element (i, k) of src / dst is at (i / rs) * ts + i % rs + k * ld (column-major: ts = rs).
+// Steps, each optional:  x -= tprev[i] * pprev[k]  ->  dst  ;  t[i] = sum_k x v[k] -> tout (or t = tgiven[i])  ;
+// part[k] = sum_i x t[i]  (or, with Y: part[k + m K] = sum_i x Y[i, m])  ;  *sspart = sum_i t[i]^2.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct TailArgs {
+    const T *src = nullptr; i64 lds = 0, tss = 0; int rs = 1;
+    T *dst = nullptr; i64 ldd = 0, tsd = 0; int rd = 1;
+    const T *tprev = nullptr; const double *pprev = nullptr;
+    const double *v = nullptr; T *tout = nullptr; const T *tgiven = nullptr;
+    double *part = nullptr, *sspart = nullptr;
+    const T *Y = nullptr; i64 ldy = 0; int M = 0;
+    i64 row0 = 0; int nrows = 0, K = 0;
+};
+
+template <typename T>
+__global__ __launch_bounds__(WG) void tail_rows_kernel(TailArgs<T> a) {
+    __shared__ double sm[WG / WAVE];
+    constexpr int MAXR = 16 / sizeof(T) - 1;
+    double t[MAXR];
+    double ss = 0.0;
+    for (int r = 0; r < MAXR; ++r) {
+        t[r] = 0.0;
+        if (r >= a.nrows) continue;  // (uniform)
+        const i64 i = a.row0 + r;
+        const T *srow = a.src + (i / a.rs) * a.tss + i % a.rs;
+        T *drow = a.dst ? a.dst + (i / a.rd) * a.tsd + i % a.rd : nullptr;
+        const double tp = a.tprev ? -(double)a.tprev[i] : 0.0;
+        double sum = 0.0;
+        for (int k = threadIdx.x; k < a.K; k += WG) {
+            T x = srow[(i64)k * a.lds];
+            if (a.tprev) x = (T)fma(tp, a.pprev[k], (double)x);
+            if (drow) drow[(i64)k * a.ldd] = x;
+            if (a.v) sum = fma((double)x, a.v[k], sum);
+        }
+        if (a.v) {
+            t[r] = (double)(T)block_sum<WG / WAVE>(sum, sm);  // the score as stored
+            if (threadIdx.x == 0 && a.tout) a.tout[i] = (T)t[r];
+        } else if (a.tgiven) {
+            t[r] = (double)a.tgiven[i];
+        }
+        ss = fma(t[r], t[r], ss);
+    }
+    if (a.part) {  // (every thread re-reads the elements it wrote itself)
+        const int nm = a.Y ? a.M : 1;
+        for (int k = threadIdx.x; k < a.K; k += WG)
+            for (int m = 0; m < nm; ++m) {
+                double p = 0.0;
+                for (int r = 0; r < MAXR; ++r)
+                    if (r < a.nrows) {
+                        const i64 i = a.row0 + r;
+                        const double x = a.dst ? (double)a.dst[(i / a.rd) * a.tsd + i % a.rd + (i64)k * a.ldd]
+                                               : (double)a.src[(i / a.rs) * a.tss + i % a.rs + (i64)k * a.lds];
+                        p = fma(x, a.Y ? (double)a.Y[i + (i64)m * a.ldy] : t[r], p);
+                    }
+                a.part[k + (i64)m * a.K] = p;
+            }
+    }
+    if (a.sspart && threadIdx.x == 0) *a.sspart = ss;
+}
+
+template <typename T>
+void launch_tail_rows(hipStream_t stream, const TailArgs<T> &a) {
+    hipLaunchKernelGGL((tail_rows_kernel<T>), dim3(1), dim3(WG), 0, stream, a);
+}
+
+// Copy into row-tile-major storage AND X^T Y in the same sweep (src/pls.cpp:396 on the way into the library's tiled copy):
+// what a KERNEL-plan fit needs before its first component when its passes run on the tiled copy -- wide matrices
+// (1024 < K <= 4096: one read + one write instead of retile_kernel + the separate X^T Y pass, config 4), and matrices
+// whose columns are not 16-byte aligned (every later pass then reads aligned tiles at the full rate).
+// grid = (row chunks, column blocks of CG*CPTB columns); a workgroup walks CONSECUTIVE source tiles of R rows (256-byte
+// column segments) of its column block: per tile CPTB row packs per lane in, the same packs out as one contiguous
+// CG*CPTB*rdst*s-byte piece per destination tile, CPTB*MT fp64 accumulators per lane (X^T Y of the lane's rows and
+// columns); part[blockIdx.x][k + m*K] = the workgroup's partial, the layout reduce_partials_kernel sums.
+// YLDS (several responses): the R x MT block of Y goes through LDS once per tile -- one element per thread in, the lane's
+// rows out as broadcast reads.  Loading it per lane would put MT 16-byte loads beside CPTB of X on the texture path
+// (the 32 column-group lanes of a row pack all fetch the same Y values): 2.9 instead of 0.9 ms at config 4.
+// EDGE as in fused_pass_kernel (2: unaligned columns -- plain loads; the consecutive tiles of a workgroup re-read the
+// line a segment shares with the next tile from L2).  N % V == 0 (the tail rows are the launcher's).
+template <typename T, int V, int R, int NT, int CPTB, int MT, int EDGE = 0>
+__global__ __launch_bounds__(NT, (NT / 256) * 2) void retile_xty_kernel(const T *src, i64 lds_, const T *__restrict__ Y,
+                                                                        i64 ldy, T *dst, i64 ldd, i64 tsd, int rdst, i64 N,
+                                                                        int K, int M, double *__restrict__ part, int tpw) {
+    constexpr int RP = R / V, CG = NT / RP;
+    constexpr int LDAUX = (EDGE == 2) ? 0 : AUX_NT;
+    constexpr bool YLDS = MT >= 4;
+    // tiles per iteration: with few columns per lane (MT = 8 leaves room for CPTB = 4 only) two tiles' loads are in
+    // flight at once -- 4 loads per lane and iteration left the sweep latency-bound (1.6 ms at config 4)
+    constexpr int TU = (CPTB < 8) ? 2 : 1;
+    constexpr int YE = (TU * R * MT + NT - 1) / NT;  // Y elements per thread and iteration (YLDS)
+    __shared__ alignas(16) T ys[2][YLDS ? TU * MT : 1][YLDS ? R : V];
+    const int rp = threadIdx.x % RP, cg = threadIdx.x / RP;
+    const int g0 = blockIdx.y * CPTB;  // first column group of this block
+    constexpr int CGD = EDGE ? WAVE / RP : CG;
+    const int cgw = EDGE ? __builtin_amdgcn_readfirstlane(cg) : 0;
+    const uint32_t soff = (uint32_t)(((i64)rp * V + (i64)(cg - cgw) * lds_) * (i64)sizeof(T));
+    const int dsub = (rp * V) / rdst, dwithin = (rp * V) % rdst, dtiles = R / rdst;
+    const uint32_t doff = (uint32_t)(((i64)dsub * tsd + dwithin + (i64)cg * ldd) * (i64)sizeof(T));
+    constexpr uint32_t OOR = 0x80000000u;
+    const i64 ntiles = (N + R - 1) / R;
+    const i64 tile0 = (i64)blockIdx.x * tpw, tile1 = min(ntiles, tile0 + (i64)tpw);
+    double acc[CPTB][MT];
+#pragma unroll
+    for (int j = 0; j < CPTB; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = 0.0;
+    int buf = 0;
+    for (i64 tile = tile0; tile < tile1; tile += TU, buf ^= 1) {
+        Pack<T, V> x[TU][CPTB];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const bool rowok = (tile + u < tile1) && ((tile + u) * R + (i64)rp * V < N);
+#pragma unroll
+            for (int j = 0; j < CPTB; ++j) {
+                const int cols = min(CGD, K - CG * (g0 + j) - cgw);
+                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * lds_ * (i64)sizeof(T)) : 0u;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<T *>(src + (tile + u) * R + (i64)((g0 + j) * CG + cgw) * lds_), (short)0, (int)nrec, BUF_WORD3);
+                x[u][j] = buf_ld<T, V, LDAUX>(rs, rowok ? soff : OOR);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (YLDS) {  // the responses of the TU tiles' rows: one pass through LDS (rows >= N, tiles of the next chunk: zeros)
+#pragma unroll
+            for (int q = 0; q < YE; ++q) {
+                const int idx = threadIdx.x + q * NT;  // = (u * MT + m) * R + row
+                const int yr = idx % R, ym = (idx / R) % MT, yu = idx / (R * MT);
+                const i64 row = (tile + yu) * R + yr;
+                if (idx < TU * R * MT)
+                    ys[buf][yu * MT + ym][yr] = (ym < M && tile + yu < tile1 && row < N) ? Y[row + (i64)ym * ldy] : (T)0;
+            }
+            __syncthreads();  // (two buffers: iteration t + 2 writes after every thread has passed this point for t + 1)
+        }
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const i64 i0 = (tile + u) * R + (i64)rp * V;
+            const bool rowok = (tile + u < tile1) && (i0 < N);
+            const uint32_t dof = rowok ? doff : OOR;
+#pragma unroll
+            for (int j = 0; j < CPTB; ++j) {
+                const int k = cg + CG * (g0 + j);
+                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+                    dst + (tile + u) * dtiles * tsd + (i64)(g0 + j) * CG * ldd, (short)0, 0x7fffffff, BUF_WORD3);
+                buf_st<T, V, AUX_NT>(rd, (k < K) ? dof : OOR, x[u][j]);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                Pack<T, V> yp;
+                if constexpr (YLDS) {
+                    yp = *reinterpret_cast<const Pack<T, V> *>(&ys[buf][u * MT + m][rp * V]);
+                } else {
+                    if (m < M && rowok) {
+                        yp = ld_pack_u<T, V>(Y + i0 + (i64)m * ldy);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) yp.v[e] = (T)0;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const double ye = (double)yp.v[e];
+#pragma unroll
+                    for (int j = 0; j < CPTB; ++j) acc[j][m] = fma((double)x[u][j].v[e], ye, acc[j][m]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CPTB; ++j) {
+        const int k = cg + CG * (g0 + j);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const double s = xor_range_sum<1, RP>(acc[j][m]);
+            if (rp == 0 && k < K && m < M) part[(i64)blockIdx.x * ((i64)K * M) + k + (i64)m * K] = s;
+        }
+    }
+}
+
+// shared by the launchers: 16-byte aligned columns / element alignment; the span of the column groups behind one descriptor
+template <typename T>
+inline bool cols_aligned(const void *q, i64 ld) {
+    constexpr int V = 16 / sizeof(T);
+    return ((uintptr_t)q % 16 == 0) && (ld % V == 0);
+}
+template <typename T>
+inline bool elem_aligned(const void *q) { return (uintptr_t)q % sizeof(T) == 0; }
+// EDGE level of a source matrix (ld in elements) read with tiles of RP row lanes: 0 plain, 1 per-wave descriptors
+// (long columns), 2 unaligned columns; -1 = not addressable at all
+template <typename T>
+inline int edge_level(const void *q, i64 ld, int cg_all, int cg_wave) {
+    if (!elem_aligned<T>(q)) return -1;
+    static const bool edge_on = !(getenv("PLS_HIP_EDGE") && atoi(getenv("PLS_HIP_EDGE")) == 0);  // A/B measurements only
+    const bool fits = (i64)cg_all * ld * (i64)sizeof(T) < (1ll << 31);
+    if (cols_aligned<T>(q, ld) && fits) return 0;
+    if (!edge_on || (i64)cg_wave * ld * (i64)sizeof(T) >= (1ll << 31)) return -1;
+    return cols_aligned<T>(q, ld) ? 1 : 2;
+}
+
+// rc as launch_fused_pass; *nb = partial rows written (<= max_rows).  M <= 8.
+template <typename T>
+int launch_retile_xty(hipStream_t stream, int num_cu, const T *src, i64 lds_, const T *Y, i64 ldy, T *dst, i64 ldd, i64 tsd,
+                      int rdst, i64 N, int K, int M, double *part, int max_rows, int *nb) {
+    constexpr int V = 16 / sizeof(T);
+    constexpr int R = 256 / sizeof(T), NT = 512;
+    constexpr int CG = NT / (R / V);
+    if (!cols_aligned<T>(dst, ldd) || tsd % V != 0 || rdst < V || R % rdst != 0 || N < 1 || M < 1 || M > 8 || max_rows < 2 ||
+        !elem_aligned<T>(Y))
+        return 1;
+    const int edge = edge_level<T>(src, lds_, CG, WAVE / (R / V));
+    if (edge < 0) return 1;
+    if (((i64)(R / rdst) * tsd + (i64)CG * ldd) * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    const i64 Nf = N - N % V;
+    int gx = 0;
+    if (Nf > 0) {
+        const i64 ntiles = (Nf + R - 1) / R;
+        // columns per lane: 8, or 4 where 8 x MT accumulators and the tiles in flight do not fit 128 registers
+        const int cptb = (M > 4 || (M > 2 && sizeof(T) == 4)) ? 4 : 8;
+        const int nkb = (K + CG * cptb - 1) / (CG * cptb);
+        // two resident workgroups per CU in total (consecutive tiles per workgroup), at most max_rows - 1 row chunks
+        const i64 want = std::max<i64>(1, std::min<i64>((2 * (i64)num_cu + nkb - 1) / nkb, max_rows - 1));
+        const i64 tpw = (ntiles + want - 1) / want;
+        gx = (int)((ntiles + tpw - 1) / tpw);
+        const dim3 g((unsigned)gx, (unsigned)nkb), b(NT);
+#define RX_LAUNCH(CPTB_, MT_, E_) \
+    hipLaunchKernelGGL((retile_xty_kernel<T, V, R, NT, CPTB_, MT_, E_>), g, b, 0, stream, src, lds_, Y, ldy, dst, ldd, tsd, rdst, Nf, K, M, part, (int)tpw)
+#define RX_CASE(CPTB_, MT_) \
+    do { if (edge == 2) RX_LAUNCH(CPTB_, MT_, 2); else if (edge) RX_LAUNCH(CPTB_, MT_, 1); else RX_LAUNCH(CPTB_, MT_, 0); } while (0)
+        if (M > 4) RX_CASE(4, 8);
+        else if (M > 2 && cptb == 4) RX_CASE(4, 4);
+        else if (M > 2) RX_CASE(8, 4);
+        else if (M > 1) RX_CASE(8, 2);
+        else RX_CASE(8, 1);
+#undef RX_CASE
+#undef RX_LAUNCH
+    }
+    if (Nf < N) {
+        TailArgs<T> a;
+        a.src = src; a.lds = lds_; a.tss = R; a.rs = R;
+        a.dst = dst; a.ldd = ldd; a.tsd = tsd; a.rd = rdst;
+        a.part = part + (i64)gx * K * M; a.Y = Y; a.ldy = ldy; a.M = M;
+        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K;
+        launch_tail_rows(stream, a);
+        ++gx;
+    }
+    *nb = gx;
+    return 0;
 }
 
 // rc as launch_fused_pass; *nss = number of t^T t partials written
@@ -334,20 +652,34 @@ int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_,
     constexpr int V = 16 / sizeof(T);
     constexpr int R = 256 / sizeof(T), NT = 512, CPT = 8;
     constexpr int CG = NT / (R / V);
-    auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
-    if (!al(src, lds_) || !al(dst, ldd) || !al(tprev, V) || !al(tout, V) || N < 1 || N % V != 0) return 1;
-    if (tss % V != 0 || tsd % V != 0 || rdst < V || R % rdst != 0) return 1;
+    if (N < 1 || max_rows < 2 || !cols_aligned<T>(dst, ldd) || !elem_aligned<T>(tprev) || !elem_aligned<T>(tout)) return 1;
+    const int edge = edge_level<T>(src, lds_, CG, WAVE / (R / V));
+    if (edge < 0 || (edge == 0 && tss % V != 0)) return 1;
+    if (tsd % V != 0 || rdst < V || R % rdst != 0) return 1;
     if (((i64)(R / rdst) * tsd + (i64)CG * ldd) * (i64)sizeof(T) >= (1ll << 31)) return 1;
-    if ((i64)CG * lds_ * (i64)sizeof(T) >= (1ll << 31) || (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    if ((i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     const size_t dyn = (size_t)K * 16;  // w and p_prev
     if (dyn > 72 * 1024) return 1;      // two workgroups per CU must fit the 160 KiB LDS
-    if (dyn > 48 * 1024 &&
-        !raise_dynamic_lds(reinterpret_cast<const void *>(&deflate_score_kernel<T, V, R, NT, CPT>), 72 * 1024))
-        return 1;
-    const i64 ntiles = (N + R - 1) / R;
-    const i64 grid = std::min<i64>(std::min<i64>(ntiles, 2 * (i64)num_cu), max_rows);
-    hipLaunchKernelGGL((deflate_score_kernel<T, V, R, NT, CPT>), dim3((unsigned)grid), dim3(NT), (size_t)K * 16,
-                       stream, src, lds_, tss, dst, ldd, tsd, rdst, N, K, tprev, pprev, w, tout, sspart);
+    auto kfn = edge == 2 ? &deflate_score_kernel<T, V, R, NT, CPT, 2>
+                         : (edge == 1 ? &deflate_score_kernel<T, V, R, NT, CPT, 1> : &deflate_score_kernel<T, V, R, NT, CPT, 0>);
+    if (dyn > 48 * 1024 && !raise_dynamic_lds(reinterpret_cast<const void *>(kfn), 72 * 1024)) return 1;
+    const i64 Nf = N - N % V;
+    i64 grid = 0;
+    if (Nf > 0) {
+        const i64 ntiles = (Nf + R - 1) / R;
+        grid = std::min<i64>(std::min<i64>(ntiles, 2 * (i64)num_cu), max_rows - 1);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), (size_t)K * 16, stream, src, lds_, tss, dst, ldd, tsd, rdst, Nf,
+                           K, tprev, pprev, w, tout, sspart);
+    }
+    if (Nf < N) {  // the last N % V rows
+        TailArgs<T> a;
+        a.src = src; a.lds = lds_; a.tss = tss; a.rs = R;
+        a.dst = dst; a.ldd = ldd; a.tsd = tsd; a.rd = rdst;
+        a.tprev = tprev; a.pprev = pprev; a.v = w; a.tout = tout; a.sspart = sspart + grid;
+        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K;
+        launch_tail_rows(stream, a);
+        ++grid;
+    }
     *nss = (int)grid;
     return 0;
 }
@@ -355,28 +687,32 @@ int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_,
 // Copy of a column-major matrix into row-tile-major storage with tiles of rdst rows (rdst divides R): read in the
 // 256-byte-segment pattern, written as contiguous tile pieces.  Used once per fit by the KERNEL plan on wide
 // matrices (1024 < K <= 4096), whose read-only passes then run fused on the short tiles.
-template <typename T, int V, int R, int NT, int CPT>
+template <typename T, int V, int R, int NT, int CPT, int EDGE = 0>
 __global__ __launch_bounds__(NT, (NT / 256) * 2) void retile_kernel(const T *src, i64 lds_, T *dst, i64 ldd, i64 tsd,
                                                                     int rdst, i64 N, int K) {
     constexpr int RP = R / V, CG = NT / RP;
+    constexpr int CGD = EDGE ? WAVE / RP : CG;
+    constexpr int LDAUX = (EDGE == 2) ? 0 : AUX_NT;
     const int rp = threadIdx.x % RP, cg = threadIdx.x / RP;
-    const uint32_t soff = (uint32_t)(((i64)rp * V + (i64)cg * lds_) * (i64)sizeof(T));
+    const int cgw = EDGE ? __builtin_amdgcn_readfirstlane(cg) : 0;
+    const uint32_t soff = (uint32_t)(((i64)rp * V + (i64)(cg - cgw) * lds_) * (i64)sizeof(T));
     const int dsub = (rp * V) / rdst, dwithin = (rp * V) % rdst, dtiles = R / rdst;
     const uint32_t doff = (uint32_t)(((i64)dsub * tsd + dwithin + (i64)cg * ldd) * (i64)sizeof(T));
     constexpr uint32_t OOR = 0x80000000u;
     const int ngroups = (K + CG - 1) / CG;
-    for (i64 tile = blockIdx.x; tile * R < N; tile += gridDim.x) {
+    TileWalk<EDGE == 2, R> walk(N);
+    for (i64 tile = walk.first(); tile * R < walk.nlim(N); tile += walk.step()) {
         const bool rowok = (tile * R + (i64)rp * V < N);
         const uint32_t so = rowok ? soff : OOR, dof = rowok ? doff : OOR;
         for (int g0 = 0; g0 < ngroups; g0 += CPT) {
             Pack<T, V> x[CPT];
 #pragma unroll
             for (int j = 0; j < CPT; ++j) {
-                const int cols = min(CG, K - CG * (g0 + j));
+                const int cols = min(CGD, K - CG * (g0 + j) - cgw);
                 const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * lds_ * (i64)sizeof(T)) : 0u;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<T *>(src + tile * R + (i64)(g0 + j) * CG * lds_), (short)0, (int)nrec, BUF_WORD3);
-                x[j] = buf_ld<T, V, AUX_NT>(rs, so);
+                    const_cast<T *>(src + tile * R + (i64)((g0 + j) * CG + cgw) * lds_), (short)0, (int)nrec, BUF_WORD3);
+                x[j] = buf_ld<T, V, LDAUX>(rs, so);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -397,25 +733,41 @@ int launch_retile(hipStream_t stream, int num_cu, const T *src, i64 lds_, T *dst
     constexpr int V = 16 / sizeof(T);
     constexpr int R = 256 / sizeof(T), NT = 512, CPT = 8;
     constexpr int CG = NT / (R / V);
-    auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
-    if (!al(src, lds_) || !al(dst, ldd) || tsd % V != 0 || rdst < V || R % rdst != 0 || N < 1 || N % V != 0) return 1;
-    if ((i64)CG * lds_ * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    if (!cols_aligned<T>(dst, ldd) || tsd % V != 0 || rdst < V || R % rdst != 0 || N < 1) return 1;
+    const int edge = edge_level<T>(src, lds_, CG, WAVE / (R / V));
+    if (edge < 0) return 1;
     if (((i64)(R / rdst) * tsd + (i64)CG * ldd) * (i64)sizeof(T) >= (1ll << 31)) return 1;
-    const i64 ntiles = (N + R - 1) / R;
-    const i64 grid = std::min<i64>(ntiles, 2 * (i64)num_cu);
-    hipLaunchKernelGGL((retile_kernel<T, V, R, NT, CPT>), dim3((unsigned)grid), dim3(NT), 0, stream, src, lds_, dst, ldd,
-                       tsd, rdst, N, K);
+    const i64 Nf = N - N % V;
+    if (Nf > 0) {
+        const i64 ntiles = (Nf + R - 1) / R;
+        const i64 grid = std::min<i64>(ntiles, 2 * (i64)num_cu);
+        auto kfn = edge == 2 ? &retile_kernel<T, V, R, NT, CPT, 2>
+                             : (edge == 1 ? &retile_kernel<T, V, R, NT, CPT, 1> : &retile_kernel<T, V, R, NT, CPT, 0>);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), 0, stream, src, lds_, dst, ldd, tsd, rdst, Nf, K);
+    }
+    if (Nf < N) {
+        TailArgs<T> a;
+        a.src = src; a.lds = lds_; a.tss = R; a.rs = R;
+        a.dst = dst; a.ldd = ldd; a.tsd = tsd; a.rd = rdst;
+        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K;
+        launch_tail_rows(stream, a);
+    }
     return 0;
 }
 
-// Will launch_deflate_score accept every deflating pass of a fit (decided once per fit, like fused_pass_covers)?
+// Will launch_deflate_score accept every deflating pass of a fit (decided once per fit, like fused_pass_mode)?
+// 0 = no, 1 = yes, 2 = yes through an EDGE instantiation (long or unaligned columns).
 template <typename T>
-bool deflate_score_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
+int deflate_score_mode(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
     constexpr int V = 16 / sizeof(T);
     constexpr int CG = 512 / ((256 / (int)sizeof(T)) / V);
-    auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
-    return al(X, ldx) && al(Tm, ldt) && N >= 1 && N % V == 0 && (size_t)K * 16 <= 72 * 1024 &&
-           (i64)CG * ldx * (i64)sizeof(T) < (1ll << 31);
+    if (N < 1 || (size_t)K * 16 > 72 * 1024 || !elem_aligned<T>(Tm)) return 0;
+    const int e = edge_level<T>(X, ldx, CG, 4);
+    return e < 0 ? 0 : (e == 0 ? 1 : 2);
+}
+template <typename T>
+bool deflate_score_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
+    return deflate_score_mode<T>(X, ldx, N, K, Tm, ldt) != 0;
 }
 
 // Loading partials p_raw = X^T t for a matrix in (ld, ts) tile addressing -- the row-tile-major work buffer of
@@ -452,7 +804,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void xty_tiled_kernel(const T *
         }
         double tv[V];
         if (rowok) {
-            const Pack<T, V> tpk = ld_pack<T, V>(t + i0);
+            const Pack<T, V> tpk = ld_pack_u<T, V>(t + i0);
 #pragma unroll
             for (int e = 0; e < V; ++e) tv[e] = (double)tpk.v[e];
         } else {
@@ -479,17 +831,28 @@ int launch_xty_tiled(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 ts
     constexpr int V = 16 / sizeof(T);
     constexpr int R = (512 / CGX) * V, NT = 512, CPT = 16;  // = tile_rows<T, CGX>()
     constexpr int CG = NT / (R / V);
-    auto al = [](const void *q, i64 ld) { return ((uintptr_t)q % 16 == 0) && (ld % V == 0); };
-    if (!al(X, ldx) || !al(t, V) || tsx % V != 0 || N < 1 || N % V != 0 || max_rows < 1) return 1;
+    if (!cols_aligned<T>(X, ldx) || !elem_aligned<T>(t) || tsx % V != 0 || N < 1 || max_rows < 2) return 1;
     if ((i64)CG * ldx * (i64)sizeof(T) >= (1ll << 31)) return 1;
-    const i64 ntiles = (N + R - 1) / R;
-    const int nkb = (K + CG * CPT - 1) / (CG * CPT);
-    // ~8 workgroups per CU in total, at most max_rows row chunks
-    const i64 want = std::max<i64>(1, std::min<i64>((8 * (i64)num_cu + nkb - 1) / nkb, max_rows));
-    const i64 tpw = (ntiles + want - 1) / want;
-    const i64 gx = (ntiles + tpw - 1) / tpw;
-    hipLaunchKernelGGL((xty_tiled_kernel<T, V, R, NT, CPT>), dim3((unsigned)gx, (unsigned)nkb), dim3(NT), 0, stream, X,
-                       ldx, tsx, N, K, t, part, (int)tpw);
+    const i64 Nf = N - N % V;
+    i64 gx = 0;
+    if (Nf > 0) {
+        const i64 ntiles = (Nf + R - 1) / R;
+        const int nkb = (K + CG * CPT - 1) / (CG * CPT);
+        // ~8 workgroups per CU in total, at most max_rows - 1 row chunks
+        const i64 want = std::max<i64>(1, std::min<i64>((8 * (i64)num_cu + nkb - 1) / nkb, max_rows - 1));
+        const i64 tpw = (ntiles + want - 1) / want;
+        gx = (ntiles + tpw - 1) / tpw;
+        hipLaunchKernelGGL((xty_tiled_kernel<T, V, R, NT, CPT>), dim3((unsigned)gx, (unsigned)nkb), dim3(NT), 0, stream, X,
+                           ldx, tsx, Nf, K, t, part, (int)tpw);
+    }
+    if (Nf < N) {
+        TailArgs<T> a;
+        a.src = X; a.lds = ldx; a.tss = tsx; a.rs = R;
+        a.tgiven = t; a.part = part + gx * K;
+        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K;
+        launch_tail_rows(stream, a);
+        ++gx;
+    }
     *nb = (int)gx;
     return 0;
 }
@@ -503,14 +866,19 @@ template <typename T, int CGX = 32>
 constexpr int tile_rows() { return (512 / CGX) * (16 / (int)sizeof(T)); }
 
 // Will launch_fused_pass accept every pass of a fit on (X, ldx) with score columns Tm + a*ldt?  (Decided once
-// per fit: the work buffer's layout depends on it.)
+// per fit: the work buffer's layout depends on it.)  0 = no; 1 = yes; 2 = yes through an EDGE instantiation (columns
+// that are not 16-byte aligned, or a leading dimension whose 32 column groups do not fit one descriptor -- up to
+// 2^31 bytes per WAVE / RP = 4 columns there).  Any N >= 1: the last N % V rows are the tail kernel's.
+template <typename T>
+int fused_pass_mode(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
+    constexpr int CG = 32;
+    if (K > CG * 32 || N < 1 || !elem_aligned<T>(Tm)) return 0;
+    const int e = edge_level<T>(X, ldx, CG, 4);
+    return e < 0 ? 0 : (e == 0 ? 1 : 2);
+}
 template <typename T>
 bool fused_pass_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
-    constexpr int V = 16 / sizeof(T);
-    constexpr int CG = 32;
-    auto al = [](const void *p, i64 ld) { return ((uintptr_t)p % 16 == 0) && (ld % V == 0); };
-    return al(X, ldx) && al(Tm, ldt) && K <= CG * 32 && N >= 1 && N % V == 0 &&
-           (i64)CG * ldx * (i64)sizeof(T) < (1ll << 31);
+    return fused_pass_mode<T>(X, ldx, N, K, Tm, ldt) != 0;
 }
 
 // rc: 0 = launched, 1 = shape/alignment not covered (caller falls back to the one-product
@@ -525,57 +893,84 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     constexpr int CG = NT / (R / V);
     static_assert(CG == CGX, "tile shape");
     const bool defl = (tprev != nullptr);
-    auto al = [](const void *p, i64 ld) { return ((uintptr_t)p % 16 == 0) && (ld % V == 0); };
-    if (!al(X, ldx) || !al(tout, V) || (defl && (!al(dst, ldd) || !al(tprev, V)))) return 1;
-    if (tsx % V != 0 || (defl && tsd % V != 0)) return 1;
-    if (K > CG * (CGX == 256 ? 16 : 32) || N < 1 || N % V != 0) return 1;
-    // a column group's byte span (its num_records, and every lane offset) must stay below 2^31
-    if ((i64)CG * ldx * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    if (!elem_aligned<T>(tout) || (defl && (!cols_aligned<T>(dst, ldd) || !elem_aligned<T>(tprev)))) return 1;
+    // the byte span of the column groups behind one descriptor (its num_records, and every lane offset) must stay below
+    // 2^31: all CG groups of the workgroup, or -- EDGE -- the WAVE / RP groups of one wave
+    int edge = edge_level<T>(X, ldx, CG, WAVE / (R / V));
+    if (edge < 0 || (edge == 0 && tsx % V != 0) || (defl && tsd % V != 0)) return 1;
+    if (K > CG * (CGX == 256 ? 16 : 32) || N < 1 || max_rows < 2) return 1;
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if (rdst > 0 && (CGX != 32 || !defl || rdst < V || R % rdst != 0 ||
                      ((i64)(R / rdst) * tsd + (i64)CG * ldd) * (i64)sizeof(T) >= (1ll << 31)))
         return 1;
-    const i64 ntiles = (N + R - 1) / R;
-    // Workgroups per CU.  Read-only passes: two (5 % faster than one on the caller's column-major X).  Read+write
-    // passes on the tiled copy: ONE (2.7 % faster than two at 16 columns per lane, 4 % at 4, equal at 8 -- less
-    // in flight is better for the read/write mix, tools/fused_grid_sweep.py); 32 columns per lane (256 VGPRs)
-    // never fit two.
-    const int per_cu = (K <= CG * 16 && !defl) ? 2 : 1;
-    i64 grid = grid_hint > 0 ? grid_hint : per_cu * (i64)num_cu;
-    grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows);
-    if (grid < 1) return 1;
-    const dim3 g((unsigned)grid), b(NT);
-#define FUSED_CASE(CPT_)                                                                                      \
-    do {                                                                                                      \
-        const size_t dyn = ((size_t)2 * CG * CPT_ * sizeof(double) > 48 * 1024) ? (size_t)2 * CG * CPT_ * sizeof(double) : 0; \
-        if (dyn > 48 * 1024) {                                                                                \
-            const void *fn = defl ? reinterpret_cast<const void *>(&fused_pass_kernel<T, V, R, NT, CPT_, true>) \
-                                  : reinterpret_cast<const void *>(&fused_pass_kernel<T, V, R, NT, CPT_, false>); \
-            if (!raise_dynamic_lds(fn, (int)dyn)) return 1;                                                   \
-        }                                                                                                     \
-        if (defl)                                                                                             \
-            hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, true>), g, b, dyn, stream, X, ldx, tsx,  \
-                               dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart, 0);                  \
-        else                                                                                                  \
-            hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, CPT_, false>), g, b, dyn, stream, X, ldx, tsx, \
-                               dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart, 0);                  \
-    } while (0)
+    if (CGX != 32 && edge != 0) return 1;  // (the short tiles only ever hold the library's own copy)
     if constexpr (CGX == 32) {
-        if (rdst > 0) {  // first deflation into shorter tiles: only the 32-columns-per-lane shape needs it
-            if (K <= CG * 16) return 1;
-            hipLaunchKernelGGL((fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true>), g, b, 0, stream, X, ldx, tsx,
-                               dst, ldd, tsd, N, K, v, tprev, pprev, tout, part, sspart, rdst);
-        } else if (K <= CG * 4) FUSED_CASE(4);
-        else if (K <= CG * 8) FUSED_CASE(8);
-        else if (K <= CG * 16) FUSED_CASE(16);
-        else FUSED_CASE(32);
-    } else if constexpr (CGX == 64 || CGX == 128) {
-        if (K <= CG * 16) FUSED_CASE(16);
-        else FUSED_CASE(32);
-    } else {
-        FUSED_CASE(16);  // 256 column groups x 2 row lanes: K <= 4096 at 16 columns per lane
+        if (rdst > 0 && K <= CG * 16) return 1;
     }
+    const i64 Nf = N - N % V;  // whole row packs; the rest is the tail kernel's
+    i64 grid = 0;
+    if (Nf > 0) {
+        const i64 ntiles = (Nf + R - 1) / R;
+        // Workgroups per CU.  Read-only passes: two (5 % faster than one on the caller's column-major X).  Read+write
+        // passes on the tiled copy: ONE (2.7 % faster than two at 16 columns per lane, 4 % at 4, equal at 8 -- less
+        // in flight is better for the read/write mix, tools/fused_grid_sweep.py); 32 columns per lane (256 VGPRs)
+        // never fit two.
+        const int per_cu = (K <= CG * 16 && !defl) ? 2 : 1;
+        grid = grid_hint > 0 ? grid_hint : per_cu * (i64)num_cu;
+        grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows - 1);
+        if (grid < 1) return 1;
+        const dim3 g((unsigned)grid), b(NT);
+#define FUSED_LAUNCH(CPT_, DEFL_, EDGE_, dyn_)                                                                            \
+    do {                                                                                                                  \
+        auto kfn = &fused_pass_kernel<T, V, R, NT, CPT_, DEFL_, AUX_NT, AUX_NT, false, EDGE_>;                           \
+        if ((dyn_) > 48 * 1024 && !raise_dynamic_lds(reinterpret_cast<const void *>(kfn), (int)(dyn_))) return 1;         \
+        hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, 0); \
+    } while (0)
+#define FUSED_EDGE(CPT_, DEFL_, dyn_)                                                                                     \
+    do {                                                                                                                  \
+        if constexpr (CGX == 32) {                                                                                        \
+            if (edge == 2) { FUSED_LAUNCH(CPT_, DEFL_, 2, dyn_); break; }                                                 \
+            if (edge == 1) { FUSED_LAUNCH(CPT_, DEFL_, 1, dyn_); break; }                                                 \
+        }                                                                                                                 \
+        FUSED_LAUNCH(CPT_, DEFL_, 0, dyn_);                                                                               \
+    } while (0)
+#define FUSED_CASE(CPT_)                                                                                                  \
+    do {                                                                                                                  \
+        const size_t dyn = ((size_t)2 * CG * CPT_ * sizeof(double) > 48 * 1024) ? (size_t)2 * CG * CPT_ * sizeof(double) : 0; \
+        if (defl) FUSED_EDGE(CPT_, true, dyn); else FUSED_EDGE(CPT_, false, dyn);                                         \
+    } while (0)
+        if constexpr (CGX == 32) {
+            if (rdst > 0) {  // first deflation into shorter tiles: only the 32-columns-per-lane shape needs it
+                auto kfn = edge == 2 ? &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 2>
+                                     : (edge == 1 ? &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 1>
+                                                  : &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 0>);
+                hipLaunchKernelGGL(kfn, g, b, 0, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, rdst);
+            } else if (K <= CG * 4) FUSED_CASE(4);
+            else if (K <= CG * 8) FUSED_CASE(8);
+            else if (K <= CG * 16) FUSED_CASE(16);
+            else FUSED_CASE(32);
+        } else if constexpr (CGX == 64 || CGX == 128) {
+            if (K <= CG * 16) FUSED_CASE(16);
+            else FUSED_CASE(32);
+        } else {
+            FUSED_CASE(16);  // 256 column groups x 2 row lanes: K <= 4096 at 16 columns per lane
+        }
 #undef FUSED_CASE
+#undef FUSED_EDGE
+#undef FUSED_LAUNCH
+    }
+    if (Nf < N) {  // the last N % V rows: one more partial row
+        TailArgs<T> a;
+        a.src = X; a.lds = ldx; a.tss = tsx; a.rs = R;
+        if (defl) {
+            a.dst = dst; a.ldd = ldd; a.tsd = tsd; a.rd = rdst > 0 ? rdst : R;
+            a.tprev = tprev; a.pprev = pprev;
+        }
+        a.v = v; a.tout = tout; a.part = part + grid * K; a.sspart = sspart + grid;
+        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K;
+        launch_tail_rows(stream, a);
+        ++grid;
+    }
     *nb = (int)grid;
     *nss = (int)grid;
     return 0;

@@ -712,10 +712,14 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // is stored row-tile-major (every R x K tile one contiguous block: fused_kernels.hpp), otherwise column-major
     // with ld = N for the one-product kernels.
     constexpr i64 TR = plsk::tile_rows<T>();
-    const bool fused_fit = c->opt_fuse && N > 0 && plsk::fused_pass_covers<T>(X, ldx, N, K, Tm, ldt);
+    // Any row count (the last N % V rows go to a tail kernel), any alignment of the columns and leading dimensions up to
+    // 2^31 / 4 bytes (mode 2: the EDGE instantiations) -- the same one-sweep traffic for every matrix the reference
+    // accepts (src/pls.cpp:419-421)
+    const int fused_mode = (c->opt_fuse && N > 0) ? plsk::fused_pass_mode<T>(X, ldx, N, K, Tm, ldt) : 0;
+    const bool fused_fit = fused_mode != 0;
+    const int wide_mode = (c->opt_fuse && !fused_fit && N > 0) ? plsk::deflate_score_mode<T>(X, ldx, N, K, Tm, ldt) : 0;
     // wide matrices (no resident tile): deflation + score in one sweep, loading in a second read
-    const bool semi_fit = nipals && c->opt_fuse && !fused_fit && N > 0 &&
-                          plsk::deflate_score_covers<T>(X, ldx, N, K, Tm, ldt);
+    const bool semi_fit = nipals && wide_mode != 0;
     const bool tiled_work = nipals && (fused_fit || semi_fit) && c->opt_work_layout != 0;
     // Row-tile-major tiles are contiguous whatever their height, so for 1024 < K <= 4096 the working copy uses
     // SHORTER tiles (8-32 rows) that do fit the registers of a CU: from the third component on the fully fused
@@ -723,15 +727,27 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // to read the caller's column-major X in 256-byte pieces (deflate_score, writing the short tiles).
     // KERNEL plan on such a matrix: X is copied ONCE into short tiles (read + write), after which every component
     // is one fused read-only pass instead of two one-product passes -- pays from the third component on.
-    bool retile_fit = !nipals && !type2 && c->opt_fuse && !fused_fit && N > 0 && A >= 3 && K <= 128 * 32 &&
-                      c->opt_work_layout != 0 && plsk::deflate_score_covers<T>(X, ldx, N, K, Tm, ldt);
+    // ... and on a matrix whose columns are not 16-byte aligned (ld odd, a base pointer at 8 mod 16): the one-sweep pass can
+    // read it (EDGE level 2) but every 256-byte segment then shares a line with its neighbours and the pass runs at 0.52
+    // instead of 0.73 of peak; with the copy (formed in the same sweep as X^T Y: retile_xty_kernel) every component reads
+    // aligned tiles.  Costs one write of X; pays from the fourth component on (PLS_HIP_COPY_MIN).
+    constexpr int FVX = 16 / (int)sizeof(T);
+    // The same copy pays for ALIGNED matrices once there are enough components: a read-only pass over the tiled copy, one
+    // contiguous 128 KB block per tile, runs at 0.85 of peak (0.63 ms at config 3) against 0.72 (0.74 ms) over the caller's
+    // column-major matrix in 256-byte segments; the copy costs 0.86 ms more than the X^T Y pass it replaces
+    // (PLS_HIP_COPY_MIN_ALIGNED, default 10 components).
+    static const int copy_min = getenv("PLS_HIP_COPY_MIN") ? atoi(getenv("PLS_HIP_COPY_MIN")) : 4;
+    static const int copy_min_al = getenv("PLS_HIP_COPY_MIN_ALIGNED") ? atoi(getenv("PLS_HIP_COPY_MIN_ALIGNED")) : 10;
+    const bool copy_fit = fused_fit && M <= 8 && A >= (vec_ok<T>(X, ldx, FVX) ? copy_min_al : copy_min);
+    bool retile_fit = !nipals && !type2 && A >= 3 && c->opt_work_layout != 0 && ((wide_mode != 0 && K <= 128 * 32) || copy_fit);
     // column groups of the short tiles of a wide matrix (1024 < K <= 4096): 16 columns per lane in 128 / 256 groups
     // (8-row fp32 / 4-row fp64 tiles at K <= 4096) -- the register shape of the headline kernel, two workgroups per CU
     // on read-only passes.  Config 4: read+write pass 0.766 -> 0.710 ms (0.70 -> 0.76 of peak), read-only pass
     // 0.364 -> 0.324 ms (0.74 -> 0.83) against 32 columns per lane in 64 / 128 groups (PLS_HIP_WIDE16=0, the round-1 shape).
     static const bool wide16 = !(getenv("PLS_HIP_WIDE16") && atoi(getenv("PLS_HIP_WIDE16")) == 0);
-    const int wide_groups = wide16 ? (K <= 128 * 16 ? 128 : (K <= 256 * 16 ? 256 : 0))
-                                   : (K <= 64 * 32 ? 64 : (K <= 128 * 32 ? 128 : 0));
+    const int wide_groups = fused_fit ? (K <= 32 * 16 ? 32 : 64)  // (the copy of a matrix the resident tile covers)
+                            : wide16 ? (K <= 128 * 16 ? 128 : (K <= 256 * 16 ? 256 : 0))
+                                     : (K <= 64 * 32 ? 64 : (K <= 128 * 32 ? 128 : 0));
     if (retile_fit) {  // the copy is optional: without room for it the one-product kernels do the job
         const i64 wr = (512 / wide_groups) * (i64)(16 / sizeof(T));
         if (ensure(c, c->work, (size_t)((N + wr - 1) / wr) * wr * K * sizeof(T)) != PLS_HIP_OK) {
@@ -746,12 +762,13 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // every later pass runs on the short tiles.
     const int mid_cg = (nipals && fused_fit && tiled_work && K > 32 * 16 && A > 2) ? 64 : 0;
     // opt-in deferred write-back (defer_kernels.hpp): up to `defer` rank-1 updates pending per stored matrix
-    const int defer = (nipals && fused_fit && tiled_work && K <= 32 * 16) ? (int)c->opt_defer : 1;
+    const int defer = (nipals && fused_mode == 1 && N % FVX == 0 && plsk::cols_aligned<T>(Tm, ldt) && tiled_work && K <= 32 * 16)
+                          ? (int)c->opt_defer : 1;
     const int work_cg = wide_cg ? wide_cg : (mid_cg ? mid_cg : 32);
     const i64 WR = (512 / work_cg) * (i64)(16 / sizeof(T));  // rows per tile of the working copy
     if ((nipals && A > 1 && N > 0) || retile_fit)
         CHK(ensure(c, c->work, (tiled_work || retile_fit) ? (size_t)((N + WR - 1) / WR) * WR * K * sizeof(T)
-                                                          : (size_t)N * K * sizeof(T)));
+                                                          : (size_t)((N + 3) & ~(i64)3) * K * sizeof(T)));
     double *part = (double *)c->part.p, *sspart = (double *)c->sspart.p;
     double *XY = (double *)c->xy.p, *v = (double *)c->v.p;
     T *work = (T *)c->work.p;
@@ -760,8 +777,25 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     Range r_fit("pls_hip_fit");
     std::unique_ptr<Range> r_phase(new Range("X^T Y"));
     const bool use_pre = have_pre && (gram || method == PLS_HIP_KERNEL_TYPE2);
-    bool xy_from_syrk = false, xx_local_done = false;
-    if (use_pre) {
+    bool xy_from_syrk = false, xx_local_done = false, retiled = false;
+    if (!use_pre && N > 0 && retile_fit && M <= 8) {
+        // the copy into tiles and X^T Y in ONE sweep over the caller's matrix (instead of retile_kernel + the X^T Y pass)
+        static const bool rx_on = !(getenv("PLS_HIP_RETILE_XTY") && atoi(getenv("PLS_HIP_RETILE_XTY")) == 0);
+        int nb = 0, rc = 1;
+        if (rx_on) {
+            Scope s(c, PLS_HIP_FAM_DEFLATE, 2 * (i64)N * K * sizeof(T) + (i64)N * M * sizeof(T) + L0 * 8);
+            rc = plsk::launch_retile_xty<T>(c->stream, c->num_cu, X, ldx, Y, ldy, work, WR, WR * (i64)K, (int)WR, N, K, M, part,
+                                            (int)prow, &nb);
+            if (rc != 0) s.on = false;
+        }
+        if (rc == 0) {
+            LAUNCH_CHECK(c);
+            CHK(launch_reduce(c, part, nb, (int)L0, nullptr, 0, red));
+            retiled = true;
+        }
+    }
+    if (retiled) {
+    } else if (use_pre) {
         hipLaunchKernelGGL(plsk::fill_slices_kernel, dim3((unsigned)((L0 + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
                            c->stream, c->pre_xy, (int)L0, red);
         LAUNCH_CHECK(c);
@@ -836,7 +870,9 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
 
     const T *Xc = X;
     i64 ldc = ldx, tsc = TR;  // column stride and tile stride of the current matrix
-    const i64 ldw = (tiled_work || retile_fit) ? WR : N, tsw = (tiled_work || retile_fit) ? WR * (i64)K : TR;
+    // (a column-major working copy keeps 16-byte columns whatever N is)
+    constexpr i64 PV = 16 / (i64)sizeof(T);
+    const i64 ldw = (tiled_work || retile_fit) ? WR : (N + PV - 1) / PV * PV, tsw = (tiled_work || retile_fit) ? WR * (i64)K : TR;
     bool cur_tiled = false;  // Xc is the row-tile-major working copy
     int defer_b = 0;         // deferred write-back: index of the stored matrix X_b
     for (int a = 0; a < A; ++a) {
@@ -867,7 +903,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 done = true;
                 if (store) { Xc = work; ldc = ldw; tsc = tsw; cur_tiled = true; defer_b = a; }
                 CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
-            } else if (fused_fit) {
+            } else if (fused_fit && !retile_fit) {
                 // tile-resident pass: [deflate with (t_{a-1}, p_{a-1}) +] t_a = X v, X^T t_a partials
                 int nb = 0, nss = 0;
                 const T *tprev = (nipals && a > 0) ? Tm + (i64)(a - 1) * ldt : nullptr;
@@ -901,7 +937,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 int nb = 0, nss = 0, rc;
                 const T *tprev = nipals ? Tm + (i64)(a - 1) * ldt : nullptr;
                 const double *pprev = nipals ? P + (i64)(a - 1) * K : nullptr;
-                if (!nipals && a == 0) {  // the one-time copy into short tiles (before the first component: it runs fused, too)
+                if (!nipals && a == 0 && !retiled) {  // the one-time copy into short tiles (before the first component: it runs fused, too)
                     Scope s(c, PLS_HIP_FAM_DEFLATE, 2 * (i64)N * K * sizeof(T));
                     if (plsk::launch_retile<T>(c->stream, c->num_cu, X, ldx, work, ldw, tsw, (int)WR, N, K) != 0) {
                         s.on = false;
@@ -914,7 +950,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     Scope s(c, PLS_HIP_FAM_FUSED, bytes);
 #define WIDE_PASS(CG_) plsk::launch_fused_pass<T, CG_>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v, tprev, pprev, \
                                                         Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid)
-                    rc = wide_cg == 64 ? WIDE_PASS(64) : (wide_cg == 128 ? WIDE_PASS(128) : WIDE_PASS(256));
+                    rc = wide_cg == 32 ? WIDE_PASS(32) : (wide_cg == 64 ? WIDE_PASS(64) : (wide_cg == 128 ? WIDE_PASS(128) : WIDE_PASS(256)));
 #undef WIDE_PASS
                     if (rc != 0) s.on = false;
                 }
@@ -942,7 +978,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                         LAUNCH_CHECK(c);
                         have_t = true;
                     }
-                    if (!have_t) CHK(launch_deflate<T>(c, Xc, ldc, work, N, N, K, tprev, pprev));
+                    if (!have_t) CHK(launch_deflate<T>(c, Xc, ldc, work, ldw, N, K, tprev, pprev));
                     Xc = work;
                     ldc = ldw;
                     tsc = tsw;

@@ -1,0 +1,160 @@
+"""Every matrix shape the reference accepts runs on the one-sweep (tile-resident) kernels: odd row counts, row counts
+that are not a multiple of 4 in fp32 storage, columns that are not 16-byte aligned (ld = N odd, an offset base pointer),
+leading dimensions beyond 2^31 / 32 bytes.  The reference's products (src/pls.cpp:419-421) work for any row count and
+any Eigen map; here those shapes used to fall back to the one-product kernels at twice the traffic.
+
+Each case checks the values against the oracle on the same inputs AND the plan taken (HIP-event families of the fit).
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import check_against, oracle_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _place(Xh, dt, ld_extra, base_off):
+    """column-major device copy of Xh with ld = rows + ld_extra, starting base_off elements into its allocation"""
+    torch = _torch()
+    n, k = Xh.shape
+    ld = n + ld_extra
+    flat = torch.full((k * ld + base_off + 8,), float("nan"), dtype=dt, device="cuda")  # NaN wherever the matrix is not
+    v = flat[base_off:base_off + k * ld].view(k, ld)[:, :n].t()
+    v.copy_(torch.from_numpy(Xh).to(dt))
+    return v, flat
+
+
+SHAPES = [
+    # N, K, M, A, dtype, ld_extra, base_off
+    (1001, 37, 2, 6, "f64", 0, 0),      # odd N, ld = N: every second column at 8 mod 16   (4 columns per lane)
+    (1001, 37, 2, 6, "f64", 0, 1),      # ... and the base pointer at 8 mod 16
+    (1001, 37, 2, 6, "f64", 1, 0),      # odd N in 16-byte aligned columns (ld = N + 1)
+    (1001, 37, 2, 3, "f64", 0, 0),      # too few components for the copy into tiles to pay: unaligned columns read directly
+    (1000, 200, 1, 7, "f64", 1, 0),     # even N, odd ld                                    (8 columns per lane)
+    (4099, 400, 1, 6, "f64", 0, 0),     # odd N, several tiles per workgroup                (16 columns per lane)
+    (2051, 513, 3, 5, "f64", 0, 1),     # K > 512: half-height tiles of the working copy    (32 columns per lane)
+    (3, 5, 1, 2, "f64", 0, 0),          # fewer rows than a tile; one row pack and a half
+    (1, 4, 1, 1, "f64", 0, 0),          # a single row
+    (33, 40, 2, 5, "f64", 0, 1),        # one full tile + one row
+    (1001, 37, 2, 6, "f32", 0, 0),      # fp32: N % 4 = 1
+    (1001, 37, 2, 6, "f32", 3, 0),      # fp32: N % 4 = 1 in aligned columns
+    (1002, 130, 1, 6, "f32", 0, 1),     # fp32: N % 4 = 2, base at 4 mod 16
+    (2051, 300, 2, 5, "f32", 0, 3),     # fp32: N % 4 = 3, base at 12 mod 16
+    (4100, 600, 1, 5, "f32", 1, 0),     # fp32: N % 4 = 0 but ld odd
+    (515, 1500, 2, 5, "f64", 0, 0),     # wide: short tiles of 8 fp64 rows (128 column groups)
+    (515, 3000, 1, 5, "f64", 0, 1),     # wide: 4-row tiles (256 column groups)
+    (1031, 2500, 2, 4, "f32", 0, 1),    # wide fp32
+    (261, 5000, 1, 4, "f64", 0, 0),     # beyond the resident tiles: semi-fused sweeps on the column-major copy
+]
+
+
+@pytest.fixture(params=[(0, 1), (1, 1)], ids=["kernel", "nipals"])
+def plan(request, handle):
+    import pls_amd
+    handle.set_option(pls_amd.OPT_ALGO, request.param[0])
+    handle.set_option(pls_amd.OPT_FUSE, 1)
+    handle.set_option(pls_amd.OPT_PROFILE, 1)
+    yield request.param
+    handle.set_option(pls_amd.OPT_ALGO, 0)
+    handle.set_option(pls_amd.OPT_PROFILE, 0)
+
+
+@pytest.mark.parametrize("N,K,M,A,dt,ld_extra,base_off", SHAPES)
+def test_edge_shapes_take_the_one_sweep_plan(handle, oracle, po, plan, monkeypatch, N, K, M, A, dt, ld_extra, base_off):
+    import pls_amd
+    torch = _torch()
+    monkeypatch.setenv("PLS_HIP_TINY", "0")  # (small single-response fits would otherwise run as ONE launch)
+    tdt = torch.float64 if dt == "f64" else torch.float32
+    Xh = oracle.synth_x(0, N, K); Yh = oracle.synth_y(0, N, M)
+    if dt == "f32":
+        Xh = Xh.astype(np.float32).astype(np.float64); Yh = Yh.astype(np.float32).astype(np.float64)
+    X, keepx = _place(Xh, tdt, ld_extra, base_off)
+    Y, keepy = _place(Yh, tdt, ld_extra, base_off)
+    # T with ld = N as well, between guard values
+    ldt = N + ld_extra
+    tflat = torch.full((A * ldt + base_off + 8,), 7.0, dtype=tdt, device="cuda")
+    T = tflat[base_off:base_off + A * ldt].view(A, ldt)[:, :N].t()
+    out = {k: pls_amd.colmajor_empty(K, A, torch.float64, "cuda", ld=K) for k in "WPR"}
+    out["Q"] = pls_amd.colmajor_empty(M, A, torch.float64, "cuda", ld=M)
+    out["B"] = pls_amd.colmajor_empty(K, M, torch.float64, "cuda", ld=K)
+    out["T"] = T
+    handle.timing()
+    handle.fit_device(X, Y, A, out=out); handle.synchronize()
+    tm = handle.timing()
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    if dt == "f64":
+        check_against(po, out, ref, Bref, ref["T"], col_err=cerr)
+    else:
+        check_against(po, out, ref, Bref, ref["T"], tol_b=2e-5, tol_col=2e-5, col_err=cerr, tol_inv=1e-4)
+    # nothing outside the N x A scores was written, nothing of the caller's X either
+    guard = tflat.clone()
+    guard[base_off:base_off + A * ldt].view(A, ldt)[:, :N] = 7.0
+    assert bool((guard == 7.0).all()), "score stores outside the N x A matrix"
+    assert np.array_equal(X.cpu().numpy().astype(np.float64), Xh)
+    # the plan taken: the one-sweep kernels, not the one-product ones
+    nipals = plan[0] == 1
+    V = 2 if dt == "f64" else 4
+    unaligned = (N + ld_extra) % V != 0 or base_off % V != 0
+    if K <= 1024:
+        assert tm["launches"]["fused"] == A and tm["launches"]["xb"] == 0, tm["launches"]
+        if not nipals and unaligned and A >= 4:
+            # KERNEL plan on unaligned columns: one copy into aligned tiles, formed in the same sweep as X^T Y
+            assert tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
+        else:
+            assert tm["launches"]["deflate"] == 0, tm["launches"]
+    elif K <= 4096:
+        # short tiles: KERNEL plan = one copy + A fused passes; NIPALS = fused from the third component on
+        assert tm["launches"]["fused"] == (A - 2 if nipals else A), tm["launches"]
+    else:
+        assert (tm["launches"]["deflate"] == A - 1) if nipals else True, tm["launches"]
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_edge_results_equal_the_aligned_ones(handle, po, dt):
+    """the same values in an aligned and in an unaligned layout: the component loop runs the same arithmetic (the EDGE
+    instantiations only change how a tile reaches the registers); the prologue's X^T Y sums in another order"""
+    import pls_amd
+    torch = _torch()
+    tdt = torch.float64 if dt == "f64" else torch.float32
+    N, K, M, A = 4096 + 64, 300, 2, 6
+    Xa = handle.synth_x(0, N, K, 77, dtype=tdt); Ya = handle.synth_y(0, N, M, 77, dtype=tdt)
+    Xu, keep = _place(Xa.cpu().numpy(), tdt, 1, 1)
+    for algo in (0, 1):
+        handle.set_option(pls_amd.OPT_ALGO, algo)
+        a = handle.fit_device(Xa, Ya, A); handle.synchronize()
+        b = handle.fit_device(Xu, Ya, A); handle.synchronize()
+        assert po.rel_fro(b["B"].cpu().numpy(), a["B"].cpu().numpy()) < (1e-12 if dt == "f64" else 1e-6), algo
+    handle.set_option(pls_amd.OPT_ALGO, 0)
+
+
+def test_very_tall_matrix_runs_fused(handle, po):
+    """one matrix of 2^24 rows x 64 fp64 columns (8.6 GB): 32 column groups of it span 4.3 GB, more than one buffer
+    descriptor addresses -- the EDGE instantiations build a descriptor per wave (4 columns) and keep the one-sweep plan"""
+    import pls_amd
+    N, K, M, A = 1 << 24, 64, 1, 4
+    X = handle.synth_x(0, N, K, 3); Y = handle.synth_y(0, N, M, 3)
+    outs = {}
+    handle.set_option(pls_amd.OPT_PROFILE, 1)
+    for algo in (0, 1):
+        handle.set_option(pls_amd.OPT_ALGO, algo)
+        handle.timing()
+        outs[algo] = handle.fit_device(X, Y, A); handle.synchronize()
+        tm = handle.timing()
+        assert tm["launches"]["fused"] == A and tm["launches"]["xb"] == 0, tm["launches"]
+    handle.set_option(pls_amd.OPT_FUSE, 0)
+    handle.set_option(pls_amd.OPT_ALGO, 0)
+    outs["unfused"] = handle.fit_device(X, Y, A); handle.synchronize()
+    handle.set_option(pls_amd.OPT_FUSE, 1)
+    handle.set_option(pls_amd.OPT_PROFILE, 0)
+    Bb = outs["unfused"]["B"].cpu().numpy()
+    for k in (0, 1):
+        assert po.rel_fro(outs[k]["B"].cpu().numpy(), Bb) < 1e-10, k
+    T = outs[1]["T"]; R = outs[1]["R"].cpu().numpy()
+    for r0 in (0, (1 << 23) + 12345, N - 1000):
+        rows = slice(r0, r0 + 1000)
+        assert po.rel_fro(T[rows, 1].cpu().numpy(), X[rows].cpu().numpy() @ R[:, 1]) < 1e-11
