@@ -129,6 +129,24 @@ def roofline_of(tm):
             "families_ms_per_fit": {f: round(tm["ms"][f] / max(tm["fits"], 1), 4) for f in tm["ms"]}}
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet, fp64 matrix cores (the guide has no fp64 figure)
+
+
+def syrk_roofline(N, K, syrk_ms):
+    """The X^T X launch of the GRAM / KERNEL_TYPE2 plans on the MFMA roofline: flops the kernel EXECUTES (16 x 16 tiles:
+    the 128 x 128 blocks above the diagonal in full, 40 of 64 tiles of every diagonal block) / launch time."""
+    if not syrk_ms or syrk_ms <= 0:
+        return None
+    nbk = (K + 127) // 128
+    tiles = 64 * (nbk * (nbk - 1) // 2) + 40 * nbk
+    executed = 2.0 * N * 16 * 16 * tiles
+    ach = executed / (syrk_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "syrk (X^T X, fp64 MFMA 16x16x4)", "achieved": round(ach, 2), "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(syrk_ms, 4),
+            "executed_gflop_per_launch": round(executed / 1e9, 2),
+            "nominal_tflops_2NK2_symmetry_counted": round(2.0 * N * K * K / (syrk_ms * 1e-3) / 1e12, 2)}
+
+
 def cpu_baseline(N, K, M, A, rows):
     """oracle C restatement (reference operation sequence: 1 + 2A passes over X), 1 core, -O3."""
     from oracle import pls_oracle as po
@@ -284,8 +302,10 @@ def main():
                 h.set_option(pls_amd.OPT_FUSE, fu)
                 e2, t2 = timed_fits(h, torch, dist, 1, X, Y, A, max(2, a.steps // 2), 1, out)
                 st = max(2, a.steps // 2)
-                alt[name] = {"components_per_s": round(A * st / e2, 2), "ms_per_fit": round(e2 / st * 1e3, 3),
-                             "roofline": roofline_of(t2)}
+                rl = roofline_of(t2)
+                if al == 2 and t2["launches"]["xty"] > 0:  # GRAM: the dominant launch is the matrix-core SYRK, not a stream
+                    rl = syrk_roofline(nrows, K, t2["ms"]["xty"] / t2["launches"]["xty"])
+                alt[name] = {"components_per_s": round(A * st / e2, 2), "ms_per_fit": round(e2 / st * 1e3, 3), "roofline": rl}
             # opt-in variant of the NIPALS plan: the deflated matrix is written back every D-th component only, the
             # pending rank-1 updates are re-applied in registers (same roundings as the explicit plan; K <= 512)
             if K <= 512:
@@ -320,17 +340,11 @@ def main():
                 xy_on_board = t2["launches"]["xty"] <= t2["fits"]
                 if not xy_on_board:
                     syrk_ms -= tm["ms"]["xty"] / max(tm["fits"], 1)
-                nbk = (K + 127) // 128                      # 128 x 128 blocks = 64 tiles of 16 x 16: the blocks above the diagonal
-                tiles = 64 * (nbk * (nbk - 1) // 2) + 40 * nbk   # in full, 40 tiles (4 waves x 10) of every diagonal block
-                executed = 2.0 * N * 16 * 16 * tiles
                 alt["type2_mfma_syrk"] = {"components_per_s": round(A * st / e2, 2), "ms_per_fit": round(e2 / st * 1e3, 3),
-                                          "syrk_ms": round(syrk_ms, 3), "syrk_launch_also_forms_xty": bool(xy_on_board),
-                                          "syrk_tflops_executed": round(executed / (syrk_ms * 1e-3) / 1e12, 2) if syrk_ms > 0 else None,
-                                          "syrk_tflops_nominal_2NK2_symmetry_counted": round(2.0 * N * K * K / (syrk_ms * 1e-3) / 1e12, 2) if syrk_ms > 0 else None,
-                                          "fp64_mfma_peak_tflops": 78.6,
+                                          "syrk_launch_also_forms_xty": bool(xy_on_board),
+                                          "roofline": syrk_roofline(nrows, K, syrk_ms),
                                           "note": "T (scores) not computed by this method; 'executed' counts the 16 x 16 tiles the kernel "
-                                                  "computes (blocks above the diagonal in full, 40 of 64 tiles of a diagonal block), "
-                                                  "'nominal' the full 2 N K^2 (can exceed the MFMA peak)"}
+                                                  "computes, 'nominal' the full 2 N K^2 (can exceed the MFMA peak)"}
             # the stand-alone rank-1 deflation (the north star's "deflation step"), X -= t p^T in place
             h.set_option(pls_amd.OPT_ALGO, algo)
             h.set_option(pls_amd.OPT_FUSE, a.fuse)

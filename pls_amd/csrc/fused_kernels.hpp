@@ -62,6 +62,17 @@ __device__ __forceinline__ void st_pack_u(T *p, const Pack<T, V> &x) {
     __builtin_memcpy(p, &x, sizeof(x));
 }
 
+// The previous score column (t_prev) is read through a buffer descriptor as well: ONE descriptor, num_records = the VALID
+// rows (the launchers keep N s below 2^31), built before the tile loop; the lane's offset is its first row.  Raw buffer
+// accesses are range-checked per dword (gfx9 family), so the 16-byte load of the pack that straddles row N reads zeros
+// for the rows behind the end -- a sweep over the library's zero-padded tiled copy can therefore run to the next
+// multiple of V rows with no code for the partial pack.  (The score STORE keeps its plain 16-byte form with an
+// element-wise branch for that one pack: as a buffer store it cost the fp32 instantiations 34 spilled registers.)
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t score_rsrc(const T *col, i64 nvalid) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(col), (short)0, (int)(nvalid * (i64)sizeof(T)), BUF_WORD3);
+}
+
 // Matrix layouts: element (i, k) of a matrix with column stride ld and tile stride ts lives at
 //   (i / R) * ts + (i % R) + k * ld.
 // The caller's column-major matrices are (ld, ts = R): a tile is K separate 256-byte segments.  The
@@ -128,7 +139,9 @@ template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX_ = AUX
 __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pass_kernel(
     const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd, i64 N, int K,  // dst may alias X (in-place deflation)
     const double *__restrict__ v, const T *__restrict__ tprev, const double *__restrict__ pprev,
-    T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart, int rdst) {
+    T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart, int rdst, i64 NV) {
+    // N: rows swept (a multiple of V); NV <= N: valid rows of the score columns (the rows between are zero padding of
+    // the library's own copy)
     constexpr int RP = R / V;    // lanes along the rows of a tile
     constexpr int CG = NT / RP;  // column groups
     constexpr int NW = NT / WAVE;
@@ -177,6 +190,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
         dtile = (R / rdst) * tsd;
     }
     constexpr uint32_t OOR = 0x80000000u;  // beyond every num_records the launcher allows
+    const __amdgpu_buffer_rsrc_t rs_tin = score_rsrc<T>(DEFL ? tprev : tout, NV);
 
     // EDGE = 2: XCD-contiguous tiles (grids that are a multiple of 8; cyclic otherwise).  The other instantiations fold
     // the three values below to blockIdx.x, gridDim.x and N at compile time.
@@ -201,13 +215,10 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
         }
         if (DEFL) {
             double tp[V];
-            if (rowok) {
-                const Pack<T, V> tpk = ld_pack_u<T, V>(tprev + i0);
+            {
+                const Pack<T, V> tpk = buf_ld<T, V>(rs_tin, rowok ? (uint32_t)(i0 * (i64)sizeof(T)) : OOR);
 #pragma unroll
                 for (int e = 0; e < V; ++e) tp[e] = -(double)tpk.v[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < V; ++e) tp[e] = 0.0;
             }
 #pragma unroll
             for (int j = 0; j < CPT; ++j) {
@@ -256,7 +267,13 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
             Pack<T, V> o;
 #pragma unroll
             for (int e = 0; e < V; ++e) o.v[e] = (T)t[e];
-            st_pack_u<T, V>(tout + i0, o);
+            if (i0 + V <= NV) {
+                st_pack_u<T, V>(tout + i0, o);
+            } else {  // the pack that straddles the last valid row (padded sweeps only)
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (i0 + e < NV) tout[i0 + e] = o.v[e];
+            }
 #pragma unroll
             for (int e = 0; e < V; ++e) ss = fma(t[e], t[e], ss);
         }
@@ -299,7 +316,7 @@ template <typename T, int V, int R, int NT, int CPT, int EDGE = 0>
 __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
     const T *src, i64 lds_, i64 tss, T *dst, i64 ldd, i64 tsd, int rdst, i64 N, int K, const T *__restrict__ tprev,
     const double *__restrict__ pprev, const double *__restrict__ w, T *__restrict__ tout,
-    double *__restrict__ sspart) {
+    double *__restrict__ sspart, i64 NV) {  // (N rows swept, NV valid score rows: see fused_pass_kernel)
     constexpr int RP = R / V, CG = NT / RP, NW = NT / WAVE;
     extern __shared__ double dyn[];  // [2K]: w, p_prev
     __shared__ double tred[2][NW][R];
@@ -322,6 +339,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
     const uint32_t doff = (uint32_t)(((i64)dsub * tsd + dwithin + (i64)cg * ldd) * (i64)sizeof(T));
     constexpr uint32_t OOR = 0x80000000u;
     const int ngroups = (K + CG - 1) / CG;
+    const __amdgpu_buffer_rsrc_t rs_tin = score_rsrc<T>(tprev, NV);
     double ss = 0.0;
     int buf = 0;
     TileWalk<EDGE == 2, R> walk(N);
@@ -330,13 +348,10 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
         const bool rowok = (i0 < N);
         const uint32_t so = rowok ? soff : OOR, dof = rowok ? doff : OOR;
         double tp[V], tacc[V];
-        if (rowok) {
-            const Pack<T, V> tpk = ld_pack_u<T, V>(tprev + i0);
+        {
+            const Pack<T, V> tpk = buf_ld<T, V>(rs_tin, rowok ? (uint32_t)(i0 * (i64)sizeof(T)) : OOR);
 #pragma unroll
             for (int e = 0; e < V; ++e) tp[e] = -(double)tpk.v[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < V; ++e) tp[e] = 0.0;
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) tacc[e] = 0.0;
@@ -385,7 +400,13 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void deflate_score_kernel(
                 const double ts = (double)o.v[e];
                 ss = fma(ts, ts, ss);
             }
-            st_pack_u<T, V>(tout + i0, o);
+            if (i0 + V <= NV) {
+                st_pack_u<T, V>(tout + i0, o);
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (i0 + e < NV) tout[i0 + e] = o.v[e];
+            }
         }
     }
     ss = block_sum<NW>(ss, sred);
@@ -409,6 +430,7 @@ struct TailArgs {
     double *part = nullptr, *sspart = nullptr;
     const T *Y = nullptr; i64 ldy = 0; int M = 0;
     i64 row0 = 0; int nrows = 0, K = 0;
+    int zero_rows = 0;  // rows behind the last one to clear in dst (the padding of the library's tiled copy up to a multiple of V)
 };
 
 template <typename T>
@@ -439,6 +461,12 @@ __global__ __launch_bounds__(WG) void tail_rows_kernel(TailArgs<T> a) {
         }
         ss = fma(t[r], t[r], ss);
     }
+    if (a.dst)
+        for (int r = 0; r < a.zero_rows; ++r) {
+            const i64 i = a.row0 + a.nrows + r;
+            T *drow = a.dst + (i / a.rd) * a.tsd + i % a.rd;
+            for (int k = threadIdx.x; k < a.K; k += WG) drow[(i64)k * a.ldd] = (T)0;
+        }
     if (a.part) {  // (every thread re-reads the elements it wrote itself)
         const int nm = a.Y ? a.M : 1;
         for (int k = threadIdx.x; k < a.K; k += WG)
@@ -636,7 +664,7 @@ int launch_retile_xty(hipStream_t stream, int num_cu, const T *src, i64 lds_, co
         a.src = src; a.lds = lds_; a.tss = R; a.rs = R;
         a.dst = dst; a.ldd = ldd; a.tsd = tsd; a.rd = rdst;
         a.part = part + (i64)gx * K * M; a.Y = Y; a.ldy = ldy; a.M = M;
-        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K;
+        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K; a.zero_rows = V - a.nrows;
         launch_tail_rows(stream, a);
         ++gx;
     }
@@ -648,11 +676,14 @@ int launch_retile_xty(hipStream_t stream, int num_cu, const T *src, i64 lds_, co
 template <typename T>
 int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_, i64 tss, T *dst, i64 ldd, i64 tsd,
                          int rdst, i64 N, int K, const T *tprev, const double *pprev, const double *w, T *tout,
-                         double *sspart, int max_rows, int *nss) {
+                         double *sspart, int max_rows, int *nss, bool src_padded = false) {
+    // src_padded: the source is the library's own copy, whose rows up to the next multiple of V exist and hold zeros --
+    // the sweep runs over them (no tail kernel); otherwise the last N % V rows go to the tail kernel
     constexpr int V = 16 / sizeof(T);
     constexpr int R = 256 / sizeof(T), NT = 512, CPT = 8;
     constexpr int CG = NT / (R / V);
     if (N < 1 || max_rows < 2 || !cols_aligned<T>(dst, ldd) || !elem_aligned<T>(tprev) || !elem_aligned<T>(tout)) return 1;
+    if ((N + V) * (i64)sizeof(T) >= (1ll << 31)) return 1;  // one descriptor per score column
     const int edge = edge_level<T>(src, lds_, CG, WAVE / (R / V));
     if (edge < 0 || (edge == 0 && tss % V != 0)) return 1;
     if (tsd % V != 0 || rdst < V || R % rdst != 0) return 1;
@@ -663,20 +694,20 @@ int launch_deflate_score(hipStream_t stream, int num_cu, const T *src, i64 lds_,
     auto kfn = edge == 2 ? &deflate_score_kernel<T, V, R, NT, CPT, 2>
                          : (edge == 1 ? &deflate_score_kernel<T, V, R, NT, CPT, 1> : &deflate_score_kernel<T, V, R, NT, CPT, 0>);
     if (dyn > 48 * 1024 && !raise_dynamic_lds(reinterpret_cast<const void *>(kfn), 72 * 1024)) return 1;
-    const i64 Nf = N - N % V;
+    const i64 Nf = src_padded ? (N + V - 1) / V * V : N - N % V;
     i64 grid = 0;
     if (Nf > 0) {
         const i64 ntiles = (Nf + R - 1) / R;
         grid = std::min<i64>(std::min<i64>(ntiles, 2 * (i64)num_cu), max_rows - 1);
         hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NT), (size_t)K * 16, stream, src, lds_, tss, dst, ldd, tsd, rdst, Nf,
-                           K, tprev, pprev, w, tout, sspart);
+                           K, tprev, pprev, w, tout, sspart, N);
     }
     if (Nf < N) {  // the last N % V rows
         TailArgs<T> a;
         a.src = src; a.lds = lds_; a.tss = tss; a.rs = R;
         a.dst = dst; a.ldd = ldd; a.tsd = tsd; a.rd = rdst;
         a.tprev = tprev; a.pprev = pprev; a.v = w; a.tout = tout; a.sspart = sspart + grid;
-        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K;
+        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K; a.zero_rows = V - a.nrows;
         launch_tail_rows(stream, a);
         ++grid;
     }
@@ -749,7 +780,7 @@ int launch_retile(hipStream_t stream, int num_cu, const T *src, i64 lds_, T *dst
         TailArgs<T> a;
         a.src = src; a.lds = lds_; a.tss = R; a.rs = R;
         a.dst = dst; a.ldd = ldd; a.tsd = tsd; a.rd = rdst;
-        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K;
+        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K; a.zero_rows = V - a.nrows;
         launch_tail_rows(stream, a);
     }
     return 0;
@@ -761,7 +792,7 @@ template <typename T>
 int deflate_score_mode(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
     constexpr int V = 16 / sizeof(T);
     constexpr int CG = 512 / ((256 / (int)sizeof(T)) / V);
-    if (N < 1 || (size_t)K * 16 > 72 * 1024 || !elem_aligned<T>(Tm)) return 0;
+    if (N < 1 || (size_t)K * 16 > 72 * 1024 || !elem_aligned<T>(Tm) || (N + 16) * (i64)sizeof(T) >= (1ll << 31)) return 0;
     const int e = edge_level<T>(X, ldx, CG, 4);
     return e < 0 ? 0 : (e == 0 ? 1 : 2);
 }
@@ -777,7 +808,7 @@ bool deflate_score_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ld
 template <typename T, int V, int R, int NT, int CPT>
 __global__ __launch_bounds__(NT, (NT / 256) * 2) void xty_tiled_kernel(const T *X, i64 ldx, i64 tsx, i64 N, int K,
                                                                        const T *__restrict__ t,
-                                                                       double *__restrict__ part, int tpw) {
+                                                                       double *__restrict__ part, int tpw, i64 NV) {
     constexpr int RP = R / V, CG = NT / RP;
     const int rp = threadIdx.x % RP, cg = threadIdx.x / RP;
     const int g0 = blockIdx.y * CPT;  // first column group of this block
@@ -785,6 +816,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void xty_tiled_kernel(const T *
     const i64 tile0 = (i64)blockIdx.x * tpw, tile1 = min(ntiles, tile0 + (i64)tpw);
     const uint32_t xoff = (uint32_t)(((i64)rp * V + (i64)cg * ldx) * (i64)sizeof(T));
     constexpr uint32_t OOR = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_t = score_rsrc<T>(t, NV);
     double pacc[CPT];
 #pragma unroll
     for (int j = 0; j < CPT; ++j) pacc[j] = 0.0;
@@ -803,13 +835,10 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void xty_tiled_kernel(const T *
             __builtin_amdgcn_sched_barrier(0);
         }
         double tv[V];
-        if (rowok) {
-            const Pack<T, V> tpk = ld_pack_u<T, V>(t + i0);
+        {
+            const Pack<T, V> tpk = buf_ld<T, V>(rs_t, rowok ? (uint32_t)(i0 * (i64)sizeof(T)) : OOR);
 #pragma unroll
             for (int e = 0; e < V; ++e) tv[e] = (double)tpk.v[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < V; ++e) tv[e] = 0.0;
         }
 #pragma unroll
         for (int j = 0; j < CPT; ++j)
@@ -832,27 +861,18 @@ int launch_xty_tiled(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 ts
     constexpr int R = (512 / CGX) * V, NT = 512, CPT = 16;  // = tile_rows<T, CGX>()
     constexpr int CG = NT / (R / V);
     if (!cols_aligned<T>(X, ldx) || !elem_aligned<T>(t) || tsx % V != 0 || N < 1 || max_rows < 2) return 1;
+    if ((N + V) * (i64)sizeof(T) >= (1ll << 31)) return 1;  // one descriptor per score column
     if ((i64)CG * ldx * (i64)sizeof(T) >= (1ll << 31)) return 1;
-    const i64 Nf = N - N % V;
-    i64 gx = 0;
-    if (Nf > 0) {
-        const i64 ntiles = (Nf + R - 1) / R;
-        const int nkb = (K + CG * CPT - 1) / (CG * CPT);
-        // ~8 workgroups per CU in total, at most max_rows - 1 row chunks
-        const i64 want = std::max<i64>(1, std::min<i64>((8 * (i64)num_cu + nkb - 1) / nkb, max_rows - 1));
-        const i64 tpw = (ntiles + want - 1) / want;
-        gx = (ntiles + tpw - 1) / tpw;
-        hipLaunchKernelGGL((xty_tiled_kernel<T, V, R, NT, CPT>), dim3((unsigned)gx, (unsigned)nkb), dim3(NT), 0, stream, X,
-                           ldx, tsx, Nf, K, t, part, (int)tpw);
-    }
-    if (Nf < N) {
-        TailArgs<T> a;
-        a.src = X; a.lds = ldx; a.tss = tsx; a.rs = R;
-        a.tgiven = t; a.part = part + gx * K;
-        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K;
-        launch_tail_rows(stream, a);
-        ++gx;
-    }
+    // (X is the library's own zero-padded copy: the sweep runs to the next multiple of V rows)
+    const i64 Nf = (N + V - 1) / V * V;
+    const i64 ntiles = (Nf + R - 1) / R;
+    const int nkb = (K + CG * CPT - 1) / (CG * CPT);
+    // ~8 workgroups per CU in total, at most max_rows row chunks
+    const i64 want = std::max<i64>(1, std::min<i64>((8 * (i64)num_cu + nkb - 1) / nkb, max_rows));
+    const i64 tpw = (ntiles + want - 1) / want;
+    const i64 gx = (ntiles + tpw - 1) / tpw;
+    hipLaunchKernelGGL((xty_tiled_kernel<T, V, R, NT, CPT>), dim3((unsigned)gx, (unsigned)nkb), dim3(NT), 0, stream, X,
+                       ldx, tsx, Nf, K, t, part, (int)tpw, N);
     *nb = (int)gx;
     return 0;
 }
@@ -872,7 +892,7 @@ constexpr int tile_rows() { return (512 / CGX) * (16 / (int)sizeof(T)); }
 template <typename T>
 int fused_pass_mode(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
     constexpr int CG = 32;
-    if (K > CG * 32 || N < 1 || !elem_aligned<T>(Tm)) return 0;
+    if (K > CG * 32 || N < 1 || !elem_aligned<T>(Tm) || (N + 16) * (i64)sizeof(T) >= (1ll << 31)) return 0;
     const int e = edge_level<T>(X, ldx, CG, 4);
     return e < 0 ? 0 : (e == 0 ? 1 : 2);
 }
@@ -887,7 +907,10 @@ bool fused_pass_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) 
 template <typename T, int CGX = 32>
 int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd,
                       i64 N, int K, const double *v, const T *tprev, const double *pprev, T *tout,
-                      double *part, int max_rows, double *sspart, int *nb, int *nss, int grid_hint, int rdst = 0) {
+                      double *part, int max_rows, double *sspart, int *nb, int *nss, int grid_hint, int rdst = 0,
+                      bool src_padded = false) {
+    // src_padded: X is the library's own copy, whose rows up to the next multiple of V exist and hold zeros -- the sweep
+    // runs over them (no tail kernel); otherwise the last N % V rows go to the tail kernel
     constexpr int V = 16 / sizeof(T);
     constexpr int R = tile_rows<T, CGX>(), NT = 512;
     constexpr int CG = NT / (R / V);
@@ -899,6 +922,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     int edge = edge_level<T>(X, ldx, CG, WAVE / (R / V));
     if (edge < 0 || (edge == 0 && tsx % V != 0) || (defl && tsd % V != 0)) return 1;
     if (K > CG * (CGX == 256 ? 16 : 32) || N < 1 || max_rows < 2) return 1;
+    if ((N + V) * (i64)sizeof(T) >= (1ll << 31)) return 1;  // one descriptor per score column
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if (rdst > 0 && (CGX != 32 || !defl || rdst < V || R % rdst != 0 ||
                      ((i64)(R / rdst) * tsd + (i64)CG * ldd) * (i64)sizeof(T) >= (1ll << 31)))
@@ -907,7 +931,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     if constexpr (CGX == 32) {
         if (rdst > 0 && K <= CG * 16) return 1;
     }
-    const i64 Nf = N - N % V;  // whole row packs; the rest is the tail kernel's
+    const i64 Nf = src_padded ? (N + V - 1) / V * V : N - N % V;  // whole row packs; the rest is the tail kernel's
     i64 grid = 0;
     if (Nf > 0) {
         const i64 ntiles = (Nf + R - 1) / R;
@@ -924,7 +948,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     do {                                                                                                                  \
         auto kfn = &fused_pass_kernel<T, V, R, NT, CPT_, DEFL_, AUX_NT, AUX_NT, false, EDGE_>;                           \
         if ((dyn_) > 48 * 1024 && !raise_dynamic_lds(reinterpret_cast<const void *>(kfn), (int)(dyn_))) return 1;         \
-        hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, 0); \
+        hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, 0, N); \
     } while (0)
 #define FUSED_EDGE(CPT_, DEFL_, dyn_)                                                                                     \
     do {                                                                                                                  \
@@ -944,7 +968,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
                 auto kfn = edge == 2 ? &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 2>
                                      : (edge == 1 ? &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 1>
                                                   : &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 0>);
-                hipLaunchKernelGGL(kfn, g, b, 0, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, rdst);
+                hipLaunchKernelGGL(kfn, g, b, 0, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, rdst, N);
             } else if (K <= CG * 4) FUSED_CASE(4);
             else if (K <= CG * 8) FUSED_CASE(8);
             else if (K <= CG * 16) FUSED_CASE(16);
@@ -967,7 +991,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
             a.tprev = tprev; a.pprev = pprev;
         }
         a.v = v; a.tout = tout; a.part = part + grid * K; a.sspart = sspart + grid;
-        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K;
+        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K; a.zero_rows = V - a.nrows;
         launch_tail_rows(stream, a);
         ++grid;
     }

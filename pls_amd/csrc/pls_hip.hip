@@ -916,12 +916,12 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     if (mid_cg && a >= 2)  // half-height tiles of the working copy, in place
                         rc = plsk::launch_fused_pass<T, 64>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v,
                                                             tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
-                                                            &nb, &nss, (int)c->opt_fused_grid);
+                                                            &nb, &nss, (int)c->opt_fused_grid, 0, true);
                     else  // (a == 1 with mid_cg: X in 256-byte segments -> half-height tiles)
                         rc = plsk::launch_fused_pass<T>(c->stream, c->num_cu, Xc, ldc, tsc, tprev ? work : nullptr, ldw, tsw,
                                                         N, K, v, tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
                                                         &nb, &nss, (int)c->opt_fused_grid,
-                                                        (mid_cg && tprev) ? (int)WR : 0);
+                                                        (mid_cg && tprev) ? (int)WR : 0, Xc == work);
                     if (rc != 0) s.on = false;  // nothing was launched: drop the event pair
                 }
                 if (rc == 0) {
@@ -949,7 +949,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     const i64 bytes = (nipals ? 2 : 1) * ((i64)N * K * sizeof(T) + (i64)N * sizeof(T)) + 3 * (i64)K * 8;
                     Scope s(c, PLS_HIP_FAM_FUSED, bytes);
 #define WIDE_PASS(CG_) plsk::launch_fused_pass<T, CG_>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v, tprev, pprev, \
-                                                        Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid)
+                                                        Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid, 0, true)
                     rc = wide_cg == 32 ? WIDE_PASS(32) : (wide_cg == 64 ? WIDE_PASS(64) : (wide_cg == 128 ? WIDE_PASS(128) : WIDE_PASS(256)));
 #undef WIDE_PASS
                     if (rc != 0) s.on = false;
@@ -970,7 +970,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                         Scope s(c, PLS_HIP_FAM_DEFLATE, bytes);
                         const int rc = plsk::launch_deflate_score<T>(c->stream, c->num_cu, Xc, ldc, tsc, work, ldw, tsw,
                                                                      (int)(tiled_work ? WR : TR), N, K, tprev, pprev, v,
-                                                                     Tm + (i64)a * ldt, sspart, (int)ssmax, &nss);
+                                                                     Tm + (i64)a * ldt, sspart, (int)ssmax, &nss, Xc == work);
                         if (rc != 0) {
                             s.on = false;
                             return fail(c, PLS_HIP_ERR_DEVICE, "deflate+score launch failed");

@@ -12,6 +12,7 @@ one = po.OracleLib(omp=True)
 h = pls_amd.Handle()
 worst = {}
 bad = 0
+widened = 0
 t0 = time.time()
 for case in range(ncases):
     kind = rng.choice(["tiny", "small", "gram", "wide", "cv"])
@@ -30,11 +31,12 @@ for case in range(ncases):
     A = max(1, min(A, N - 1))  # beyond the rank of X the reference's results are inf / NaN (src/pls.cpp:427-428): nothing to compare
     f32 = bool(rng.integers(0, 4) == 0)
     X = one.synth_x(case * 7919, N, K); Y = one.synth_y(case * 7919, N, M)
+    cond = 0.0
     if f32:
         X = np.asfortranarray(X.astype(np.float32).astype(np.float64)); Y = np.asfortranarray(Y.astype(np.float32).astype(np.float64))
     dt = torch.float32 if f32 else torch.float64
     Xd = pls_amd.as_colmajor(torch.from_numpy(X).to(dt).cuda()); Yd = pls_amd.as_colmajor(torch.from_numpy(Y).to(dt).cuda())
-    tol = 5e-5 if f32 else 1e-9
+    tol = 5e-5 if f32 else 1e-10  # fp64: the north star's bar on the coefficients
     try:
         if kind == "cv":
             ts = int(rng.integers(1, max(2, N // 3))); nf = int(rng.integers(1, 6))
@@ -66,15 +68,20 @@ for case in range(ncases):
             alt = one.plsr(X, Y, A, nipals=True)
             cond = po.rel_fro(one.coefficients(alt["R"], alt["Q"]), Bref)
             lim = max(tol, 50 * cond)
+            if cond > tol / 50:  # the CPU routes themselves disagree beyond the bar: counted, judged against their spread
+                widened += 1
         else:
             lim = max(tol, 1e-7)
         if not np.isfinite(err) or err > lim:
             bad += 1
             print("FAIL", label, "err", err, "limit", lim, flush=True)
-        worst[kind] = max(worst.get(kind, 0.0), err if np.isfinite(err) else 1e9)
+        key = f"{kind}/{'f32' if f32 else 'f64'}"  # worst figures per storage type
+        worst[key] = max(worst.get(key, 0.0), err if np.isfinite(err) else 1e9)
+        if kind != "cv" and not f32 and cond <= tol / 50:
+            worst["f64, well-conditioned B (limit 1e-10)"] = max(worst.get("f64, well-conditioned B (limit 1e-10)", 0.0), err)
     except Exception as e:  # noqa: BLE001
         bad += 1
         print("EXC ", kind, N, K, M, A, f32, repr(e)[:200], flush=True)
     if case % 20 == 19: print(f"{case + 1} cases, {bad} bad, {time.time() - t0:.0f} s, worst {worst}", flush=True)
-print("done:", ncases, "cases,", bad, "bad; worst relative errors", worst)
+print("done:", ncases, "cases,", bad, "bad;", widened, "judged against the spread of the CPU routes; worst relative errors", worst)
 sys.exit(1 if bad else 0)
