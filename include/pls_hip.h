@@ -250,9 +250,16 @@ PLS_HIP_API int pls_hip_synth_y(pls_hip_handle h, void *Y, int64_t ldy, int64_t 
  * The reference's Model is one object driven by one host thread (include/PLS/pls.h:187-199, src/pls.cpp:340-353).
  * A group keeps that shape while the rows of X and Y are spread over the GPUs of the node: it owns one handle and
  * one stream per member and runs every call with one host thread per member inside the library.  The members'
- * partial products are summed by a reducer the group installs itself -- a fixed-order all-reduce in which
- * every member reads the other members' partials directly over xGMI (peer access) and sums them in rank order, so
- * all members hold identical bits; it is ordered on the members' streams with HIP events, no host synchronisation.
+ * partial products are summed by a reducer the group installs itself -- a fixed-order all-reduce with no RCCL and,
+ * when every member has a GPU of its own, nothing on the host at all: each member WRITES its partial sums into an
+ * inbox on every peer over xGMI and raises a sequence flag there, and the consumer's kernel spins on its flags and adds
+ * the inboxes in rank order ("device-side exchange": two small launches per member and collective, a one-hop direct
+ * write as SURVEY.md 8(e) recommends for these latency-bound messages; a member that waits longer than 30 s -- a peer
+ * failed or fell out of step -- makes the call return PLS_HIP_ERR_REDUCER).  The exchange is tried once on known
+ * values when the group is created.  Where it is not available (members that share a GPU -- see below -- or no peer
+ * writes into fine-grained memory), and for messages beyond 512 KB, the members instead READ each other's buffers
+ * behind two host-thread barriers per collective ("host-synchronised exchange").  Either way all members end up with
+ * identical bits.  PLS_HIP_GROUP_EXCHANGE = device | host overrides the choice.
  * `devices[r]` is the HIP ordinal of member r; an ordinal may repeat ("virtual shards" sharing one GPU: the way the
  * sharded path is exercised on a one-GPU machine).  A group of one member is a plain single-GPU fit.
  *
@@ -268,6 +275,8 @@ typedef struct pls_hip_matrix_s *pls_hip_matrix;
 PLS_HIP_API int pls_hip_group_create(pls_hip_group *out, int n, const int *devices);
 PLS_HIP_API int pls_hip_group_destroy(pls_hip_group g);
 PLS_HIP_API int pls_hip_group_size(pls_hip_group g);
+/* 1 = the device-side exchange carries the group's collectives, 0 = the host-synchronised one (or one member) */
+PLS_HIP_API int pls_hip_group_exchange(pls_hip_group g);
 /* member r's handle (options, timing); it stays owned by the group */
 PLS_HIP_API int pls_hip_group_handle(pls_hip_group g, int rank, pls_hip_handle *out);
 PLS_HIP_API int pls_hip_group_set_option(pls_hip_group g, int option, int64_t value);

@@ -75,6 +75,7 @@ PROTOTYPES = [
     ("pls_hip_group_create", _int, [ctypes.POINTER(_vp), _int, ctypes.POINTER(_int)]),
     ("pls_hip_group_destroy", _int, [_vp]),
     ("pls_hip_group_size", _int, [_vp]),
+    ("pls_hip_group_exchange", _int, [_vp]),
     ("pls_hip_group_handle", _int, [_vp, _int, ctypes.POINTER(_vp)]),
     ("pls_hip_group_set_option", _int, [_vp, _int, _i64]),
     ("pls_hip_group_last_error", ctypes.c_char_p, [_vp]),

@@ -24,6 +24,69 @@ __global__ __launch_bounds__(256) void peer_sum_kernel(PeerPtrs src, int n, i64 
     }
 }
 
+// ---- device-side exchange (the default for messages up to XCHG_CAP doubles) -----------------------------------------
+// Every member owns an INBOX on its device: [2 parities][n members][XCHG_CAP] doubles + [2][n] sequence flags, in
+// fine-grained memory (remote writes become visible to a kernel that is already running).  All-reduce number q of a
+// member (every member issues the same sequence of collectives):
+//   push   (one workgroup per destination):  the member's 8 reduction slices summed to ONE vector, written into slot
+//          [q & 1][rank] of every member's inbox over xGMI, then -- system-scope release -- flag[q & 1][rank] = q;
+//   gather (same stream, right behind):  spins (system-scope acquire) until its own n flags show q, sums the n slots in
+//          rank order into slice 0 of the member's buffer and clears slices 1..7 (the consumers add the 8 slices).
+// No host thread, no event, no copy takes part: two small kernels per member and collective.  Two parities suffice: a
+// member can only reach collective q + 2 after it has gathered q + 1, i.e. after every peer has PUSHED q + 1, which
+// each peer does behind its own gather of q.  A wait that lasts longer than XCHG_TIMEOUT_S (a member that failed or
+// fell out of step) sets the member's status word and leaves the loop -- the fit then reports PLS_HIP_ERR_REDUCER.
+constexpr i64 XCHG_CAP = 1 << 16;        // doubles per message (512 KB); larger messages take the host-synchronised path
+constexpr int XCHG_THREADS = 1024;
+constexpr double XCHG_TIMEOUT_S = 30.0;  // (a peer's first fit may still be loading code objects or allocating; PLS_HIP_XCHG_TIMEOUT_S)
+
+struct XchgPeers {
+    double *slot[GROUP_MAX];                 // inbox slot [parity][my rank] of every member
+    unsigned long long *flag[GROUP_MAX];     // its flag
+};
+
+__global__ __launch_bounds__(XCHG_THREADS) void xchg_push_kernel(XchgPeers peers, const double *__restrict__ buf, int L,
+                                                                 int slices, unsigned long long seq) {
+    double *dst = peers.slot[blockIdx.x];
+    for (int j = threadIdx.x; j < L; j += XCHG_THREADS) {
+        double sum = buf[j];
+        for (int sl = 1; sl < slices; ++sl) sum += buf[(i64)sl * L + j];
+        __hip_atomic_store(dst + j, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(peers.flag[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void xchg_gather_kernel(const double *inbox, const unsigned long long *flags, int n, i64 cap,
+                                                          int L, int slices, unsigned long long seq, double *__restrict__ buf,
+                                                          int *status, int *host_status, long long limit) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) ok = (*status == 0);  // an earlier wait of this fit timed out: do not wait again
+    __syncthreads();
+    if ((int)threadIdx.x < n && ok) {
+        const long long t0 = wall_clock64();  // limit: ticks of the device's wall clock (hipDeviceAttributeWallClockRate)
+        while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            if (wall_clock64() - t0 > limit) {
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (!ok && threadIdx.x == 0) {
+        *status = 1;
+        __hip_atomic_store(host_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-mapped: read without a copy)
+    }
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < L; j += gridDim.x * 256) {
+        double sum = ok ? __hip_atomic_load(inbox + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __builtin_nan("");
+        for (int m = 1; m < n && ok; ++m) sum += __hip_atomic_load(inbox + (i64)m * cap + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        buf[j] = sum;
+        for (int sl = 1; sl < slices; ++sl) buf[(i64)sl * L + j] = 0.0;
+    }
+}
+
 // host barrier of the member threads; abort() releases every waiter with `false` (a member failed)
 class GroupBarrier {
 public:
@@ -97,6 +160,14 @@ struct pls_hip_group_s {
     std::vector<i64> scratch_count;
     std::vector<hipEvent_t> ready[2], done[2];
     std::vector<int> phase;
+    // device-side exchange (see above): per member inbox, flags, status word, collectives issued so far
+    bool xchg = false;
+    std::vector<double *> inbox;
+    std::vector<unsigned long long *> xflags;
+    std::vector<int *> xstatus;
+    int *xhost = nullptr, *xhost_dev = nullptr;  // one host-mapped word per member: a wait timed out
+    std::vector<unsigned long long> xseq;
+    std::vector<long long> xlimit;  // time limit of a wait in wall-clock ticks of the member's device
     std::string err;
     // freed blocks of resident matrices, kept for the next allocation of the same size (a Model that is rebuilt on
     // data of the same shape, cross-validation refits): hipMalloc / hipFree of multi-GB blocks cost 50-250 ms when
@@ -121,6 +192,69 @@ int gfail(pls_hip_group_s *g, int code, const std::string &msg) {
     return code;
 }
 
+// the two launches of one device-side collective of member r (its device current); buf: `slices` x L doubles
+int xchg_launch(pls_hip_group_s *g, int r, double *buf, int L, int slices, hipStream_t stream, long long limit) {
+    const int n = g->n;
+    const unsigned long long seq = ++g->xseq[r];
+    const int par = (int)(seq & 1);
+    XchgPeers peers;
+    for (int j = 0; j < n; ++j) {
+        peers.slot[j] = g->inbox[j] + ((i64)par * n + r) * XCHG_CAP;
+        peers.flag[j] = g->xflags[j] + par * n + r;
+    }
+    hipLaunchKernelGGL(xchg_push_kernel, dim3(n), dim3(XCHG_THREADS), 0, stream, peers, (const double *)buf, L, slices, seq);
+    hipLaunchKernelGGL(xchg_gather_kernel, dim3((unsigned)std::min<i64>(16, (L + 255) / 256)), dim3(256), 0, stream,
+                       (const double *)(g->inbox[r] + (i64)par * n * XCHG_CAP), (const unsigned long long *)(g->xflags[r] + par * n),
+                       n, XCHG_CAP, L, slices, seq, buf, g->xstatus[r], g->xhost_dev + r, limit);
+    return hipGetLastError() == hipSuccess ? 0 : 13;
+}
+
+// drain every member's stream and start the sequence numbers over (after a time-out or a failed member)
+void xchg_reset(pls_hip_group_s *g) {
+    for (int r = 0; r < g->n; ++r)
+        if (hipSetDevice(g->dev[r]) == hipSuccess) (void)hipStreamSynchronize(g->stream[r]);
+    for (int r = 0; r < g->n; ++r) {
+        if (hipSetDevice(g->dev[r]) != hipSuccess) continue;
+        (void)hipMemset(g->xflags[r], 0, (size_t)2 * g->n * 8 + 64);
+        (void)hipDeviceSynchronize();
+        g->xhost[r] = 0;
+        g->xseq[r] = 0;
+    }
+    (void)hipSetDevice(g->dev[0]);
+}
+
+// One round of the exchange on known values when the group is created: member r contributes r + 1, every member must end
+// up with n (n + 1) / 2 within two seconds.  Anything else (no peer writes into fine-grained memory on this system, members
+// that share a GPU without a hardware queue each, ...) switches the group to the host-synchronised exchange for good.
+bool xchg_selftest(pls_hip_group_s *g) {
+    const int n = g->n;
+    std::vector<double *> buf(n, nullptr);
+    bool ok = true;
+    for (int r = 0; r < n && ok; ++r) {
+        double host[plsk::RED_SLICES] = {0};
+        host[0] = r + 1.0;
+        ok = hipSetDevice(g->dev[r]) == hipSuccess && hipMalloc((void **)&buf[r], sizeof(host)) == hipSuccess &&
+             hipMemcpy(buf[r], host, sizeof(host), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    for (int r = 0; r < n && ok; ++r) {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, g->dev[r]) != hipSuccess || khz <= 0) khz = 100000;
+        ok = hipSetDevice(g->dev[r]) == hipSuccess &&
+             xchg_launch(g, r, buf[r], 1, plsk::RED_SLICES, g->stream[r], (long long)(2.0 * 1e3 * khz)) == 0;
+    }
+    for (int r = 0; r < n; ++r) {
+        if (hipSetDevice(g->dev[r]) != hipSuccess) { ok = false; continue; }
+        double got = 0.0;
+        if (hipStreamSynchronize(g->stream[r]) != hipSuccess ||
+            (buf[r] && hipMemcpy(&got, buf[r], 8, hipMemcpyDeviceToHost) != hipSuccess) || got != 0.5 * n * (n + 1) || g->xhost[r] != 0)
+            ok = false;
+        if (buf[r]) (void)hipFree(buf[r]);
+    }
+    (void)hipGetLastError();
+    if (!ok) xchg_reset(g);
+    return ok;
+}
+
 // pls_hip_allreduce_fn of a group member (called on the member's thread, device current)
 int group_allreduce(void *user, void *buf, int64_t count, void *stream_) {
     Member *m = static_cast<Member *>(user);
@@ -128,11 +262,12 @@ int group_allreduce(void *user, void *buf, int64_t count, void *stream_) {
     const int r = m->rank, n = g->n;
     if (n == 1) return 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (g->xchg && count % plsk::RED_SLICES == 0 && count / plsk::RED_SLICES <= XCHG_CAP)
+        return xchg_launch(g, r, (double *)buf, (int)(count / plsk::RED_SLICES), plsk::RED_SLICES, stream, g->xlimit[r]);
     const int ph = (g->phase[r] ^= 1);
     if (g->scratch_count[r] < count) {
         if (g->scratch[r]) {
-            if (hipStreamSynchronize(stream) != hipSuccess) return 2;
-            (void)hipFree(g->scratch[r]);
+            g->h[r]->graveyard.push_back(g->scratch[r]);  // (released when no member is running)
             g->scratch[r] = nullptr;
         }
         if (hipMalloc((void **)&g->scratch[r], (size_t)count * 8) != hipSuccess) return 3;
@@ -167,6 +302,11 @@ template <typename F>
 int run_members(pls_hip_group_s *g, F fn) {
     std::vector<int> rc(g->n, PLS_HIP_OK);
     g->bar.reset(g->n);
+    for (int r = 0; r < g->n; ++r)  // workspace the members outgrew in earlier calls (no member is running now)
+        if (!g->h[r]->graveyard.empty() && hipSetDevice(g->dev[r]) == hipSuccess) {
+            for (void *q : g->h[r]->graveyard) (void)hipFree(q);
+            g->h[r]->graveyard.clear();
+        }
     auto body = [&](int r) {
         int code = PLS_HIP_ERR_DEVICE;
         if (hipSetDevice(g->dev[r]) == hipSuccess) code = fn(r);
@@ -177,6 +317,33 @@ int run_members(pls_hip_group_s *g, F fn) {
     for (int r = 1; r < g->n; ++r) th.emplace_back(body, r);
     body(0);
     for (std::thread &t : th) t.join();
+    if (g->xchg) {
+        // device-side exchange: a wait that timed out (host-mapped status words), or a member that failed and left the
+        // others out of step -> drain every stream, start the sequence numbers over
+        bool timed_out = false, failed = false;
+        for (int r = 0; r < g->n; ++r) {
+            timed_out = timed_out || g->xhost[r] != 0;
+            failed = failed || rc[r] != PLS_HIP_OK;
+        }
+        if (timed_out || failed) {
+            for (int r = 0; r < g->n; ++r)
+                if (hipSetDevice(g->dev[r]) == hipSuccess) (void)hipStreamSynchronize(g->stream[r]);
+            std::string state;
+            for (int r = 0; r < g->n; ++r) {
+                timed_out = timed_out || g->xhost[r] != 0;
+                if (hipSetDevice(g->dev[r]) != hipSuccess) continue;
+                std::vector<unsigned long long> fl(2 * g->n, 0);  // what the member had received when it gave up
+                (void)hipMemcpy(fl.data(), g->xflags[r], fl.size() * 8, hipMemcpyDeviceToHost);
+                state += " member " + std::to_string(r) + " (collective " + std::to_string(g->xseq[r]) + ") has";
+                for (unsigned long long f : fl) state += " " + std::to_string(f);
+            }
+            xchg_reset(g);
+            if (timed_out && !failed) {
+                g->err = "device-side exchange: a member waited longer than the time limit for its peers' partial sums;" + state;
+                return PLS_HIP_ERR_REDUCER;
+            }
+        }
+    }
     for (int r = 0; r < g->n; ++r)
         if (rc[r] != PLS_HIP_OK) {
             // prefer the message of a member that failed on its own over one that was released by the abort
@@ -247,6 +414,27 @@ int pls_hip_group_create(pls_hip_group *out, int n, const int *devices) {
     g->scratch.assign(n, nullptr);
     g->scratch_count.assign(n, 0);
     g->phase.assign(n, 0);
+    g->inbox.assign(n, nullptr);
+    g->xflags.assign(n, nullptr);
+    g->xstatus.assign(n, nullptr);
+    g->xseq.assign(n, 0);
+    g->xlimit.assign(n, 0);
+    {
+        // PLS_HIP_GROUP_EXCHANGE = device | host.  Default: device when every member has a GPU of its own; members that
+        // SHARE a GPU (virtual shards: tests, rehearsals) wait for each other's kernels on one device, which needs as
+        // many hardware queues as members (GPU_MAX_HW_QUEUES) -- there the host-synchronised exchange stays the default.
+        bool distinct = true;
+        for (int a = 0; a < n; ++a)
+            for (int b = a + 1; b < n; ++b) distinct = distinct && devices[a] != devices[b];
+        const char *e = getenv("PLS_HIP_GROUP_EXCHANGE");
+        g->xchg = n > 1 && (e ? std::strcmp(e, "device") == 0 : distinct);
+        if (g->xchg && (hipHostMalloc((void **)&g->xhost, GROUP_MAX * sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess ||
+                        hipHostGetDevicePointer((void **)&g->xhost_dev, g->xhost, 0) != hipSuccess)) {
+            (void)hipGetLastError();
+            g->xchg = false;
+        }
+        if (g->xchg) std::memset(g->xhost, 0, GROUP_MAX * sizeof(int));
+    }
     g->freelist.resize(n);
     for (int p = 0; p < 2; ++p) {
         g->ready[p].assign(n, nullptr);
@@ -267,10 +455,27 @@ int pls_hip_group_create(pls_hip_group *out, int n, const int *devices) {
         if (hipStreamCreateWithFlags(&g->stream[r], hipStreamNonBlocking) != hipSuccess) { rc = PLS_HIP_ERR_DEVICE; break; }
         rc = pls_hip_create(&g->h[r], devices[r], g->stream[r]);
         if (rc != PLS_HIP_OK) break;
+        g->h[r]->defer_free = true;
         for (int p = 0; p < 2; ++p)
             if (hipEventCreateWithFlags(&g->ready[p][r], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&g->done[p][r], hipEventDisableTiming) != hipSuccess)
                 rc = PLS_HIP_ERR_DEVICE;
+        if (rc == PLS_HIP_OK && n > 1 && g->xchg) {
+            const size_t ib = (size_t)2 * n * XCHG_CAP * 8, fb = (size_t)2 * n * 8;
+            if (hipExtMallocWithFlags((void **)&g->inbox[r], ib, hipDeviceMallocFinegrained) != hipSuccess ||
+                hipExtMallocWithFlags((void **)&g->xflags[r], fb + 64, hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                g->xchg = false;  // (no fine-grained memory: the host-synchronised exchange)
+            } else {
+                g->xstatus[r] = reinterpret_cast<int *>(g->xflags[r] + 2 * n);
+                int khz = 0;
+                if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, devices[r]) != hipSuccess || khz <= 0) khz = 100000;
+                const char *te = getenv("PLS_HIP_XCHG_TIMEOUT_S");
+                const double secs = (te && atof(te) > 0) ? atof(te) : XCHG_TIMEOUT_S;
+                g->xlimit[r] = (long long)(secs * 1e3 * khz);
+                if (hipMemset(g->xflags[r], 0, fb + 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = PLS_HIP_ERR_DEVICE;
+            }
+        }
         g->member[r].g = g.get();
         g->member[r].rank = r;
         if (rc == PLS_HIP_OK && n > 1) {
@@ -283,6 +488,7 @@ int pls_hip_group_create(pls_hip_group *out, int n, const int *devices) {
         pls_hip_group_destroy(g.release());
         return rc;
     }
+    if (g->xchg && !xchg_selftest(g.get())) g->xchg = false;
     *out = g.release();
     return PLS_HIP_OK;
 }
@@ -293,6 +499,8 @@ int pls_hip_group_destroy(pls_hip_group g) {
         (void)hipSetDevice(g->dev[r]);
         if (g->h[r]) (void)pls_hip_destroy(g->h[r]);  // synchronises the member's stream
         if (g->scratch[r]) (void)hipFree(g->scratch[r]);
+        if (r < (int)g->inbox.size() && g->inbox[r]) (void)hipFree(g->inbox[r]);
+        if (r < (int)g->xflags.size() && g->xflags[r]) (void)hipFree(g->xflags[r]);
         if (r < (int)g->freelist.size())
             for (auto &b : g->freelist[r]) (void)hipFree(b.p);
         for (int p = 0; p < 2; ++p) {
@@ -301,11 +509,14 @@ int pls_hip_group_destroy(pls_hip_group g) {
         }
         if (g->stream[r]) (void)hipStreamDestroy(g->stream[r]);
     }
+    if (g->xhost) (void)hipHostFree(g->xhost);
     delete g;
     return PLS_HIP_OK;
 }
 
 int pls_hip_group_size(pls_hip_group g) { return g ? g->n : 0; }
+
+int pls_hip_group_exchange(pls_hip_group g) { return (g && g->xchg) ? 1 : 0; }
 
 int pls_hip_group_handle(pls_hip_group g, int rank, pls_hip_handle *out) {
     if (!g || !out || rank < 0 || rank >= g->n) return PLS_HIP_ERR_INVALID;

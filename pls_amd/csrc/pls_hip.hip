@@ -75,6 +75,14 @@ struct pls_hip_context {
     // X^T X (K x K) and X^T Y (K x M) of THIS member's rows, already formed while the rows were uploaded
     // (upload_accumulate): a fit that may use the Gram plan takes them instead of two passes over X
     const double *pre_xx = nullptr, *pre_xy = nullptr;
+    // Members of a group: workspace that has to grow is not freed on the spot -- hipFree waits for the whole DEVICE, and a
+    // member that shares its GPU with others (virtual shards) would wait for a peer's exchange kernel that in turn waits for
+    // this member's next collective.  The old blocks are released when no member is running (run_members).
+    bool defer_free = false;
+    std::vector<void *> graveyard;
+    // replica guard of sharded fits (small_kernels.hpp): host-mapped flag "the ranks derived different W/P/Q/R/B"
+    int *diverged = nullptr, *diverged_dev = nullptr;
+    DevBuf guard;
 };
 
 namespace {
@@ -102,8 +110,12 @@ int fail(pls_hip_context *c, int code, const std::string &msg) {
 int ensure(pls_hip_context *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.bytes && b.p) return PLS_HIP_OK;
     if (b.p) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // earlier launches may still read it
-        HIPCHK(c, hipFree(b.p));
+        if (c->defer_free) {
+            c->graveyard.push_back(b.p);
+        } else {
+            HIPCHK(c, hipStreamSynchronize(c->stream));  // earlier launches may still read it
+            HIPCHK(c, hipFree(b.p));
+        }
         b.p = nullptr;
         b.bytes = 0;
     }
@@ -645,6 +657,44 @@ int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX
     return compute_xx_finish(c, K, XX);
 }
 
+// Sharded fits: every rank must have derived the same bits (small_kernels.hpp, "replica guard").  Two small launches and one
+// 512-byte all-reduce per fit; the verdict lands in a host-mapped flag that pls_hip_synchronize (and the host-memory entry)
+// turn into PLS_HIP_ERR_REDUCER.
+int replica_guard(pls_hip_context *c, const double *W, const double *P, const double *Q, const double *R, const double *B,
+                  int K, int M, int A) {
+    if (!c->reducer || c->nranks < 2 || c->nranks > 1024) return PLS_HIP_OK;
+    static const bool on = !(getenv("PLS_HIP_REPLICA_GUARD") && atoi(getenv("PLS_HIP_REPLICA_GUARD")) == 0);
+    if (!on) return PLS_HIP_OK;
+    if (!c->diverged) {
+        if (hipHostMalloc((void **)&c->diverged, 64, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&c->diverged_dev, c->diverged, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            c->diverged = nullptr;
+            return PLS_HIP_OK;  // (no mapped host memory: the guard is an extra, not a precondition)
+        }
+        *c->diverged = 0;
+    }
+    CHK(ensure(c, c->guard, (size_t)plsk::RED_SLICES * 8 * 8));
+    double *g = (double *)c->guard.p;
+    hipLaunchKernelGGL(plsk::replica_checksum_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream, W, P, R, Q, B, (i64)K * A,
+                       (i64)M * A, (i64)K * M, g);
+    LAUNCH_CHECK(c);
+    CHK(do_allreduce(c, g, (i64)plsk::RED_SLICES * 8));
+    hipLaunchKernelGGL(plsk::replica_verify_kernel, dim3(1), dim3(plsk::WAVE), 0, c->stream, (const double *)g, c->nranks,
+                       c->diverged_dev);
+    LAUNCH_CHECK(c);
+    return PLS_HIP_OK;
+}
+
+int check_diverged(pls_hip_context *c) {  // (the stream has been synchronised)
+    if (c->diverged && *c->diverged) {
+        *c->diverged = 0;
+        return fail(c, PLS_HIP_ERR_REDUCER, "the ranks of the sharded fit derived different W / P / Q / R / B: the reducer did not "
+                                            "leave identical sums on every rank");
+    }
+    return PLS_HIP_OK;
+}
+
 // ---- the fit on device pointers -----------------------------------------------------------
 template <typename T>
 int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64 N, int K, int M,
@@ -736,9 +786,12 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // contiguous 128 KB block per tile, runs at 0.85 of peak (0.63 ms at config 3) against 0.72 (0.74 ms) over the caller's
     // column-major matrix in 256-byte segments; the copy costs 0.86 ms more than the X^T Y pass it replaces
     // (PLS_HIP_COPY_MIN_ALIGNED, default 10 components).
+    // Beyond 512 columns the direct pass (32 columns per lane, one workgroup per CU) already reads at 0.81 of peak and the
+    // copy only pays from ~30 components on (one shard of config 5: 2.65 -> 2.52 ms per pass against 4.1 ms for the copy).
     static const int copy_min = getenv("PLS_HIP_COPY_MIN") ? atoi(getenv("PLS_HIP_COPY_MIN")) : 4;
     static const int copy_min_al = getenv("PLS_HIP_COPY_MIN_ALIGNED") ? atoi(getenv("PLS_HIP_COPY_MIN_ALIGNED")) : 10;
-    const bool copy_fit = fused_fit && M <= 8 && A >= (vec_ok<T>(X, ldx, FVX) ? copy_min_al : copy_min);
+    const bool copy_fit = fused_fit && M <= 8 &&
+                          A >= (vec_ok<T>(X, ldx, FVX) ? (K <= 32 * 16 ? copy_min_al : 3 * copy_min_al + 2) : copy_min);
     bool retile_fit = !nipals && !type2 && A >= 3 && c->opt_work_layout != 0 && ((wide_mode != 0 && K <= 128 * 32) || copy_fit);
     // column groups of the short tiles of a wide matrix (1024 < K <= 4096): 16 columns per lane in 128 / 256 groups
     // (8-row fp32 / 4-row fp64 tiles at K <= 4096) -- the register shape of the headline kernel, two workgroups per CU
@@ -865,7 +918,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             int nss = 0;
             CHK(launch_xb<T>(c, X, ldx, N, K, R, K, A, Tm, ldt, nullptr, &nss));
         }
-        return PLS_HIP_OK;
+        return replica_guard(c, W, P, Q, R, B, K, M, A);
     }
 
     const T *Xc = X;
@@ -1017,7 +1070,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                            K, M, A, B);
         LAUNCH_CHECK(c);
     }
-    return PLS_HIP_OK;
+    return replica_guard(c, W, P, Q, R, B, K, M, A);
 }
 
 int check_handle(pls_hip_handle h) { return h ? PLS_HIP_OK : PLS_HIP_ERR_INVALID; }
@@ -1176,6 +1229,9 @@ int pls_hip_destroy(pls_hip_handle h) {
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (void *q : h->graveyard) (void)hipFree(q);
+    if (h->guard.p) (void)hipFree(h->guard.p);
+    if (h->diverged) (void)hipHostFree(h->diverged);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     h->stager.release();
@@ -1260,7 +1316,7 @@ int pls_hip_synchronize(pls_hip_handle h) {
     CHK(check_handle(h));
     CHK(set_device(h));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PLS_HIP_OK;
+    return check_diverged(h);
 }
 
 const char *pls_hip_last_error(pls_hip_handle h) { return h ? h->err.c_str() : "null handle"; }
@@ -1416,6 +1472,7 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
         if (B) CHK(d2h(h, B, K, dB, K, K, M, 8));
         if (method == PLS_HIP_KERNEL_TYPE1) CHK(d2h(h, T, ldt, dT, dldt, N, A, es));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        CHK(check_diverged(h));
     }
     return PLS_HIP_OK;
 }

@@ -706,4 +706,52 @@ __global__ __launch_bounds__(WG) void coefficients_kernel(const double *__restri
     B[idx] = s;
 }
 
+// ------------------------------------------------------------------------------------
+// Replica guard of a row-sharded fit.  After the reduction every rank runs the same K-sized arithmetic on the same
+// reduced partials, so W, P, Q, R, B must agree bit for bit across the ranks -- PROVIDED the reducer really left
+// identical bits everywhere (ring / tree all-reduces do; a reducer that does not would silently fork the replicas).
+// replica_checksum_kernel: an order-independent 64-bit checksum of the rank's results (sum of mixed bit patterns),
+// cut into four 16-bit pieces p_j; out (RED_SLICES x 8 doubles, slice 0 used) = [p_0..p_3, p_0^2..p_3^2].
+// After the SUM all-reduce of `out` over n ranks, replica_verify_kernel checks n * sum(p_j^2) == (sum p_j)^2 for every
+// piece -- by Cauchy-Schwarz that holds exactly when all ranks sent the same p_j (all values are integers below 2^53
+// for n <= 1024) -- and raises the handle's host-mapped flag otherwise; pls_hip_synchronize reports it.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long guard_mix(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(UPD_THREADS) void replica_checksum_kernel(const double *__restrict__ W, const double *__restrict__ P,
+                                                                       const double *__restrict__ Rm, const double *__restrict__ Q,
+                                                                       const double *__restrict__ B, i64 nKA, i64 nMA, i64 nKM,
+                                                                       double *__restrict__ out) {
+    __shared__ unsigned long long acc;
+    if (threadIdx.x == 0) acc = 0ull;
+    __syncthreads();
+    unsigned long long h = 0ull;
+    const double *arr[5] = {W, P, Rm, Q, B};
+    const i64 len[5] = {nKA, nKA, nKA, nMA, B ? nKM : 0};
+    for (int a = 0; a < 5; ++a)
+        for (i64 i = threadIdx.x; i < len[a]; i += UPD_THREADS)
+            h += guard_mix((unsigned long long)__double_as_longlong(arr[a][i]) + 0x9E3779B97F4A7C15ull * (unsigned long long)(i * 5 + a + 1));
+    atomicAdd(&acc, h);
+    __syncthreads();
+    if (threadIdx.x < RED_SLICES * 8) {
+        double v = 0.0;
+        if (threadIdx.x < 8) {
+            const double p = (double)((acc >> (16 * (threadIdx.x & 3))) & 0xFFFFull);
+            v = threadIdx.x < 4 ? p : p * p;
+        }
+        out[threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(WAVE) void replica_verify_kernel(const double *__restrict__ red, int nranks, int *host_flag) {
+    if (threadIdx.x < 4) {
+        const double s1 = red_sum(red, 8, threadIdx.x), s2 = red_sum(red, 8, 4 + threadIdx.x);
+        if ((double)nranks * s2 != s1 * s1) __hip_atomic_store(host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace plsk

@@ -25,12 +25,13 @@ def row_partition(n_rows: int, world_size: int, rank: int) -> tuple[int, int]:
     return row0, base + (1 if rank < extra else 0)
 
 
-def attach_reducer(handle, K: int, M: int, group=None):
+def attach_reducer(handle, K: int, M: int, group=None, post=None):
     """Give `handle` an all-reduce over torch.distributed's default (or the given) group.
 
     nccl backend: dist.all_reduce on the CUDA staging tensor, enqueued behind the library's
     kernels on the current stream.  gloo backend (CPU rehearsal of N>1, or several ranks sharing
     one GPU in tests): the staging tensor is bounced through host memory.
+    post(view, call_index): testing aid, called on the reduced device view after every collective (fault injection).
     """
     import torch
     import torch.distributed as dist
@@ -49,6 +50,7 @@ def attach_reducer(handle, K: int, M: int, group=None):
             self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
     streams = {}  # hipStream_t -> torch view of it (the library's launch stream, whatever torch's current one is)
+    calls = [0]
 
     def _cb(_user, buf, n, _stream):
         try:
@@ -75,6 +77,9 @@ def attach_reducer(handle, K: int, M: int, group=None):
                     dist.all_reduce(hb, op=dist.ReduceOp.SUM, group=group)
                     view.copy_(hb, non_blocking=False)
                     st.synchronize()
+                if post is not None:
+                    post(view, calls[0])
+                calls[0] += 1
             return 0
         except Exception:  # an exception must not unwind through the C frame
             import traceback

@@ -349,6 +349,12 @@ class Group:
     def set_option(self, opt: int, value: int):
         self._check(self._lib.pls_hip_group_set_option(self.g, opt, int(value)))
 
+    @property
+    def exchange(self) -> str:
+        """'device': the members push their partial sums into each other's inboxes (no host in a collective);
+        'host': the host-synchronised exchange (members sharing a GPU, or a single member)"""
+        return "device" if self._lib.pls_hip_group_exchange(self.g) else "host"
+
     def upload(self, a, dtype=np.float64):
         a = _np_f(a, dtype)
         m = ctypes.c_void_p()

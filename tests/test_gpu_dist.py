@@ -266,3 +266,63 @@ def test_library_rccl_reducer_single_rank():
     p.join(timeout=60)
     assert "error" not in same, same.get("error")
     assert p.exitcode == 0 and all(same.values()), same
+
+
+def _guard_worker(rank, world, port, q, corrupt):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import pls_amd
+    from pls_amd.distributed import attach_reducer, row_partition
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        N, K, M, A = 4096, 96, 2, 6
+        h = pls_amd.Handle()
+        h.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_NIPALS)
+        row0, nrows = row_partition(N, world, rank)
+        X = h.synth_x(row0, nrows, K, pls_amd.SEED_DEFAULT); Y = h.synth_y(row0, nrows, M, pls_amd.SEED_DEFAULT)
+
+        def post(view, call):  # a reducer that leaves DIFFERENT sums on the ranks: rank 1's third collective is off by one ulp-ish
+            if corrupt and rank == 1 and call == 2:
+                view[0] += 1e-9 * (abs(float(view[0])) + 1.0)
+
+        attach_reducer(h, K, M, post=post)
+        h.fit_device(X, Y, A)
+        status = "ok"
+        try:
+            h.synchronize()
+        except pls_amd.PlsHipError as e:
+            status = f"error {e.code}"
+        # the handle stays usable: the next (clean) fit passes the guard again
+        attach_reducer(h, K, M)
+        h.fit_device(X, Y, A); h.synchronize()
+        q.put((rank, {"status": status}))
+        h.close()
+    except BaseException:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt", [False, True], ids=["clean", "one-rank-off"])
+def test_replica_divergence_guard(corrupt):
+    """Every rank of a sharded fit must derive the same bits.  The library checks it itself after the component loop (a
+    checksum of W, P, Q, R, B, compared across the ranks with one 512-byte sum all-reduce) and pls_hip_synchronize reports
+    PLS_HIP_ERR_REDUCER on EVERY rank when a reducer left different sums on one of them."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q, corrupt)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=180)
+    assert not any("error" in r[1] for r in res), [r[1].get("error") for r in res]
+    want = "error 5" if corrupt else "ok"
+    assert [r[1]["status"] for r in res] == [want, want], res

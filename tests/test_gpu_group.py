@@ -171,3 +171,18 @@ def test_upload_xy_streamed_gram(groups, oracle, po, n, N, K, M, A, dt):
             g.free(m)
     finally:
         g.set_option(pls_amd.OPT_ALGO, 0)
+
+
+def test_device_side_exchange_virtual_members():
+    """The device-side exchange (every member pushes its partial sums into its peers' inboxes and spins on sequence flags:
+    no host thread, event or copy per collective) is the default when every member has its own GPU.  Virtual members share
+    one GPU and wait for each other's kernels there, which takes one hardware queue per member: a process of its own with
+    GPU_MAX_HW_QUEUES set (tools/group_exchange_check.py: plans x shapes x 2, 3, 4, 8 members against single-handle fits)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PLS_HIP_GROUP_EXCHANGE="device", GPU_MAX_HW_QUEUES="16")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "group_exchange_check.py"), "2", "3", "4", "8"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "exchange check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
