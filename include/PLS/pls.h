@@ -119,6 +119,16 @@ Colsz optimal_num_components(const Residual &residual, const float_type ALPHA = 
 void print_validation(const Residual &residual, const VALIDATION_OUTPUT out_type,
                       std::ostream &os = std::cerr);
 
+// ---- where Models run (extension; the reference is a CPU library) --------------------------------
+// The GPUs the Models created FROM NOW ON use: {0, 1, 2, 3} = those HIP devices with the rows of every matrix spread
+// over them, an ordinal may repeat (virtual shards on one GPU), {} = back to the environment (PLS_HIP_DEVICES = "4" or
+// "0,2,5"; default PLS_HIP_DEVICE or device 0).  Existing Models keep the context they were built on.  There is no
+// process-wide device state: every host thread gets a context of its own (streams, workspace) on first use, a Model
+// carries the context it was built on, so Models of different threads run at the same time -- as upstream, where a
+// Model shares nothing with another (include/PLS/pls.h:184-266 there).
+struct DeviceContext;
+void set_devices(const std::vector<int> &devices);
+
 // ---- the regression object -----------------------------------------------------------------
 // X: N x K predictors, Y: N x M responses, A components.
 // W (K x A) weights, P (K x A) X-loadings, Q (M x A) Y-loadings, R (K x A) weights that map the
@@ -170,6 +180,7 @@ private:
     // scores of the last fit stay RESIDENT ON THE DEVICE(S) instead (row-sharded over the GPUs PLS_HIP_DEVICES
     // names): no second host copy of X, no N x A read-back per fit; print_state() fetches T when it is asked for.
     struct Resident;
+    std::shared_ptr<DeviceContext> _ctx;      // the devices, streams and workspace this Model runs on
     std::shared_ptr<const Resident> _data;    // X, Y of the constructor
     std::shared_ptr<const Resident> _scores;  // T of the last plsr() (KERNEL_TYPE1 only, as upstream)
     size_t A;

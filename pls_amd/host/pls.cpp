@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <fstream>
 #include <iomanip>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 
@@ -21,14 +23,6 @@
 namespace {
 
 typedef Eigen::Index Index;
-
-// One device context per process, created on first use: a pls_hip_group (include/pls_hip.h) over the GPUs that
-// PLS_HIP_DEVICES names -- "4" = devices 0..3, "0,2,5" = that list (an ordinal may repeat: virtual shards on one
-// GPU); default: the single device PLS_HIP_DEVICE (or 0).  The rows of every matrix are spread over the members,
-// one host thread per member inside the library; the library keeps its workspace in the member handles, so
-// repeated fits reuse the same device buffers.
-std::recursive_mutex g_mu;  // recursive: resident temporaries are released while a caller still holds it
-pls_hip_group g_group = nullptr;
 
 std::vector<int> device_list() {
     std::vector<int> devs;
@@ -55,73 +49,124 @@ std::vector<int> device_list() {
     return devs;
 }
 
-pls_hip_group group() {
-    if (!g_group) {
-        const std::vector<int> devs = device_list();
-        const int rc = pls_hip_group_create(&g_group, static_cast<int>(devs.size()), devs.data());
-        if (rc != PLS_HIP_OK)
-            throw std::runtime_error("PLS: no usable MI355X (gfx950) device (pls_hip_group_create status " +
-                                     std::to_string(rc) + "); this library has no CPU path");
-        // PLS_HIP_ALGO = auto (default) | kernel | nipals | gram.  auto: the Gram plan whenever X^T X came with the
-        // upload (it is accumulated on the matrix cores while the rows cross PCIe) or the cost model favours it, the
-        // reference's own operation sequence (kernel) otherwise; same results to rounding either way.
-        const char *e = std::getenv("PLS_HIP_ALGO");
-        const std::string a(e ? e : "auto");
-        pls_hip_group_set_option(g_group, PLS_HIP_OPT_ALGO,
-                                 a == "nipals" ? PLS_HIP_ALGO_NIPALS
-                                 : a == "gram" ? PLS_HIP_ALGO_GRAM
-                                 : a == "kernel" ? PLS_HIP_ALGO_KERNEL
-                                                 : PLS_HIP_ALGO_AUTO);
+// what PLS::set_devices last asked for (empty: the environment decides); every change starts a new generation of contexts
+std::mutex g_cfg_mu;
+std::vector<int> g_cfg_devs;
+std::atomic<unsigned long> g_cfg_gen{1};
+
+}  // namespace
+
+// A device context: a pls_hip_group (include/pls_hip.h) over the GPUs PLS_HIP_DEVICES names -- "4" = devices 0..3,
+// "0,2,5" = that list (an ordinal may repeat: virtual shards on one GPU); default: the single device PLS_HIP_DEVICE (or 0) --
+// or over the list given to PLS::set_devices.  The rows of every matrix are spread over the members, one host thread per
+// member inside the library; the library keeps its workspace in the member handles, so repeated fits reuse the same device
+// buffers.  The reference has no shared state between Models (include/PLS/pls.h:184-266 upstream): here a Model carries its
+// context, every host thread gets a context of its own on first use, and nothing is process-global -- two threads fit two
+// Models at the same time on their own streams and workspaces.  A context serves one call at a time (`mu`): a Model that is
+// handed to another thread simply queues behind its owner's calls.
+struct PLS::DeviceContext {
+    pls_hip_group g = nullptr;
+    std::mutex mu;
+    pls_hip_handle plain = nullptr;  // folds on gathered data when the group has several members (run_folds)
+    int plain_device = 0;
+    ~DeviceContext() {
+        if (plain) pls_hip_destroy(plain);
+        if (g) pls_hip_group_destroy(g);
     }
-    return g_group;
+};
+
+namespace {
+
+typedef std::shared_ptr<PLS::DeviceContext> Ctx;
+
+Ctx make_context() {
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> lock(g_cfg_mu);
+        devs = g_cfg_devs;
+    }
+    if (devs.empty()) devs = device_list();  // (the environment is read again for every new context)
+    Ctx c = std::make_shared<PLS::DeviceContext>();
+    const int rc = pls_hip_group_create(&c->g, static_cast<int>(devs.size()), devs.data());
+    if (rc != PLS_HIP_OK)
+        throw std::runtime_error("PLS: no usable MI355X (gfx950) device (pls_hip_group_create status " +
+                                 std::to_string(rc) + "); this library has no CPU path");
+    c->plain_device = devs[0];
+    // PLS_HIP_ALGO = auto (default) | kernel | nipals | gram.  auto: the Gram plan whenever X^T X came with the
+    // upload (it is accumulated on the matrix cores while the rows cross PCIe) or the cost model favours it, the
+    // reference's own operation sequence (kernel) otherwise; same results to rounding either way.
+    const char *e = std::getenv("PLS_HIP_ALGO");
+    const std::string a(e ? e : "auto");
+    pls_hip_group_set_option(c->g, PLS_HIP_OPT_ALGO,
+                             a == "nipals" ? PLS_HIP_ALGO_NIPALS
+                             : a == "gram" ? PLS_HIP_ALGO_GRAM
+                             : a == "kernel" ? PLS_HIP_ALGO_KERNEL
+                                             : PLS_HIP_ALGO_AUTO);
+    return c;
 }
 
-pls_hip_handle device() {  // member 0's handle: the K-sized products that need no sharding
+// the calling thread's default context (created on first use, replaced after PLS::set_devices)
+Ctx current_context() {
+    thread_local Ctx mine;
+    thread_local unsigned long mine_gen = 0;
+    const unsigned long gen = g_cfg_gen.load();
+    if (!mine || mine_gen != gen) {
+        mine = make_context();
+        mine_gen = gen;
+    }
+    return mine;
+}
+
+pls_hip_handle device(const Ctx &c) {  // member 0's handle: the K-sized products that need no sharding
     pls_hip_handle h = nullptr;
-    pls_hip_group_handle(group(), 0, &h);
+    pls_hip_group_handle(c->g, 0, &h);
     return h;
 }
 
-void check(int rc, const char *what) {
+void check(const Ctx &c, int rc, const char *what) {
     if (rc != PLS_HIP_OK) {
-        std::string msg = g_group ? pls_hip_group_last_error(g_group) : "";
-        if (msg.empty() && g_group) msg = pls_hip_last_error(device());
+        std::string msg = pls_hip_group_last_error(c->g);
+        if (msg.empty()) msg = pls_hip_last_error(device(c));
         throw std::runtime_error(std::string("PLS: ") + what + " failed: " + msg);
     }
 }
 
-// a host matrix placed on the device(s); freed with the last owner
+// a host matrix placed on the device(s) of a context; freed with the last owner.  Its calls do NOT take the context's
+// lock (the caller holds it); the destructor does -- so a ResidentMatrix must outlive the lock_guard of the scope that
+// fills it (declare it first).
 struct ResidentMatrix {
+    Ctx ctx;
     pls_hip_matrix m = nullptr;
     ResidentMatrix() {}
+    explicit ResidentMatrix(const Ctx &c) : ctx(c) {}
     ResidentMatrix(const ResidentMatrix &) = delete;
     ResidentMatrix &operator=(const ResidentMatrix &) = delete;
     ~ResidentMatrix() {
-        if (m && g_group) {
-            std::lock_guard<std::recursive_mutex> lock(g_mu);
-            pls_hip_group_free(g_group, m);
+        if (m && ctx) {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            pls_hip_group_free(ctx->g, m);
         }
     }
-    void upload(const Mat2D &src) {  // caller holds g_mu
-        check(pls_hip_group_upload(group(), src.data(), src.rows(), src.rows(), src.cols(), PLS_HIP_F64, &m),
+    void upload(const Mat2D &src) {
+        check(ctx, pls_hip_group_upload(ctx->g, src.data(), src.rows(), src.rows(), src.cols(), PLS_HIP_F64, &m),
               "pls_hip_group_upload");
     }
     void alloc(Index rows, Index cols) {
-        check(pls_hip_group_alloc(group(), rows, cols, PLS_HIP_F64, &m), "pls_hip_group_alloc");
+        check(ctx, pls_hip_group_alloc(ctx->g, rows, cols, PLS_HIP_F64, &m), "pls_hip_group_alloc");
     }
     Mat2D download(Index col0, Index ncols) const {
         int64_t N = 0, K = 0;
         pls_hip_matrix_shape(m, &N, &K, nullptr);
         Mat2D out(static_cast<Index>(N), ncols);
-        check(pls_hip_group_download(group(), m, col0, ncols, out.data(), N), "pls_hip_group_download");
+        check(ctx, pls_hip_group_download(ctx->g, m, col0, ncols, out.data(), N), "pls_hip_group_download");
         return out;
     }
 };
 
 // X and Y of one data set: X^T X and X^T Y are formed while X streams in and stay with the pair (pls_hip.h)
 void upload_pair(const Mat2D &X, const Mat2D &Y, ResidentMatrix &dX, ResidentMatrix &dY) {
-    check(pls_hip_group_upload_xy(group(), X.data(), X.rows(), Y.data(), Y.rows(), X.rows(), X.cols(), Y.cols(),
-                                  PLS_HIP_F64, &dX.m, &dY.m),
+    check(dX.ctx, pls_hip_group_upload_xy(dX.ctx->g, X.data(), X.rows(), Y.data(), Y.rows(), X.rows(), X.cols(), Y.cols(),
+                                          PLS_HIP_F64, &dX.m, &dY.m),
           "pls_hip_group_upload_xy");
 }
 
@@ -157,9 +202,21 @@ std::vector<float_type> real_part(const Mat2Dc &m, Index cols) {
 struct PLS::Model::Resident {
     ResidentMatrix X, Y, T;
     Index N = 0, K = 0, M = 0;
+    explicit Resident(const Ctx &c) : X(c), Y(c), T(c) {}
 };
 
 namespace PLS {
+
+// Extension (no upstream counterpart): which GPUs the Models created from now on use -- {0, 1, 2, 3} = those devices, an
+// ordinal may repeat (virtual shards), {} = back to the PLS_HIP_DEVICES / PLS_HIP_DEVICE environment.  Existing Models keep
+// the context they were built on.
+void set_devices(const std::vector<int> &devices) {
+    {
+        std::lock_guard<std::mutex> lock(g_cfg_mu);
+        g_cfg_devs = devices;
+    }
+    ++g_cfg_gen;
+}
 
 // ---------------------------------------------------------------------------------------------
 // text input (ref :23-67)
@@ -380,10 +437,11 @@ Model::Model(const Mat2D &X, const Mat2D &Y, const METHOD &algorithm, const size
     W.setZero(K, static_cast<Index>(A));
     R.setZero(K, static_cast<Index>(A));
     Q.setZero(M, static_cast<Index>(A));
-    std::shared_ptr<Resident> d = std::make_shared<Resident>();
+    _ctx = current_context();
+    std::shared_ptr<Resident> d = std::make_shared<Resident>(_ctx);
     d->N = X.rows(); d->K = K; d->M = M;
     {
-        std::lock_guard<std::recursive_mutex> lock(g_mu);
+        std::lock_guard<std::mutex> lock(_ctx->mu);
         upload_pair(X, Y, d->X, d->Y);
     }
     _data = d;
@@ -399,10 +457,11 @@ Model::Model(const Mat2D &X, const Mat2D &Y, const METHOD &algorithm)
 void Model::plsr(const Mat2D &X, const Mat2D &Y, const METHOD &algorithm) {
     if (X.rows() == 0 || X.rows() != Y.rows() || static_cast<size_t>(X.cols()) < A)
         throw std::invalid_argument("PLS::Model::plsr: need X.rows() > 0, X.rows() == Y.rows(), X.cols() >= A");
-    Resident d;  // data of this call only: the constructor's X, Y stay what the cross-validation methods use (ref :487)
+    if (!_ctx) _ctx = current_context();
+    Resident d(_ctx);  // data of this call only: the constructor's X, Y stay what the cross-validation methods use (ref :487)
     d.N = X.rows(); d.K = X.cols(); d.M = Y.cols();
     {
-        std::lock_guard<std::recursive_mutex> lock(g_mu);
+        std::lock_guard<std::mutex> lock(_ctx->mu);
         upload_pair(X, Y, d.X, d.Y);
     }
     fit_resident(d, algorithm);
@@ -413,15 +472,16 @@ void Model::fit_resident(const Resident &d, const METHOD &algorithm) {
     const Index K = d.K, M = d.M, Ai = static_cast<Index>(A);
     std::vector<float_type> w(static_cast<size_t>(K * Ai)), p(w.size()), r(w.size());
     std::vector<float_type> q(static_cast<size_t>(M * Ai));
+    const Ctx &ctx = d.X.ctx;
     std::shared_ptr<Resident> sc;
     {
-        std::lock_guard<std::recursive_mutex> lock(g_mu);
+        std::lock_guard<std::mutex> lock(ctx->mu);
         if (algorithm == KERNEL_TYPE1) {  // T exists for KERNEL_TYPE1 only (ref :394,434); it stays on the device(s)
-            sc = std::make_shared<Resident>();
+            sc = std::make_shared<Resident>(ctx);
             sc->N = d.N; sc->K = Ai;
             sc->T.alloc(d.N, Ai);
         }
-        check(pls_hip_group_fit(group(), d.X.m, d.Y.m, Ai,
+        check(ctx, pls_hip_group_fit(ctx->g, d.X.m, d.Y.m, Ai,
                                 algorithm == KERNEL_TYPE1 ? PLS_HIP_KERNEL_TYPE1 : PLS_HIP_KERNEL_TYPE2, w.data(), p.data(),
                                 q.data(), r.data(), sc ? sc->T.m : nullptr, nullptr),
               "pls_hip_group_fit");
@@ -440,16 +500,16 @@ namespace {
 
 // X_new (host) * Bm (K x C, host) -> N x C on the host: X_new goes to the device(s) through the staging pipeline,
 // the product runs row-sharded, the result comes back
-Mat2D product_on_device(const Mat2D &X_new, const std::vector<float_type> &bm, Index C) {
+Mat2D product_on_device(const Ctx &ctx, const Mat2D &X_new, const std::vector<float_type> &bm, Index C) {
     const Index N = X_new.rows(), K = X_new.cols();
     Mat2D out(N, C);
     if (N == 0 || C == 0) return out;
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
-    ResidentMatrix X, O;
+    ResidentMatrix X(ctx), O(ctx);  // (released after the lock below)
+    std::lock_guard<std::mutex> lock(ctx->mu);
     X.upload(X_new);
     O.alloc(N, C);
-    check(pls_hip_group_xb(group(), X.m, bm.data(), K, C, O.m), "pls_hip_group_xb");
-    check(pls_hip_group_download(group(), O.m, 0, C, out.data(), N), "pls_hip_group_download");
+    check(ctx, pls_hip_group_xb(ctx->g, X.m, bm.data(), K, C, O.m), "pls_hip_group_xb");
+    check(ctx, pls_hip_group_download(ctx->g, O.m, 0, C, out.data(), N), "pls_hip_group_download");
     return out;
 }
 
@@ -458,7 +518,7 @@ Mat2D product_on_device(const Mat2D &X_new, const std::vector<float_type> &bm, I
 const Mat2Dc Model::scores(const Mat2D &X_new, const size_t comp) const {
     if (comp > A) throw std::invalid_argument("PLS::Model::scores: comp > A");  // assert in the reference (ref :440)
     const Index N = X_new.rows(), c = static_cast<Index>(comp);
-    const Mat2D s = product_on_device(X_new, real_part(R, c), c);
+    const Mat2D s = product_on_device(_ctx ? _ctx : current_context(), X_new, real_part(R, c), c);
     Mat2Dc out(N, c);
     for (Index j = 0; j < c; ++j)
         for (Index i = 0; i < N; ++i) out(i, j) = std::complex<float_type>(s(i, j), 0);
@@ -474,17 +534,18 @@ const Mat2Dc Model::coefficients(const size_t comp) const {
     const std::vector<float_type> r = real_part(R, Ai), q = real_part(Q, Ai);
     std::vector<float_type> b(static_cast<size_t>(K * M));
     {
-        std::lock_guard<std::recursive_mutex> lock(g_mu);
-        if (pls_hip_coefficients(device(), r.data(), q.data(), K, M, Ai, static_cast<Index>(comp), PLS_HIP_MEM_HOST,
+        const Ctx ctx = _ctx ? _ctx : current_context();
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        if (pls_hip_coefficients(device(ctx), r.data(), q.data(), K, M, Ai, static_cast<Index>(comp), PLS_HIP_MEM_HOST,
                                  b.data()) != PLS_HIP_OK)
-            throw std::runtime_error(std::string("PLS: pls_hip_coefficients failed: ") + pls_hip_last_error(device()));
+            throw std::runtime_error(std::string("PLS: pls_hip_coefficients failed: ") + pls_hip_last_error(device(ctx)));
     }
     return to_complex(b, K, M);
 }
 
 const Mat2D Model::fitted_values(const Mat2D &X_new, const size_t comp) const {
     const Mat2Dc Bc = coefficients(comp);
-    return product_on_device(X_new, real_part(Bc, Bc.cols()), Bc.cols());
+    return product_on_device(_ctx ? _ctx : current_context(), X_new, real_part(Bc, Bc.cols()), Bc.cols());
 }
 
 const Mat2D Model::residuals(const Mat2D &X_new, const Mat2D &Y_new, const size_t comp) const {
@@ -533,20 +594,21 @@ std::vector<Mat2D> run_folds(const ResidentMatrix &X, const ResidentMatrix &Y, I
     const Index nobs = static_cast<Index>(num_folds * test_size), Ai = static_cast<Index>(A);
     std::vector<float_type> e(static_cast<size_t>(nobs * Ai * M));
     {
-        std::lock_guard<std::recursive_mutex> lock(g_mu);
-        if (pls_hip_group_size(group()) == 1) {
-            check(pls_hip_group_cv_folds(group(), X.m, Y.m, Ai, test_idx.data(), static_cast<int64_t>(test_size),
-                                         static_cast<int64_t>(num_folds), e.data()),
+        const Ctx &ctx = X.ctx;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        if (pls_hip_group_size(ctx->g) == 1) {
+            check(ctx, pls_hip_group_cv_folds(ctx->g, X.m, Y.m, Ai, test_idx.data(), static_cast<int64_t>(test_size),
+                                              static_cast<int64_t>(num_folds), e.data()),
                   "pls_hip_group_cv_folds");
-        } else {  // several devices: gather the rows once, member 0 runs the folds
+        } else {  // several devices: gather the rows once, member 0's device runs the folds
             const Mat2D Xh = X.download(0, K), Yh = Y.download(0, M);
-            static pls_hip_handle plain = nullptr;  // a member handle carries the group's reducer; folds need none
-            if (!plain && pls_hip_create(&plain, device_list()[0], nullptr) != PLS_HIP_OK)
+            // (a member handle carries the group's reducer; folds need none: a plain handle of the context's own)
+            if (!ctx->plain && pls_hip_create(&ctx->plain, ctx->plain_device, nullptr) != PLS_HIP_OK)
                 throw std::runtime_error("PLS: pls_hip_create failed for the cross-validation handle");
-            if (pls_hip_cv_folds(plain, Xh.data(), N, Yh.data(), N, N, K, M, Ai, test_idx.data(),
+            if (pls_hip_cv_folds(ctx->plain, Xh.data(), N, Yh.data(), N, N, K, M, Ai, test_idx.data(),
                                  static_cast<int64_t>(test_size), static_cast<int64_t>(num_folds), PLS_HIP_F64,
                                  PLS_HIP_MEM_HOST, e.data()) != PLS_HIP_OK)
-                throw std::runtime_error(std::string("PLS: pls_hip_cv_folds failed: ") + pls_hip_last_error(plain));
+                throw std::runtime_error(std::string("PLS: pls_hip_cv_folds failed: ") + pls_hip_last_error(ctx->plain));
         }
     }
     std::vector<Mat2D> Ev(static_cast<size_t>(M), Mat2D::Zero(nobs, Ai));
@@ -611,11 +673,12 @@ void Model::print_explained_variance(const Mat2D &X, const Mat2D &Y, std::ostrea
     const std::vector<float_type> r = real_part(R, Ai), q = real_part(Q, Ai);
     std::vector<float_type> sse(static_cast<size_t>(M * Ai));
     {
-        std::lock_guard<std::recursive_mutex> lock(g_mu);
-        ResidentMatrix dX, dY;
+        const Ctx ctx = _ctx ? _ctx : current_context();
+        ResidentMatrix dX(ctx), dY(ctx);  // (released after the lock)
+        std::lock_guard<std::mutex> lock(ctx->mu);
         dX.upload(X);
         dY.upload(Y);
-        check(pls_hip_group_model_sse(group(), dX.m, dY.m, Ai, r.data(), q.data(), sse.data()), "pls_hip_group_model_sse");
+        check(ctx, pls_hip_group_model_sse(ctx->g, dX.m, dY.m, Ai, r.data(), q.data(), sse.data()), "pls_hip_group_model_sse");
     }
     const Row sst = SST(Y);
     for (size_t nc = 1; nc <= A; ++nc) {
@@ -636,7 +699,7 @@ void Model::print_state(std::ostream &os) const {
     os << "Q:" << std::endl << Q << std::endl;
     Mat2Dc T;  // fetched from the device(s) only here; empty for KERNEL_TYPE2, as upstream (ref :394,434)
     if (_scores) {
-        std::lock_guard<std::recursive_mutex> lock(g_mu);
+        std::lock_guard<std::mutex> lock(_scores->T.ctx->mu);
         const Mat2D t = _scores->T.download(0, static_cast<Index>(A));
         T = Mat2Dc(t.rows(), t.cols());
         for (Index j = 0; j < t.cols(); ++j)

@@ -378,6 +378,49 @@ class Group:
         self._check(self._lib.pls_hip_group_alloc(self.g, N, K, L.F64 if dtype == np.float64 else L.F32, ctypes.byref(m)))
         return m
 
+    def member_handle(self, r: int):
+        h = ctypes.c_void_p()
+        L.check(self._lib.pls_hip_group_handle(self.g, r, ctypes.byref(h)))
+        return h
+
+    def block(self, m, r: int):
+        """(device pointer, ld, row0, nrows) of member r's block of a resident matrix"""
+        ptr, ld, r0, nr = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        L.check(self._lib.pls_hip_matrix_block(m, r, ctypes.byref(ptr), ctypes.byref(ld), ctypes.byref(r0), ctypes.byref(nr)))
+        return ptr, int(ld.value), int(r0.value), int(nr.value)
+
+    def synth(self, N: int, cols: int, seed: int, which: str = "x", dtype=np.float64):
+        """resident N x cols matrix of the synthetic generator (DESIGN.md "Synthetic inputs"), every member generating
+        its own rows on its device -- no host copy (config 5 at its own size: 137 GB)"""
+        m = self.alloc(N, cols, dtype)
+        fn = self._lib.pls_hip_synth_x if which == "x" else self._lib.pls_hip_synth_y
+        for r in range(self.n):
+            h = self.member_handle(r)
+            ptr, ld, r0, nr = self.block(m, r)
+            L.check(fn(h, ptr, ld, r0, nr, cols, seed, L.F64 if dtype == np.float64 else L.F32), h)
+        for r in range(self.n):
+            L.check(self._lib.pls_hip_synchronize(self.member_handle(r)))
+        return m
+
+    def gram(self, Am, Bm):
+        """A^T B (cols x cols, numpy) of two resident matrices with the same row partition: each member's block product
+        on its device (pls_hip_xty), summed on the host.  Size-independent checks on matrices that never leave the GPUs."""
+        ka, kb = self.shape(Am)[1], self.shape(Bm)[1]
+        import torch
+        total = np.zeros((ka, kb))
+        for r in range(self.n):
+            h = self.member_handle(r)
+            pa, lda, _, nr = self.block(Am, r)
+            pb, ldb, _, _ = self.block(Bm, r)
+            if nr == 0:
+                continue
+            out = torch.empty((kb, ka), dtype=torch.float64, device="cuda")  # column-major ka x kb
+            L.check(self._lib.pls_hip_xty(h, pa, lda, pb, ldb, nr, ka, kb, L.F64 if self.shape(Am)[2] == np.float64 else L.F32,
+                                          out.data_ptr()), h)
+            L.check(self._lib.pls_hip_synchronize(h), h)
+            total += out.cpu().numpy().T
+        return total
+
     def shape(self, m):
         n, k, dt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
         L.check(self._lib.pls_hip_matrix_shape(m, ctypes.byref(n), ctypes.byref(k), ctypes.byref(dt)))

@@ -123,3 +123,15 @@ def test_cli_usage_and_ragged_input(tmp_path):
     bad.write_text("1,2,3\n4,5\n")
     r = subprocess.run([CLI, str(bad), str(bad), "1"], capture_output=True, text=True)
     assert r.returncode == 1 and "columns" in r.stderr           # reference src/pls.cpp:54-58
+
+
+def test_concurrent_models_and_set_devices():
+    """Two host threads build, use and cross-validate their own Models at the same time -- bit-identical to the same work
+    done serially (every thread has a device context of its own; nothing is process-global); a Model handed to another
+    thread keeps its context; PLS::set_devices moves NEW Models to three virtual members (tests/cpp/concurrent_models.cpp)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "concurrent_models")
+    env = dict(os.environ)
+    env.pop("PLS_HIP_DEVICES", None)
+    r = subprocess.run([exe, os.path.join(DATA, "nir.csv"), os.path.join(DATA, "octane.csv")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "concurrent ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -222,3 +222,56 @@ def test_config5_one_shard_full_size(handle, oracle, po):
         assert d < 1e-8, (a, d)
     del outs[1]
     torch.cuda.empty_cache()
+
+
+def test_config5_at_its_own_size_on_one_gpu(po):
+    """BASELINE config 5 -- 16,777,216 x 1,024 fp64, m = 4, A = 20, row-sharded over 8 -- at its OWN row count: eight
+    virtual members of 2,097,152 rows each on the one GPU (137.4 GB of X resident in 288 GB of HBM, generated on the device
+    by every member at its own row offset).  The real row count, the real number of collectives, 64-bit offsets end to end;
+    the only thing missing against an 8-GPU node is the xGMI hop.  KERNEL plan (NIPALS would need a second 137 GB).
+    Size-independent checks: the members bit-identical (inside pls_hip_group_fit), P^T R = I, the 20 scores orthogonal
+    over all 16.7 M rows, B equal to the GRAM plan's (an independent route: X^T X on the matrix cores), row blocks of T on
+    three members against the host product of the same generator rows."""
+    import time
+    import pls_amd
+    torch = pytest.importorskip("torch")
+    free, total = torch.cuda.mem_get_info()
+    if free < 170e9:
+        pytest.skip("needs 170 GB of free HBM")
+    N, K, M, A, n = 1 << 24, 1024, 4, 20, 8
+    g = pls_amd.Group([0] * n)
+    try:
+        X = g.synth(N, K, pls_amd.SEED_DEFAULT, "x"); Y = g.synth(N, M, pls_amd.SEED_DEFAULT, "y")
+        assert [b[1] for b in g.blocks(X)] == [N // n] * n
+        g.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_KERNEL)
+        out = g.fit(X, Y, A)                     # warm-up: workspaces
+        g.free(out["T"])
+        t0 = time.perf_counter(); out = g.fit(X, Y, A); dt = time.perf_counter() - t0
+        print(f"config 5 at full size, 8 virtual members on one GPU, KERNEL plan: {dt*1e3:.1f} ms per fit = {A/dt:.1f} components/s "
+              f"({g.exchange} exchange)")
+        W, P, Q, R, B = (out[k] for k in "WPQRB")
+        assert np.isfinite(B).all()
+        assert np.allclose((W ** 2).sum(0), 1.0, atol=1e-12)
+        assert np.allclose(P.T @ R, np.eye(A), atol=1e-8)
+        G = g.gram(out["T"], out["T"])           # T^T T over all the shards
+        assert np.abs(G - np.diag(np.diag(G))).max() < 1e-9 * np.diag(G).max()
+        # scores of three members against the generator's rows on the host (the last 512 rows of each block)
+        class _Raw:  # zero-copy view of device memory the group owns
+            def __init__(self, p, k):
+                self.__cuda_array_interface__ = {"shape": (k,), "typestr": "<f8", "data": (p, False), "version": 2}
+
+        rows = 512
+        for r in (0, 3, 7):
+            ptr, ld, r0, nr = g.block(out["T"], r)
+            Xh = po.synth_x(r0 + nr - rows, rows, K)
+            for c in (0, 7, 19):
+                t = torch.as_tensor(_Raw(ptr.value + 8 * (c * ld + nr - rows), rows), device="cuda").cpu().numpy()
+                assert po.rel_fro(t, Xh @ R[:, c]) < 1e-10, (r, c)
+        g.free(out["T"])
+        # the GRAM plan: X^T X of every shard on the matrix cores, summed over the members, component loop on K x K
+        g.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_GRAM)
+        out2 = g.fit(X, Y, A)
+        assert po.rel_fro(out2["B"], B) < 1e-10
+        g.free(out2["T"])
+    finally:
+        g.close()
