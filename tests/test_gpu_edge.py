@@ -108,8 +108,8 @@ def test_edge_shapes_take_the_one_sweep_plan(handle, oracle, po, plan, monkeypat
         else:
             assert tm["launches"]["deflate"] == 0, tm["launches"]
     elif K <= 4096:
-        # short tiles: KERNEL plan = one copy + A fused passes; NIPALS = fused from the third component on
-        assert tm["launches"]["fused"] == (A - 2 if nipals else A), tm["launches"]
+        # short tiles: one copy into them (in the same sweep as X^T Y) + A fused passes, read-only (KERNEL) or in place (NIPALS)
+        assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
     else:
         assert (tm["launches"]["deflate"] == A - 1) if nipals else True, tm["launches"]
 
