@@ -60,10 +60,12 @@ def parse():
     ap.add_argument("--fuse", type=int, default=1)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (gloo: rehearsal with ranks sharing one GPU)")
-    ap.add_argument("--reducer", default=None, choices=["torch", "rccl"],
-                    help="N > 1: rccl (default with --backend nccl) = the library's own RCCL communicator, ncclAllReduce "
-                         "issued on the launch stream with no Python in the component loop (include/pls_hip_rccl.h); "
-                         "torch (default with --backend gloo) = torch.distributed all_reduce from a ctypes callback")
+    ap.add_argument("--reducer", default=None, choices=["torch", "rccl", "ipc"],
+                    help="N > 1: ipc (default with --backend nccl) = the library's device-side exchange, every rank writing "
+                         "its partial sums straight into the other ranks' inboxes over xGMI (pls_hip_xchg_*, no RCCL in the "
+                         "component loop); falls back -- on every rank together -- to rccl = the library's own RCCL "
+                         "communicator, ncclAllReduce issued on the launch stream (include/pls_hip_rccl.h), and from there "
+                         "to torch (default with --backend gloo) = torch.distributed all_reduce from a ctypes callback")
     ap.add_argument("--no-alt", action="store_true", help="skip the alternative execution plans")
     ap.add_argument("--defer", type=int, default=1, choices=[1, 2, 3, 4],
                     help="NIPALS plan: write the deflated matrix back every D-th component only (default 1 = explicit "
@@ -190,7 +192,7 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a)
     if a.reducer is None:
-        a.reducer = "rccl" if a.backend == "nccl" else "torch"
+        a.reducer = "ipc" if a.backend == "nccl" else "torch"
     import torch
     import torch.distributed as dist
 
@@ -222,7 +224,17 @@ def main():
         Yt = pls_amd.colmajor_empty(nrows, M, tdt, Y.device, ld=nrows); Yt.copy_(Y); Y = Yt
     reducer_used = None
     if world > 1:
-        reducer_used = a.reducer if a.backend == "nccl" else "torch"
+        reducer_used = a.reducer
+        notes = []
+        if reducer_used == "ipc":
+            # the device-side exchange sets itself up collectively (self-test included) and raises on EVERY rank if any
+            # rank cannot do it: then all of them move on to RCCL -- a scaling run must not die here
+            from pls_amd.distributed import attach_ipc_exchange
+            try:
+                attach_ipc_exchange(h)
+            except Exception as e:  # noqa: BLE001
+                notes.append("device-side exchange unavailable: " + repr(e))
+                reducer_used = "rccl" if a.backend == "nccl" else "torch"
         if reducer_used == "rccl":
             # the library's own communicator; if it cannot be set up on EVERY rank (the ranks agree on that through
             # torch.distributed), all of them fall back to the torch reducer -- a scaling run must not die here
@@ -241,8 +253,10 @@ def main():
                     detach_rccl_reducer(h)
                 attach_reducer(h, K, M)
                 reducer_used = "torch (library RCCL communicator unavailable" + (": " + why if why else " on another rank") + ")"
-        else:
+        elif reducer_used == "torch":
             attach_reducer(h, K, M)
+        if notes:
+            reducer_used += " (" + "; ".join(notes) + ")"
     algo = {"nipals": pls_amd.ALGO_NIPALS, "kernel": pls_amd.ALGO_KERNEL, "gram": pls_amd.ALGO_GRAM}[a.algo]
     h.set_option(pls_amd.OPT_ALGO, algo)
     h.set_option(pls_amd.OPT_FUSE, a.fuse)
@@ -268,6 +282,7 @@ def main():
         h.set_option(pls_amd.OPT_PROFILE, 1)
         _, tm = timed_fits(h, torch, dist, world, X, Y, A, min(a.steps, 3), 1, out)
         roofline_where = "separate profiled steps after the timed region (N > 1)"
+    h.synchronize()  # (raises if the ranks of a sharded fit diverged or the exchange timed out: include/pls_hip.h)
     value = A * a.steps / el
     es = 8 if dt == "f64" else 4
     line = {

@@ -245,6 +245,29 @@ PLS_HIP_API int pls_hip_synth_x(pls_hip_handle h, void *X, int64_t ldx, int64_t 
 PLS_HIP_API int pls_hip_synth_y(pls_hip_handle h, void *Y, int64_t ldy, int64_t row0, int64_t nrows,
                     int64_t M, uint64_t seed, int dtype);
 
+/* ---- one process per GPU without RCCL: the device-side exchange across processes ---------------------------------
+ *
+ * The reducer of a row-sharded fit (pls_hip_set_reducer) as a direct exchange between the ranks' GPUs: every rank owns an
+ * inbox in fine-grained device memory, exported with hipIpcGetMemHandle; a collective is two small launches per rank --
+ * the rank WRITES its partial sums into every peer's inbox over xGMI and raises a sequence flag there, then spins on its
+ * own flags and adds the inboxes in rank order (exchange_kernels.hpp; the same kernels the in-process group uses).  These
+ * messages are a few KB and latency-bound, which is what this form is for; RCCL (include/pls_hip_rccl.h) or any other
+ * pls_hip_allreduce_fn remain alternatives.  Set-up, on every rank:
+ *     pls_hip_xchg_create(h, rank, nranks, mine)         -> `mine`: PLS_HIP_XCHG_HANDLE_BYTES to publish
+ *     (all-gather the blobs in rank order with whatever the application has: MPI, torch.distributed, a file)
+ *     pls_hip_xchg_connect(h, all)                        opens the peers' inboxes, installs the reducer
+ *     pls_hip_xchg_selftest(h)                            COLLECTIVE: one round on known values with a 5 s limit;
+ *                                                         PLS_HIP_ERR_REDUCER if this system cannot do it -- then every
+ *                                                         rank should pls_hip_xchg_destroy and take another reducer
+ * A rank that waits longer than 30 s (PLS_HIP_XCHG_TIMEOUT_S) for a peer -- a rank failed or fell out of step -- gives up:
+ * pls_hip_synchronize returns PLS_HIP_ERR_REDUCER from then on.  2 <= nranks <= 16.
+ */
+#define PLS_HIP_XCHG_HANDLE_BYTES 160
+PLS_HIP_API int pls_hip_xchg_create(pls_hip_handle h, int rank, int nranks, void *mine);
+PLS_HIP_API int pls_hip_xchg_connect(pls_hip_handle h, const void *all);
+PLS_HIP_API int pls_hip_xchg_selftest(pls_hip_handle h);
+PLS_HIP_API int pls_hip_xchg_destroy(pls_hip_handle h);
+
 /* ---- one process, several GPUs: a group of handles behind one call ------------------
  *
  * The reference's Model is one object driven by one host thread (include/PLS/pls.h:187-199, src/pls.cpp:340-353).

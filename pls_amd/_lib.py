@@ -20,6 +20,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 ALGO_KERNEL, ALGO_NIPALS, ALGO_GRAM, ALGO_AUTO = 0, 1, 2, 3
 OPT_ALGO, OPT_FUSE, OPT_PROFILE, OPT_POWER_ITERS, OPT_FUSED_GRID, OPT_WORK_LAYOUT, OPT_DEFER, OPT_GRAPH = 1, 2, 3, 4, 5, 6, 7, 8
 REDUCE_SLICES = 8
+XCHG_HANDLE_BYTES = 160  # PLS_HIP_XCHG_HANDLE_BYTES
 FAM_XTY, FAM_XB, FAM_DEFLATE, FAM_FUSED, FAM_SMALL, FAM_COUNT = 0, 1, 2, 3, 4, 5
 FAM_NAMES = ("xty", "xb", "deflate", "fused", "small")
 
@@ -74,6 +75,10 @@ PROTOTYPES = [
     # one process, several GPUs: groups and resident matrices
     ("pls_hip_group_create", _int, [ctypes.POINTER(_vp), _int, ctypes.POINTER(_int)]),
     ("pls_hip_group_destroy", _int, [_vp]),
+    ("pls_hip_xchg_create", _int, [_vp, _int, _int, _vp]),
+    ("pls_hip_xchg_connect", _int, [_vp, _vp]),
+    ("pls_hip_xchg_selftest", _int, [_vp]),
+    ("pls_hip_xchg_destroy", _int, [_vp]),
     ("pls_hip_group_size", _int, [_vp]),
     ("pls_hip_group_exchange", _int, [_vp]),
     ("pls_hip_group_handle", _int, [_vp, _int, ctypes.POINTER(_vp)]),
@@ -123,6 +128,11 @@ def lib() -> ctypes.CDLL:
         raise ImportError("libpls_hip.so ABI version mismatch")
     _LIB = L
     return L
+
+
+def last_error(handle) -> str:
+    raw = lib().pls_hip_last_error(handle)
+    return raw.decode("utf-8", "replace") if raw else ""
 
 
 def check(rc: int, handle=None) -> None:

@@ -9,7 +9,13 @@
 
 namespace {
 
-constexpr int GROUP_MAX = 16;
+constexpr int GROUP_MAX = plsk::XCHG_MAX;
+using plsk::XCHG_CAP;
+using plsk::XCHG_THREADS;
+using plsk::XCHG_TIMEOUT_S;
+using plsk::XchgPeers;
+using plsk::xchg_gather_kernel;
+using plsk::xchg_push_kernel;
 
 struct PeerPtrs {
     const double *p[GROUP_MAX];
@@ -21,69 +27,6 @@ __global__ __launch_bounds__(256) void peer_sum_kernel(PeerPtrs src, int n, i64 
         double s = src.p[0][i];
         for (int j = 1; j < n; ++j) s += src.p[j][i];
         out[i] = s;
-    }
-}
-
-// ---- device-side exchange (the default for messages up to XCHG_CAP doubles) -----------------------------------------
-// Every member owns an INBOX on its device: [2 parities][n members][XCHG_CAP] doubles + [2][n] sequence flags, in
-// fine-grained memory (remote writes become visible to a kernel that is already running).  All-reduce number q of a
-// member (every member issues the same sequence of collectives):
-//   push   (one workgroup per destination):  the member's 8 reduction slices summed to ONE vector, written into slot
-//          [q & 1][rank] of every member's inbox over xGMI, then -- system-scope release -- flag[q & 1][rank] = q;
-//   gather (same stream, right behind):  spins (system-scope acquire) until its own n flags show q, sums the n slots in
-//          rank order into slice 0 of the member's buffer and clears slices 1..7 (the consumers add the 8 slices).
-// No host thread, no event, no copy takes part: two small kernels per member and collective.  Two parities suffice: a
-// member can only reach collective q + 2 after it has gathered q + 1, i.e. after every peer has PUSHED q + 1, which
-// each peer does behind its own gather of q.  A wait that lasts longer than XCHG_TIMEOUT_S (a member that failed or
-// fell out of step) sets the member's status word and leaves the loop -- the fit then reports PLS_HIP_ERR_REDUCER.
-constexpr i64 XCHG_CAP = 1 << 16;        // doubles per message (512 KB); larger messages take the host-synchronised path
-constexpr int XCHG_THREADS = 1024;
-constexpr double XCHG_TIMEOUT_S = 30.0;  // (a peer's first fit may still be loading code objects or allocating; PLS_HIP_XCHG_TIMEOUT_S)
-
-struct XchgPeers {
-    double *slot[GROUP_MAX];                 // inbox slot [parity][my rank] of every member
-    unsigned long long *flag[GROUP_MAX];     // its flag
-};
-
-__global__ __launch_bounds__(XCHG_THREADS) void xchg_push_kernel(XchgPeers peers, const double *__restrict__ buf, int L,
-                                                                 int slices, unsigned long long seq) {
-    double *dst = peers.slot[blockIdx.x];
-    for (int j = threadIdx.x; j < L; j += XCHG_THREADS) {
-        double sum = buf[j];
-        for (int sl = 1; sl < slices; ++sl) sum += buf[(i64)sl * L + j];
-        __hip_atomic_store(dst + j, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(peers.flag[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__global__ __launch_bounds__(256) void xchg_gather_kernel(const double *inbox, const unsigned long long *flags, int n, i64 cap,
-                                                          int L, int slices, unsigned long long seq, double *__restrict__ buf,
-                                                          int *status, int *host_status, long long limit) {
-    __shared__ int ok;
-    if (threadIdx.x == 0) ok = (*status == 0);  // an earlier wait of this fit timed out: do not wait again
-    __syncthreads();
-    if ((int)threadIdx.x < n && ok) {
-        const long long t0 = wall_clock64();  // limit: ticks of the device's wall clock (hipDeviceAttributeWallClockRate)
-        while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-            if (wall_clock64() - t0 > limit) {
-                ok = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
-    if (!ok && threadIdx.x == 0) {
-        *status = 1;
-        __hip_atomic_store(host_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-mapped: read without a copy)
-    }
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < L; j += gridDim.x * 256) {
-        double sum = ok ? __hip_atomic_load(inbox + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __builtin_nan("");
-        for (int m = 1; m < n && ok; ++m) sum += __hip_atomic_load(inbox + (i64)m * cap + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        buf[j] = sum;
-        for (int sl = 1; sl < slices; ++sl) buf[(i64)sl * L + j] = 0.0;
     }
 }
 
@@ -194,19 +137,8 @@ int gfail(pls_hip_group_s *g, int code, const std::string &msg) {
 
 // the two launches of one device-side collective of member r (its device current); buf: `slices` x L doubles
 int xchg_launch(pls_hip_group_s *g, int r, double *buf, int L, int slices, hipStream_t stream, long long limit) {
-    const int n = g->n;
-    const unsigned long long seq = ++g->xseq[r];
-    const int par = (int)(seq & 1);
-    XchgPeers peers;
-    for (int j = 0; j < n; ++j) {
-        peers.slot[j] = g->inbox[j] + ((i64)par * n + r) * XCHG_CAP;
-        peers.flag[j] = g->xflags[j] + par * n + r;
-    }
-    hipLaunchKernelGGL(xchg_push_kernel, dim3(n), dim3(XCHG_THREADS), 0, stream, peers, (const double *)buf, L, slices, seq);
-    hipLaunchKernelGGL(xchg_gather_kernel, dim3((unsigned)std::min<i64>(16, (L + 255) / 256)), dim3(256), 0, stream,
-                       (const double *)(g->inbox[r] + (i64)par * n * XCHG_CAP), (const unsigned long long *)(g->xflags[r] + par * n),
-                       n, XCHG_CAP, L, slices, seq, buf, g->xstatus[r], g->xhost_dev + r, limit);
-    return hipGetLastError() == hipSuccess ? 0 : 13;
+    return plsk::xchg_launch_piece(stream, g->n, r, g->inbox.data(), g->xflags.data(), buf, L, 0, L, slices, ++g->xseq[r],
+                                   g->xstatus[r], g->xhost_dev + r, limit);
 }
 
 // drain every member's stream and start the sequence numbers over (after a time-out or a failed member)
@@ -468,11 +400,7 @@ int pls_hip_group_create(pls_hip_group *out, int n, const int *devices) {
                 g->xchg = false;  // (no fine-grained memory: the host-synchronised exchange)
             } else {
                 g->xstatus[r] = reinterpret_cast<int *>(g->xflags[r] + 2 * n);
-                int khz = 0;
-                if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, devices[r]) != hipSuccess || khz <= 0) khz = 100000;
-                const char *te = getenv("PLS_HIP_XCHG_TIMEOUT_S");
-                const double secs = (te && atof(te) > 0) ? atof(te) : XCHG_TIMEOUT_S;
-                g->xlimit[r] = (long long)(secs * 1e3 * khz);
+                g->xlimit[r] = plsk::xchg_time_limit(devices[r]);
                 if (hipMemset(g->xflags[r], 0, fb + 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = PLS_HIP_ERR_DEVICE;
             }
         }

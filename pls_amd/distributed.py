@@ -154,3 +154,41 @@ def detach_rccl_reducer(handle):
     lib, comm = handle._rccl
     L.check(lib.pls_hip_rccl_detach(handle.h, comm), handle.h)
     handle._rccl = None
+
+
+def attach_ipc_exchange(handle, group=None):
+    """The library's own device-side exchange between the ranks' GPUs (include/pls_hip.h, pls_hip_xchg_*): every rank
+    writes its partial sums straight into the other ranks' inboxes (opened over IPC) and spins on sequence flags -- two
+    small launches per rank and collective, no RCCL, nothing on the host.  torch.distributed is used three times, at
+    set-up: to all-gather the 160-byte IPC handles and to let the ranks agree that every step worked.  Ends with a
+    collective self-test; raises on EVERY rank (after releasing the exchange) if any rank could not set it up, so that
+    the caller can fall back to attach_rccl_reducer / attach_reducer on all of them."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lib = handle._lib
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+    def agree(ok: bool, what: str, why: str = ""):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            lib.pls_hip_xchg_destroy(handle.h)
+            raise RuntimeError(f"device-side exchange unavailable ({what}" + (f": {why}" if why else " on another rank") + ")")
+
+    mine = ctypes.create_string_buffer(L.XCHG_HANDLE_BYTES)
+    rc = lib.pls_hip_xchg_create(handle.h, rank, world, mine)
+    agree(rc == L.OK, "create", "" if rc == L.OK else L.last_error(handle.h))
+    blobs = [None] * world
+    dist.all_gather_object(blobs, bytes(mine.raw), group=group)
+    allb = ctypes.create_string_buffer(b"".join(blobs), L.XCHG_HANDLE_BYTES * world)
+    rc = lib.pls_hip_xchg_connect(handle.h, allb)
+    agree(rc == L.OK, "connect", "" if rc == L.OK else L.last_error(handle.h))
+    rc = lib.pls_hip_xchg_selftest(handle.h)
+    agree(rc == L.OK, "self-test", "" if rc == L.OK else L.last_error(handle.h))
+
+
+def detach_ipc_exchange(handle):
+    L.check(handle._lib.pls_hip_xchg_destroy(handle.h), handle.h)

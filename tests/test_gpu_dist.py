@@ -29,7 +29,7 @@ def _split(N, world, rank, splits):
     return sum(splits[:rank]), splits[rank]
 
 
-def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0, splits=None):
+def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0, splits=None, reducer="torch"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import torch
@@ -45,8 +45,14 @@ def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0, splits=None)
         row0, nrows = _split(N, world, rank, splits)
         X = h.synth_x(row0, nrows, K, pls_amd.SEED_DEFAULT)
         Y = h.synth_y(row0, nrows, M, pls_amd.SEED_DEFAULT)
-        attach_reducer(h, K, M)
+        if reducer == "ipc":   # the library's device-side exchange between processes (gloo only carries the set-up)
+            from pls_amd.distributed import attach_ipc_exchange
+            attach_ipc_exchange(h)
+        else:
+            attach_reducer(h, K, M)
         out = h.fit_device(X, Y, A, method=method)
+        h.synchronize()
+        out = h.fit_device(X, Y, A, method=method, out=out)   # (a second fit: sequence numbers carried on)
         h.synchronize()
         res = {k: v.cpu().numpy() for k, v in out.items() if v is not None}   # T is None for KERNEL_TYPE2
         # sharded pre-processing and metrics use the same reducer (column statistics over all rows)
@@ -63,13 +69,13 @@ def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0, splits=None)
         dist.destroy_process_group()
 
 
-def _run(world, N, K, M, A, algo, fuse, method=0, splits=None, timeout=180):
+def _run(world, N, K, M, A, algo, fuse, method=0, splits=None, timeout=180, reducer="torch"):
     """spawn `world` ranks sharing the GPU; returns [(rank, outputs)] sorted by rank"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, K, M, A, algo, fuse, q, method, splits))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, K, M, A, algo, fuse, q, method, splits, reducer))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -326,3 +332,26 @@ def test_replica_divergence_guard(corrupt):
     assert not any("error" in r[1] for r in res), [r[1].get("error") for r in res]
     want = "error 5" if corrupt else "ok"
     assert [r[1]["status"] for r in res] == [want, want], res
+
+
+@pytest.mark.parametrize("world,splits,algo,method", [(2, None, 1, 0), (3, [2048, 0, 2048], 0, 0), (3, [1365, 1366, 1365], 1, 0),
+                                                      (2, None, 0, 1)],
+                         ids=["2ranks-nipals", "3ranks-empty-shard-kernel", "3ranks-odd-shards-nipals", "2ranks-type2"])
+def test_sharded_fit_over_the_ipc_exchange(world, splits, algo, method):
+    """One process per rank, the ranks' partial sums exchanged by the library itself: every rank writes into the other
+    ranks' inboxes (hipIpcOpenMemHandle) and spins on sequence flags -- no RCCL, no torch in a collective.  Config 5's own
+    K = 1,024, m = 4, A = 20 on the 4,096-row twin; KERNEL_TYPE2 sends its 8 x K x K partial of X^T X in 512 KB pieces.
+    Bit-identical ranks, B against the committed fixture."""
+    from conftest import GOLDEN
+    from oracle import pls_oracle as po
+    g = np.load(os.path.join(GOLDEN, "c5twin_4096x1024_m4_A20.npz"))
+    N, K, M, A = (int(g[k]) for k in ("N", "K", "M", "A"))
+    res = _run(world, N, K, M, A, algo, 1, method=method, splits=splits, reducer="ipc")
+    for rank, out in res:
+        assert po.rel_fro(out["B"], g["B"]) < 1e-10, rank
+        for k in "WPQRB":
+            assert np.array_equal(out[k], res[0][1][k]), (rank, k)
+    if method == 0:
+        T = np.concatenate([out["T"] for _, out in res], axis=0)
+        G = T.T @ T
+        assert np.abs(G - np.diag(np.diag(G))).max() < 1e-9 * np.diag(G).max()
