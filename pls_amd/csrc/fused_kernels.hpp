@@ -190,6 +190,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
         dtile = (R / rdst) * tsd;
     }
     constexpr uint32_t OOR = 0x80000000u;  // beyond every num_records the launcher allows
+    constexpr bool TBUF = DEFL && sizeof(T) == 8 && R == 32 && CPT == 16;
     const __amdgpu_buffer_rsrc_t rs_tin = score_rsrc<T>(DEFL ? tprev : tout, NV);
 
     // EDGE = 2: XCD-contiguous tiles (grids that are a multiple of 8; cyclic otherwise).  The other instantiations fold
@@ -216,7 +217,19 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
         if (DEFL) {
             double tp[V];
             {
-                const Pack<T, V> tpk = buf_ld<T, V>(rs_tin, rowok ? (uint32_t)(i0 * (i64)sizeof(T)) : OOR);
+                // t_prev of the lane's rows; behind row NV (padded sweeps) zeros.  Two forms, chosen per instantiation by
+                // measurement (same box, A/B): through a range-checked buffer descriptor -- the headline shape: 701 vs 693
+                // components/s at config 3 -- or as a plain 16-byte load with an element-wise branch for the one straddling
+                // pack -- every other shape: +0.3 ... +0.7 % (config 4, the shards of configs 3 and 5).
+                Pack<T, V> tpk;
+                if constexpr (TBUF) {
+                    tpk = buf_ld<T, V>(rs_tin, rowok ? (uint32_t)(i0 * (i64)sizeof(T)) : OOR);
+                } else if (i0 + V <= NV) {
+                    tpk = ld_pack_u<T, V>(tprev + i0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) tpk.v[e] = (i0 + e < NV) ? tprev[i0 + e] : (T)0;
+                }
 #pragma unroll
                 for (int e = 0; e < V; ++e) tp[e] = -(double)tpk.v[e];
             }

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collects the measurement evidence of a round on the GPU box into gpurun_out/evidence/ (copy what is to be judged
 # into profiles/rNN/ afterwards).  rocprofv3: the program goes directly after `--`; counters in their own passes.
-# usage: bash tools/collect_evidence.sh [part ...]   parts: c3 deflate c4 c5 eighth host roctx small   (default: all)
+# usage: bash tools/collect_evidence.sh [part ...]   parts: c3 deflate c4 c5 eighth edge group host roctx small fuzz   (default: all but fuzz)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 E=gpurun_out/evidence; mkdir -p $E
-PARTS="${*:-c3 deflate c4 c5 eighth host roctx small}"
+PARTS="${*:-c3 deflate c4 c5 eighth edge group host roctx small}"
 stats() {  # name, command...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $E/tmp_$name -o p -- "$@" > $E/${name}_bench_under_rocprof.json 2> $E/tmp_$name.err
@@ -46,6 +46,45 @@ c5)
 eighth)
   python3 bench.py --workload C3eighth --steps 20 --warmup 5 --no-cpu --no-alt > $E/bench_C3eighth.json 2> /dev/null
   stats c3eighth python3 bench.py --workload C3eighth --steps 10 --warmup 3 --no-alt --no-cpu ;;
+edge)
+  # the shapes that used to fall off the one-sweep kernels, next to their aligned twins (round 3)
+  for wl in C3 C3odd- C3odd+ tall64 tall64a C4 C4odd; do for algo in nipals kernel; do
+    python3 bench.py --workload $wl --algo $algo --steps 10 --warmup 3 --no-cpu --no-alt > $E/edge_bench_${wl}_${algo}.json 2> /dev/null
+  done; done
+  python3 - <<'PY'
+import glob, json, os
+E = "gpurun_out/evidence"
+rows = []
+for f in sorted(glob.glob(E + "/edge_bench_*.json")):
+    try:
+        d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+    except Exception:
+        continue
+    r = d["roofline"]
+    rows.append((os.path.basename(f)[11:-5], d["value"], d["ms_per_step"], r["kernel"], r["avg_launch_ms"], r["frac"], r["families_ms_per_fit"]))
+with open(E + "/edge_shapes_summary.txt", "w") as out:
+    out.write("workload_plan  components/s  ms/fit  dominant family: avg launch ms, fraction of 8 TB/s; family ms per fit\n")
+    for r in rows:
+        out.write("%-18s %9.1f %9.3f  %s %.4f ms %.4f  %s\n" % r)
+PY
+  stats c3odd_kernel python3 bench.py --workload C3odd- --algo kernel --steps 3 --warmup 1 --no-alt --no-cpu
+  pmc C3odd_kernel python3 bench.py --workload C3odd- --algo kernel --steps 2 --warmup 1 --no-alt --no-cpu
+  stats c3odd_nipals python3 bench.py --workload C3odd- --steps 3 --warmup 1 --no-alt --no-cpu
+  ./pls_amd/csrc/tune/unaligned_probe > $E/unaligned_probe.txt 2>&1 ;;
+group)
+  # the two in-process exchanges with virtual members (one hardware queue per member), the cross-process exchange with
+  # ranks sharing the GPU, config 5 at its own size
+  export GPU_MAX_HW_QUEUES=16
+  for mode in host device; do
+    PLS_HIP_GROUP_EXCHANGE=$mode python3 tools/group_overhead.py 131072 512 20 2> /dev/null | grep members > $E/group_overhead_eighth_$mode.txt
+    PLS_HIP_GROUP_EXCHANGE=$mode python3 tools/group_overhead.py 2> /dev/null | grep members > $E/group_overhead_C3_$mode.txt
+  done
+  unset GPU_MAX_HW_QUEUES
+  bash tools/r3_ipc_bench.sh > $E/ipc_exchange_shared_gpu.txt 2>&1
+  cp gpurun_out/r3/ipc_bench_*.json $E/ 2> /dev/null
+  python3 -m pytest tests/test_gpu_configs.py -q -m gpu -k own_size -s 2>&1 | grep -E "config 5|passed|failed" > $E/config5_full_size_one_gpu.txt ;;
+fuzz)
+  python3 tools/fuzz_parity.py 1500 3 > $E/fuzz_parity.txt 2>&1 ;;
 host)
   ./tools/host_entry_time 1048576 512 1 20 5 > $E/host_entry_time_C3.txt 2>&1
   PLS_HIP_ALGO=kernel ./tools/host_entry_time 1048576 512 1 20 3 > $E/host_entry_time_C3_kernel_plan.txt 2>&1
