@@ -224,11 +224,11 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
                 Pack<T, V> tpk;
                 if constexpr (TBUF) {
                     tpk = buf_ld<T, V>(rs_tin, rowok ? (uint32_t)(i0 * (i64)sizeof(T)) : OOR);
-                } else if (i0 + V <= NV) {
+                } else if (rowok && i0 + V <= NV) {
                     tpk = ld_pack_u<T, V>(tprev + i0);
-                } else {
+                } else {  // (rows the sweep does not cover must contribute nothing: the tail kernel owns row NV - 1 of an odd matrix)
 #pragma unroll
-                    for (int e = 0; e < V; ++e) tpk.v[e] = (i0 + e < NV) ? tprev[i0 + e] : (T)0;
+                    for (int e = 0; e < V; ++e) tpk.v[e] = (rowok && i0 + e < NV) ? tprev[i0 + e] : (T)0;
                 }
 #pragma unroll
                 for (int e = 0; e < V; ++e) tp[e] = -(double)tpk.v[e];
@@ -635,12 +635,13 @@ inline int edge_level(const void *q, i64 ld, int cg_all, int cg_wave) {
     return cols_aligned<T>(q, ld) ? 1 : 2;
 }
 
-// rc as launch_fused_pass; *nb = partial rows written (<= max_rows).  M <= 8.
-template <typename T>
+// rc as launch_fused_pass; *nb = partial rows written (<= max_rows).  M <= 8.  CGX: column groups of the SOURCE tile (32:
+// 256-byte segments; 8 / 16: the taller tiles of narrow matrices, whose copy uses the same tile height).
+template <typename T, int CGX = 32>
 int launch_retile_xty(hipStream_t stream, int num_cu, const T *src, i64 lds_, const T *Y, i64 ldy, T *dst, i64 ldd, i64 tsd,
                       int rdst, i64 N, int K, int M, double *part, int max_rows, int *nb) {
     constexpr int V = 16 / sizeof(T);
-    constexpr int R = 256 / sizeof(T), NT = 512;
+    constexpr int R = (512 / CGX) * V, NT = 512;
     constexpr int CG = NT / (R / V);
     if (!cols_aligned<T>(dst, ldd) || tsd % V != 0 || rdst < V || R % rdst != 0 || N < 1 || M < 1 || M > 8 || max_rows < 2 ||
         !elem_aligned<T>(Y))
@@ -902,11 +903,20 @@ constexpr int tile_rows() { return (512 / CGX) * (16 / (int)sizeof(T)); }
 // per fit: the work buffer's layout depends on it.)  0 = no; 1 = yes; 2 = yes through an EDGE instantiation (columns
 // that are not 16-byte aligned, or a leading dimension whose 32 column groups do not fit one descriptor -- up to
 // 2^31 bytes per WAVE / RP = 4 columns there).  Any N >= 1: the last N % V rows are the tail kernel's.
+// Column groups of the tile that reads the caller's matrix.  32 (16 row lanes, 256-byte segments) from 257 columns on;
+// NARROW matrices take taller tiles with fewer column groups, so that a lane still has 8-16 loads in flight: 8 groups x 64
+// row lanes (128 fp64 rows, 1 KB segments) up to 128 columns, 16 x 32 up to 256.  With the 32-group tile a 64-column matrix
+// has 2 loads per lane and streams at 0.64-0.68 of peak (config-3-sized: 581 / 1,097 components/s), a 32-column one at 0.38-0.46.
+inline int tall_groups(int K) {
+    static const bool on = !(getenv("PLS_HIP_TALL_TILES") && atoi(getenv("PLS_HIP_TALL_TILES")) == 0);  // A/B measurements only
+    return !on ? 32 : (K <= 128 ? 8 : (K <= 256 ? 16 : 32));
+}
+
 template <typename T>
 int fused_pass_mode(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
-    constexpr int CG = 32;
-    if (K > CG * 32 || N < 1 || !elem_aligned<T>(Tm) || (N + 16) * (i64)sizeof(T) >= (1ll << 31)) return 0;
-    const int e = edge_level<T>(X, ldx, CG, 4);
+    const int CG = tall_groups(K);
+    if (K > 32 * 32 || N < 1 || !elem_aligned<T>(Tm) || (N + 16) * (i64)sizeof(T) >= (1ll << 31)) return 0;
+    const int e = edge_level<T>(X, ldx, CG, CG / 8);  // (a wave holds 64 / (512 / CG) = CG / 8 column groups)
     return e < 0 ? 0 : (e == 0 ? 1 : 2);
 }
 template <typename T>
@@ -934,13 +944,13 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     // 2^31: all CG groups of the workgroup, or -- EDGE -- the WAVE / RP groups of one wave
     int edge = edge_level<T>(X, ldx, CG, WAVE / (R / V));
     if (edge < 0 || (edge == 0 && tsx % V != 0) || (defl && tsd % V != 0)) return 1;
-    if (K > CG * (CGX == 256 ? 16 : 32) || N < 1 || max_rows < 2) return 1;
+    if (K > CG * ((CGX == 256 || CGX < 32) ? 16 : 32) || N < 1 || max_rows < 2) return 1;
     if ((N + V) * (i64)sizeof(T) >= (1ll << 31)) return 1;  // one descriptor per score column
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if (rdst > 0 && (CGX != 32 || !defl || rdst < V || R % rdst != 0 ||
                      ((i64)(R / rdst) * tsd + (i64)CG * ldd) * (i64)sizeof(T) >= (1ll << 31)))
         return 1;
-    if (CGX != 32 && edge != 0) return 1;  // (the short tiles only ever hold the library's own copy)
+    if (CGX > 32 && edge != 0) return 1;  // (the short tiles only ever hold the library's own copy)
     if constexpr (CGX == 32) {
         if (rdst > 0 && K <= CG * 16) return 1;
     }
@@ -965,7 +975,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     } while (0)
 #define FUSED_EDGE(CPT_, DEFL_, dyn_)                                                                                     \
     do {                                                                                                                  \
-        if constexpr (CGX == 32) {                                                                                        \
+        if constexpr (CGX <= 32) {                                                                                        \
             if (edge == 2) { FUSED_LAUNCH(CPT_, DEFL_, 2, dyn_); break; }                                                 \
             if (edge == 1) { FUSED_LAUNCH(CPT_, DEFL_, 1, dyn_); break; }                                                 \
         }                                                                                                                 \
@@ -989,6 +999,12 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         } else if constexpr (CGX == 64 || CGX == 128) {
             if (K <= CG * 16) FUSED_CASE(16);
             else FUSED_CASE(32);
+        } else if constexpr (CGX == 8) {  // narrow matrices: 128-row (fp64) tiles
+            if (K <= CG * 4) FUSED_CASE(4);
+            else if (K <= CG * 8) FUSED_CASE(8);
+            else FUSED_CASE(16);
+        } else if constexpr (CGX == 16) {
+            FUSED_CASE(16);
         } else {
             FUSED_CASE(16);  // 256 column groups x 2 row lanes: K <= 4096 at 16 columns per lane
         }

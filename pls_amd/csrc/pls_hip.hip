@@ -769,7 +769,9 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // NIPALS keeps the deflated matrix in a library-owned buffer.  When the tile-resident pass covers the fit it
     // is stored row-tile-major (every R x K tile one contiguous block: fused_kernels.hpp), otherwise column-major
     // with ld = N for the one-product kernels.
-    constexpr i64 TR = plsk::tile_rows<T>();
+    // the tile that reads the caller's matrix: 32 column groups x 16 row lanes, taller with fewer groups for narrow matrices
+    const int tall_cg = plsk::tall_groups(K);
+    const i64 TR = (512 / tall_cg) * (i64)(16 / sizeof(T));
     // Any row count (the last N % V rows go to a tail kernel), any alignment of the columns and leading dimensions up to
     // 2^31 / 4 bytes (mode 2: the EDGE instantiations) -- the same one-sweep traffic for every matrix the reference
     // accepts (src/pls.cpp:419-421)
@@ -806,7 +808,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // on read-only passes.  Config 4: read+write pass 0.766 -> 0.710 ms (0.70 -> 0.76 of peak), read-only pass
     // 0.364 -> 0.324 ms (0.74 -> 0.83) against 32 columns per lane in 64 / 128 groups (PLS_HIP_WIDE16=0, the round-1 shape).
     static const bool wide16 = !(getenv("PLS_HIP_WIDE16") && atoi(getenv("PLS_HIP_WIDE16")) == 0);
-    const int wide_groups = fused_fit ? (K <= 32 * 16 ? 32 : 64)  // (the copy of a matrix the resident tile covers)
+    const int wide_groups = fused_fit ? (K <= 32 * 16 ? tall_cg : 64)  // (the copy of a matrix the resident tile covers)
                             : wide16 ? (K <= 128 * 16 ? 128 : (K <= 256 * 16 ? 256 : 0))
                                      : (K <= 64 * 32 ? 64 : (K <= 128 * 32 ? 128 : 0));
     if (retile_fit) {  // the copy is optional: without room for it the one-product kernels do the job
@@ -823,9 +825,9 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // every later pass runs on the short tiles.
     const int mid_cg = (nipals && fused_fit && tiled_work && K > 32 * 16 && A > 2) ? 64 : 0;
     // opt-in deferred write-back (defer_kernels.hpp): up to `defer` rank-1 updates pending per stored matrix
-    const int defer = (nipals && fused_mode == 1 && N % FVX == 0 && plsk::cols_aligned<T>(Tm, ldt) && tiled_work && K <= 32 * 16)
+    const int defer = (nipals && fused_mode == 1 && tall_cg == 32 && N % FVX == 0 && plsk::cols_aligned<T>(Tm, ldt) && tiled_work && K <= 32 * 16)
                           ? (int)c->opt_defer : 1;
-    const int work_cg = wide_cg ? wide_cg : (mid_cg ? mid_cg : 32);
+    const int work_cg = wide_cg ? wide_cg : (mid_cg ? mid_cg : tall_cg);
     const i64 WR = (512 / work_cg) * (i64)(16 / sizeof(T));  // rows per tile of the working copy
     if ((nipals && A > 1 && N > 0) || retile_fit)
         CHK(ensure(c, c->work, (tiled_work || retile_fit) ? (size_t)((N + WR - 1) / WR) * WR * K * sizeof(T)
@@ -849,8 +851,10 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         int nb = 0, rc = 1;
         if (rx_on) {
             Scope s(c, PLS_HIP_FAM_DEFLATE, 2 * (i64)N * K * sizeof(T) + (i64)N * M * sizeof(T) + L0 * 8);
-            rc = plsk::launch_retile_xty<T>(c->stream, c->num_cu, X, ldx, Y, ldy, work, WR, WR * (i64)K, (int)WR, N, K, M, part,
-                                            (int)prow, &nb);
+            // (the source tile is as tall as the copy's for narrow matrices, the 256-byte-segment tile otherwise)
+#define RX_CALL(CG_) plsk::launch_retile_xty<T, CG_>(c->stream, c->num_cu, X, ldx, Y, ldy, work, WR, WR * (i64)K, (int)WR, N, K, M, part, (int)prow, &nb)
+            rc = (fused_fit && tall_cg == 8) ? RX_CALL(8) : ((fused_fit && tall_cg == 16) ? RX_CALL(16) : RX_CALL(32));
+#undef RX_CALL
             if (rc != 0) s.on = false;
         }
         if (rc == 0) {
@@ -982,11 +986,13 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                         rc = plsk::launch_fused_pass<T, 64>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v,
                                                             tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
                                                             &nb, &nss, (int)c->opt_fused_grid, 0, true);
-                    else  // (a == 1 with mid_cg: X in 256-byte segments -> half-height tiles)
-                        rc = plsk::launch_fused_pass<T>(c->stream, c->num_cu, Xc, ldc, tsc, tprev ? work : nullptr, ldw, tsw,
-                                                        N, K, v, tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
-                                                        &nb, &nss, (int)c->opt_fused_grid,
-                                                        (mid_cg && tprev) ? (int)WR : 0, Xc == work);
+                    else {  // (a == 1 with mid_cg: X in 256-byte segments -> half-height tiles)
+#define TALL_PASS(CG_) plsk::launch_fused_pass<T, CG_>(c->stream, c->num_cu, Xc, ldc, tsc, tprev ? work : nullptr, ldw, tsw, N, K, v, tprev, \
+                                                       pprev, Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss,                        \
+                                                       (int)c->opt_fused_grid, (mid_cg && tprev) ? (int)WR : 0, Xc == work)
+                        rc = tall_cg == 8 ? TALL_PASS(8) : (tall_cg == 16 ? TALL_PASS(16) : TALL_PASS(32));
+#undef TALL_PASS
+                    }
                     if (rc != 0) s.on = false;  // nothing was launched: drop the event pair
                 }
                 if (rc == 0) {
@@ -1015,7 +1021,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     Scope s(c, PLS_HIP_FAM_FUSED, bytes);
 #define WIDE_PASS(CG_) plsk::launch_fused_pass<T, CG_>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v, tprev, pprev, \
                                                         Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid, 0, true)
-                    rc = wide_cg == 32 ? WIDE_PASS(32) : (wide_cg == 64 ? WIDE_PASS(64) : (wide_cg == 128 ? WIDE_PASS(128) : WIDE_PASS(256)));
+                    rc = wide_cg == 8 ? WIDE_PASS(8) : (wide_cg == 16 ? WIDE_PASS(16) : (wide_cg == 32 ? WIDE_PASS(32)
+                         : (wide_cg == 64 ? WIDE_PASS(64) : (wide_cg == 128 ? WIDE_PASS(128) : WIDE_PASS(256)))));
 #undef WIDE_PASS
                     if (rc != 0) s.on = false;
                 }

@@ -50,6 +50,16 @@ SHAPES = [
     (515, 3000, 1, 5, "f64", 0, 1),     # wide: 4-row tiles (256 column groups)
     (1031, 2500, 2, 4, "f32", 0, 1),    # wide fp32
     (261, 5000, 1, 4, "f64", 0, 0),     # beyond the resident tiles: semi-fused sweeps on the column-major copy
+    # odd N with every tile height of the working copy and enough components for an error in one row's contribution to
+    # show (a lane just behind the swept rows once picked up t_prev of the tail row: 1e-5 in P from the second component on)
+    (1365, 1024, 4, 9, "f64", 0, 0),    # 16-row tiles (512 < K <= 1024)
+    (1365, 520, 4, 8, "f64", 1, 0),
+    (1365, 128, 2, 10, "f64", 0, 0),    # 128-row tiles of narrow matrices (8 column groups)
+    (1381, 200, 2, 10, "f64", 0, 1),    # 64-row tiles (16 column groups)
+    (1381, 700, 1, 12, "f64", 0, 0),
+    (1367, 900, 2, 8, "f32", 0, 0),
+    (1365, 100, 1, 8, "f32", 0, 2),
+    (4099, 30, 1, 6, "f64", 0, 0),      # 4 columns per lane of the 128-row tile
 ]
 
 
