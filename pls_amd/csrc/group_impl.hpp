@@ -1,7 +1,9 @@
 // group_impl.hpp -- pls_hip_group: one process, one handle + one host thread per GPU (include/pls_hip.h, "one
 // process, several GPUs").  Included at the end of pls_hip.hip: it drives the members through the public entry
 // points on their own handles and adds (a) the row partition and the resident matrices, (b) the in-process
-// all-reduce: every member reads the other members' partial buffers over peer access and sums them in rank order.
+// all-reduce: the device-side exchange of exchange_kernels.hpp (every member writes its partial sums into its peers'
+// inboxes; default when every member has its own GPU) or, for members that share a GPU and for messages beyond 512 KB,
+// the host-synchronised form in which every member reads the other members' buffers over peer access.
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -11,11 +13,6 @@ namespace {
 
 constexpr int GROUP_MAX = plsk::XCHG_MAX;
 using plsk::XCHG_CAP;
-using plsk::XCHG_THREADS;
-using plsk::XCHG_TIMEOUT_S;
-using plsk::XchgPeers;
-using plsk::xchg_gather_kernel;
-using plsk::xchg_push_kernel;
 
 struct PeerPtrs {
     const double *p[GROUP_MAX];

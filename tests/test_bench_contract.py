@@ -84,3 +84,20 @@ def test_bench_gpus_flag_alone_starts_the_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "row-shard x2" and d["config"]["reducer"] == "torch"
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_the_device_side_exchange():
+    """The reducer `bench.py --gpus N` takes by default on a multi-GPU node (`--reducer ipc`: the library's device-side
+    exchange between processes), rehearsed with two ranks on the one GPU (gloo only carries the set-up): one contract
+    line, the reducer it reports is the exchange itself (no fall-back), and the replica guard at the end stayed quiet."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "tiny", "--backend", "gloo", "--reducer", "ipc"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["reducer"] == "ipc" and d["value"] > 0

@@ -60,6 +60,12 @@ SHAPES = [
     (1367, 900, 2, 8, "f32", 0, 0),
     (1365, 100, 1, 8, "f32", 0, 2),
     (4099, 30, 1, 6, "f64", 0, 0),      # 4 columns per lane of the 128-row tile
+    # the copy + X^T Y sweep on the tall source tiles, several responses (Y block through LDS, two tiles in flight)
+    (1001, 100, 8, 6, "f32", 0, 1),
+    (1002, 200, 5, 6, "f64", 1, 0),
+    (2049, 64, 3, 5, "f32", 0, 0),
+    (2050, 120, 4, 12, "f64", 0, 0),    # aligned columns, enough components for the KERNEL plan's copy
+    (2052, 250, 8, 12, "f32", 0, 0),
 ]
 
 
@@ -112,7 +118,7 @@ def test_edge_shapes_take_the_one_sweep_plan(handle, oracle, po, plan, monkeypat
     unaligned = (N + ld_extra) % V != 0 or base_off % V != 0
     if K <= 1024:
         assert tm["launches"]["fused"] == A and tm["launches"]["xb"] == 0, tm["launches"]
-        if not nipals and unaligned and A >= 4:
+        if not nipals and ((unaligned and A >= 4) or (not unaligned and A >= 10 and K <= 512)):
             # KERNEL plan on unaligned columns: one copy into aligned tiles, formed in the same sweep as X^T Y
             assert tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
         else:

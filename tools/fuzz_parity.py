@@ -35,7 +35,18 @@ for case in range(ncases):
     if f32:
         X = np.asfortranarray(X.astype(np.float32).astype(np.float64)); Y = np.asfortranarray(Y.astype(np.float32).astype(np.float64))
     dt = torch.float32 if f32 else torch.float64
-    Xd = pls_amd.as_colmajor(torch.from_numpy(X).to(dt).cuda()); Yd = pls_amd.as_colmajor(torch.from_numpy(Y).to(dt).cuda())
+    # layout: half of the cases in the reference's own (ld = rows: odd N leaves columns unaligned), sometimes with extra padding
+    # and a base pointer off the 16-byte grid; the rest in 16-byte aligned columns
+    if rng.integers(0, 2) == 0:
+        ldx, off = N + int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        def place(a, cols):
+            flat = torch.full((cols * ldx + off + 8,), float("nan"), dtype=dt, device="cuda")
+            v = flat[off:off + cols * ldx].view(cols, ldx)[:, :N].t()
+            v.copy_(torch.from_numpy(a).to(dt))
+            return v
+        Xd, Yd = place(X, K), place(Y, M)
+    else:
+        Xd = pls_amd.as_colmajor(torch.from_numpy(X).to(dt).cuda()); Yd = pls_amd.as_colmajor(torch.from_numpy(Y).to(dt).cuda())
     tol = 5e-5 if f32 else 1e-10  # fp64: the north star's bar on the coefficients
     try:
         if kind == "cv":
