@@ -14,6 +14,9 @@
 // that failed or fell out of step) sets the member's status words and leaves the loop; later waits of the same member
 // return at once.  Messages longer than XCHG_CAP go in pieces (or, in the group, through the host-synchronised path).
 #pragma once
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace plsk {
@@ -81,7 +84,18 @@ inline int xchg_launch_piece(hipStream_t stream, int n, int rank, double *const 
         peers.slot[j] = inboxes[j] + ((i64)par * n + rank) * XCHG_CAP;
         peers.flag[j] = flagsv[j] + par * n + rank;
     }
-    hipLaunchKernelGGL(xchg_push_kernel, dim3(n), dim3(XCHG_THREADS), 0, stream, peers, (const double *)buf, Ltot, j0, L, slices, seq);
+    // fault injection for the tests of the time-out path: PLS_HIP_TEST_DROP_PUSH="rank:collective" makes that rank skip
+    // that one push, once per process (its peers -- and itself -- then wait for a flag that never comes)
+    static const char *drop = getenv("PLS_HIP_TEST_DROP_PUSH");
+    static bool dropped = false;  // (once per process)
+    bool skip = false;
+    if (drop && !dropped) {
+        int dr = -1;
+        unsigned long long dq = 0;
+        if (sscanf(drop, "%d:%llu", &dr, &dq) == 2) skip = dropped = (dr == rank && dq == seq);
+    }
+    if (!skip)
+        hipLaunchKernelGGL(xchg_push_kernel, dim3(n), dim3(XCHG_THREADS), 0, stream, peers, (const double *)buf, Ltot, j0, L, slices, seq);
     hipLaunchKernelGGL(xchg_gather_kernel, dim3((unsigned)std::min<i64>(16, (L + 255) / 256)), dim3(256), 0, stream,
                        (const double *)(inboxes[rank] + (i64)par * n * XCHG_CAP), (const unsigned long long *)(flagsv[rank] + par * n),
                        n, XCHG_CAP, Ltot, j0, L, slices, seq, buf, status, host_status, limit);

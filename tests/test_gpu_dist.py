@@ -355,3 +355,52 @@ def test_sharded_fit_over_the_ipc_exchange(world, splits, algo, method):
         T = np.concatenate([out["T"] for _, out in res], axis=0)
         G = T.T @ T
         assert np.abs(G - np.diag(np.diag(G))).max() < 1e-9 * np.diag(G).max()
+
+
+def _ipc_timeout_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      PLS_HIP_XCHG_TIMEOUT_S="1.5", PLS_HIP_TEST_DROP_PUSH="1:4")
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import pls_amd
+    from pls_amd.distributed import attach_ipc_exchange, row_partition
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        N, K, M, A = 4096, 64, 1, 6
+        h = pls_amd.Handle()
+        row0, nrows = row_partition(N, world, rank)
+        X = h.synth_x(row0, nrows, K, pls_amd.SEED_DEFAULT); Y = h.synth_y(row0, nrows, M, pls_amd.SEED_DEFAULT)
+        attach_ipc_exchange(h)            # (self-test = collective 1)
+        h.fit_device(X, Y, A)             # rank 1 drops the push of collective 4
+        status = "ok"
+        try:
+            h.synchronize()
+        except pls_amd.PlsHipError as e:
+            status = f"error {e.code}"
+        q.put((rank, {"status": status}))
+        h.close()
+    except BaseException:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ipc_exchange_time_out_is_reported_on_every_rank():
+    """A rank that never delivers a partial sum (fault injection: one push dropped) must not hang the others: every rank's wait
+    ends at the time limit and pls_hip_synchronize returns PLS_HIP_ERR_REDUCER on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ipc_timeout_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=180)
+    assert not any("error" in r[1] for r in res), [r[1].get("error") for r in res]
+    assert [r[1]["status"] for r in res] == ["error 5", "error 5"], res

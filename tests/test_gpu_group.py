@@ -186,3 +186,38 @@ def test_device_side_exchange_virtual_members():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "group_exchange_check.py"), "2", "3", "4", "8"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "exchange check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_device_side_exchange_time_out_and_recovery():
+    """A member that never delivers (fault injection: one push dropped) must not hang the others: every member's wait ends at
+    the time limit, the call returns PLS_HIP_ERR_REDUCER, the group re-synchronises its sequence numbers, and the next fit
+    is right again."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import pls_amd
+from oracle import pls_oracle as po
+ora = po.OracleLib()
+g = pls_amd.Group([0, 0, 0])
+assert g.exchange == "device"
+N, K, M, A = 3000, 40, 2, 5
+Xh, Yh = ora.synth_x(0, N, K), ora.synth_y(0, N, M)
+ref = ora.plsr(Xh, Yh, A); Bref = ora.coefficients(ref["R"], ref["Q"])
+X, Y = g.upload(Xh), g.upload(Yh)
+try:
+    g.fit(X, Y, A)            # member 1 drops the push of its collective 4 (self-test = 1, X^T Y = 2, components from 3)
+    print("no error")
+except pls_amd.PlsHipError as e:
+    print("error", e.code, str(e)[:120])
+out = g.fit(X, Y, A)          # sequence numbers start over; the injected collective number does not come again
+print("refit", po.rel_fro(out["B"], Bref) < 1e-10)
+''' % root
+    env = dict(os.environ, PLS_HIP_GROUP_EXCHANGE="device", GPU_MAX_HW_QUEUES="16", PLS_HIP_XCHG_TIMEOUT_S="1.5",
+               PLS_HIP_TEST_DROP_PUSH="1:4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "error 5" in r.stdout and "refit True" in r.stdout, r.stdout[-1500:]
