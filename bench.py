@@ -44,6 +44,7 @@ WORKLOADS = {
     "tall64": (1 << 24, 64, 1, 20, "f64"),   # 32 column groups of one matrix span 4.3 GB: per-wave descriptors
     "tall64a": (8388544, 64, 1, 20, "f64"),  # the tallest 64-column matrix one descriptor per column-group set still covers
     "C4odd": (131071, 4096, 8, 50, "f32"),
+    "C4m16": (131072, 4096, 16, 50, "f32"), "C4m32": (131072, 4096, 32, 50, "f32"),  # more responses than the cooperative update takes
     # narrow matrices, 4.3 GB each (few columns per lane in the resident tile)
     "narrow32": (1 << 24, 32, 1, 20, "f64"), "narrow128": (1 << 22, 128, 1, 20, "f64"), "narrow256": (1 << 21, 256, 1, 20, "f64"),
 }

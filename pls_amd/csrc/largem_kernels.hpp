@@ -77,6 +77,18 @@ __global__ __launch_bounds__(WG) void lm_scale_kernel(const double *__restrict__
     if (i < n) out[i] = in[i] / tr[0];
 }
 
+// The dominant eigenvector of G (M x M, M <= MMAX = 32) in ONE launch, in LDS: the solver of component_update_body
+// (repeated squaring to the fixed point, two polishing steps, sign convention).  For 9 <= M <= 32 responses on matrices
+// with many columns, where the rest of the update runs as the multi-workgroup kernels of this file.
+__global__ __launch_bounds__(UPD_THREADS) void lm_eig_lds_kernel(const double *__restrict__ G, int M, int iters,
+                                                                 double *__restrict__ qe) {
+    __shared__ double Gs[MMAX * MMAX], Bs[MMAX * MMAX], Cs[MMAX * MMAX], qs[MMAX];
+    for (int i = threadIdx.x; i < M * M; i += UPD_THREADS) Gs[i] = G[i];
+    __syncthreads();
+    dominant_eigvec_lds(Gs, Bs, Cs, qs, M, iters);
+    if ((int)threadIdx.x < M) qe[threadIdx.x] = qs[threadIdx.x];
+}
+
 // From Bm ~ v1 v1^T: the column with the largest diagonal entry, two power steps on G, unit norm, largest-|.| entry
 // positive (lowest index on ties) -> qe.   One workgroup of UPD_THREADS; M <= LM_MAX (qe staged in LDS).
 __global__ __launch_bounds__(UPD_THREADS) void lm_eig_finish_kernel(const double *__restrict__ G, const double *__restrict__ Bm,

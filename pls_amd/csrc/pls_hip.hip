@@ -488,20 +488,27 @@ int launch_update_large(pls_hip_context *c, const double *red, double *XY, doubl
                            (const double *)xred, (int)MM, G);
         LAUNCH_CHECK(c);
     }
-    // dominant eigenvector: B_0 = G / tr G, B_{j+1} = B_j^2 / tr(B_j^2)
-    const dim3 sq((M + 15) / 16, (M + 15) / 16), sqb(16, 16);
-    const unsigned nmm = (unsigned)((MM + plsk::WG - 1) / plsk::WG);
-    hipLaunchKernelGGL(plsk::lm_trace_kernel, dim3(1), blk, 0, c->stream, (const double *)G, M, tr);
-    hipLaunchKernelGGL(plsk::lm_scale_kernel, dim3(nmm), blk, 0, c->stream, (const double *)G, (const double *)tr, MM, Bm);
-    for (int it = 0; it < (int)c->opt_power_iters; ++it) {
-        hipLaunchKernelGGL(plsk::lm_square_kernel, sq, sqb, 0, c->stream, (const double *)Bm, M, Cm);
-        hipLaunchKernelGGL(plsk::lm_trace_kernel, dim3(1), blk, 0, c->stream, (const double *)Cm, M, tr);
-        hipLaunchKernelGGL(plsk::lm_scale_kernel, dim3(nmm), blk, 0, c->stream, (const double *)Cm, (const double *)tr, MM, Bm);
+    if (M <= plsk::MMAX) {
+        // up to 32 responses: the whole direction solve in one workgroup's LDS, one launch
+        hipLaunchKernelGGL(plsk::lm_eig_lds_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream, (const double *)G, M,
+                           (int)c->opt_power_iters, qe);
+        LAUNCH_CHECK(c);
+    } else {
+        // dominant eigenvector: B_0 = G / tr G, B_{j+1} = B_j^2 / tr(B_j^2)
+        const dim3 sq((M + 15) / 16, (M + 15) / 16), sqb(16, 16);
+        const unsigned nmm = (unsigned)((MM + plsk::WG - 1) / plsk::WG);
+        hipLaunchKernelGGL(plsk::lm_trace_kernel, dim3(1), blk, 0, c->stream, (const double *)G, M, tr);
+        hipLaunchKernelGGL(plsk::lm_scale_kernel, dim3(nmm), blk, 0, c->stream, (const double *)G, (const double *)tr, MM, Bm);
+        for (int it = 0; it < (int)c->opt_power_iters; ++it) {
+            hipLaunchKernelGGL(plsk::lm_square_kernel, sq, sqb, 0, c->stream, (const double *)Bm, M, Cm);
+            hipLaunchKernelGGL(plsk::lm_trace_kernel, dim3(1), blk, 0, c->stream, (const double *)Cm, M, tr);
+            hipLaunchKernelGGL(plsk::lm_scale_kernel, dim3(nmm), blk, 0, c->stream, (const double *)Cm, (const double *)tr, MM, Bm);
+        }
+        LAUNCH_CHECK(c);
+        hipLaunchKernelGGL(plsk::lm_eig_finish_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream, (const double *)G,
+                           (const double *)Bm, M, qe);
+        LAUNCH_CHECK(c);
     }
-    LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(plsk::lm_eig_finish_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream, (const double *)G,
-                       (const double *)Bm, M, qe);
-    LAUNCH_CHECK(c);
     hipLaunchKernelGGL(plsk::lm_w_kernel, dim3(nparts), blk, 0, c->stream, (const double *)XY, (const double *)qe, K, M, wraw, ssp);
     LAUNCH_CHECK(c);
     double *wn = W + (i64)n * K;
@@ -522,7 +529,12 @@ int launch_update_large(pls_hip_context *c, const double *red, double *XY, doubl
 int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, double *P,
                   double *Q, double *R, double *v, int K, int M, int A, int a, int nip) {
     const int n = a + 1;
-    if (M > plsk::MMAX) return launch_update_large(c, red, XY, W, P, Q, R, v, K, M, A, a, nip);
+    // 9 <= M <= 32 responses on many columns: the one-workgroup kernel walks K x M values several times and forms the
+    // M (M + 1) / 2 Gram entries one wave per pair (208 us per component at K = 4096, M = 16; 630 us at M = 32 -- more
+    // than the 0.32 ms pass); the multi-workgroup kernels of the many-response path with the LDS eigen solve: ~12 launches
+    static const bool mid_on = !(getenv("PLS_HIP_MID_UPDATE") && atoi(getenv("PLS_HIP_MID_UPDATE")) == 0);
+    if (M > plsk::MMAX || (mid_on && M > 8 && (i64)K * M >= 16384))
+        return launch_update_large(c, red, XY, W, P, Q, R, v, K, M, A, a, nip);
     // PLS_HIP_COOP_UPDATE=0 in the environment keeps the single-workgroup kernel (A/B measurements only)
     static const bool coop_on = !(getenv("PLS_HIP_COOP_UPDATE") && atoi(getenv("PLS_HIP_COOP_UPDATE")) == 0);
     if (coop_on && plsk::coop_update_covers(K, M) && A <= 4096) {

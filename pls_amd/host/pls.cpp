@@ -69,11 +69,23 @@ struct PLS::DeviceContext {
     std::mutex mu;
     pls_hip_handle plain = nullptr;  // folds on gathered data when the group has several members (run_folds)
     int plain_device = 0;
-    ~DeviceContext() {
-        if (plain) pls_hip_destroy(plain);
-        if (g) pls_hip_group_destroy(g);
-    }
+    ~DeviceContext();
 };
+
+namespace {
+
+// Contexts that outlive main() (a Model with static storage duration) are not torn down: by then the HIP runtime may be
+// unloading.  The flag is raised by an atexit handler registered with the first context, i.e. one that runs BEFORE the
+// handlers the runtime registered when it was loaded; thread-local contexts of the main thread go before any of them.
+std::atomic<bool> g_exiting{false};
+
+}  // namespace
+
+PLS::DeviceContext::~DeviceContext() {
+    if (g_exiting.load()) return;
+    if (plain) pls_hip_destroy(plain);
+    if (g) pls_hip_group_destroy(g);
+}
 
 namespace {
 
@@ -86,6 +98,8 @@ Ctx make_context() {
         devs = g_cfg_devs;
     }
     if (devs.empty()) devs = device_list();  // (the environment is read again for every new context)
+    static std::once_flag once;
+    std::call_once(once, [] { std::atexit([] { g_exiting.store(true); }); });
     Ctx c = std::make_shared<PLS::DeviceContext>();
     const int rc = pls_hip_group_create(&c->g, static_cast<int>(devs.size()), devs.data());
     if (rc != PLS_HIP_OK)

@@ -518,6 +518,17 @@ def test_cooperative_component_update(handle, oracle, po, mode, N, K, M, A):
     check_against(po, out, ref, Bref, ref["T"], col_err=cerr, tol_inv=1e-7)
 
 
+@pytest.mark.parametrize("N,K,M,A", [(300, 2048, 16, 5), (260, 1024, 32, 4), (500, 1900, 9, 6), (130, 5000, 12, 4)])
+def test_nine_to_32_responses_on_many_columns(handle, oracle, po, mode, N, K, M, A):
+    """9 <= M <= 32 with K M >= 16 K values: the component update runs as the multi-workgroup kernels of the
+    many-response path (X^T Y deflation, Gram matrix by the column-reduction kernels, r recurrence) with the direction
+    solved in one workgroup's LDS -- the one-workgroup kernel took 208 us per component at K = 4096, M = 16."""
+    Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    out = handle.fit_device(to_dev(Xh), to_dev(Yh), A); handle.synchronize()
+    check_against(po, out, ref, Bref, ref["T"], col_err=cerr)
+
+
 @pytest.mark.parametrize("N,K,M,A", [(512, 2300, 3, 4), (516, 1536, 1, 5), (260, 4096, 2, 5)])
 def test_wide_matrix_fp32(handle, oracle, po, mode, N, K, M, A):
     torch = _torch()
