@@ -7,6 +7,7 @@ import numpy as np, torch, pls_amd
 from oracle import pls_oracle as po
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+random_options = len(sys.argv) > 3 and sys.argv[3] == "options"  # also draw handle options per case
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 one = po.OracleLib(omp=True)
 h = pls_amd.Handle()
@@ -48,6 +49,11 @@ for case in range(ncases):
     else:
         Xd = pls_amd.as_colmajor(torch.from_numpy(X).to(dt).cuda()); Yd = pls_amd.as_colmajor(torch.from_numpy(Y).to(dt).cuda())
     tol = 5e-5 if f32 else 1e-10  # fp64: the north star's bar on the coefficients
+    if random_options:  # every combination must give the same model: layout of the copy, unfused kernels, deferred write-back, grids
+        h.set_option(pls_amd.OPT_WORK_LAYOUT, int(rng.integers(0, 2)))
+        h.set_option(pls_amd.OPT_FUSE, int(rng.integers(0, 4) != 0))
+        h.set_option(pls_amd.OPT_DEFER, int(rng.choice([1, 1, 2, 3, 4])))
+        h.set_option(pls_amd.OPT_FUSED_GRID, int(rng.choice([0, 0, 7, 64, 300, 1000])))
     try:
         if kind == "cv":
             ts = int(rng.integers(1, max(2, N // 3))); nf = int(rng.integers(1, 6))
