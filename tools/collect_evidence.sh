@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collects the measurement evidence of a round on the GPU box into gpurun_out/evidence/ (copy what is to be judged
 # into profiles/rNN/ afterwards).  rocprofv3: the program goes directly after `--`; counters in their own passes.
-# usage: bash tools/collect_evidence.sh [part ...]   parts: c3 deflate c4 c5 eighth edge group host roctx small fuzz   (default: all but fuzz)
+# usage: bash tools/collect_evidence.sh [part ...]   parts: c3 deflate c4 c5 eighth edge narrow group host roctx small fuzz   (default: all but fuzz)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 E=gpurun_out/evidence; mkdir -p $E
-PARTS="${*:-c3 deflate c4 c5 eighth edge group host roctx small}"
+PARTS="${*:-c3 deflate c4 c5 eighth edge narrow group host roctx small}"
 stats() {  # name, command...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $E/tmp_$name -o p -- "$@" > $E/${name}_bench_under_rocprof.json 2> $E/tmp_$name.err
@@ -71,6 +71,30 @@ PY
   pmc C3odd_kernel python3 bench.py --workload C3odd- --algo kernel --steps 2 --warmup 1 --no-alt --no-cpu
   stats c3odd_nipals python3 bench.py --workload C3odd- --steps 3 --warmup 1 --no-alt --no-cpu
   ./pls_amd/csrc/tune/unaligned_probe > $E/unaligned_probe.txt 2>&1 ;;
+narrow)
+  # narrow matrices (taller tiles) and 9-32 responses on many columns, with the previous forms beside them
+  for wl in narrow32 tall64a narrow128 narrow256; do for algo in nipals kernel; do
+    python3 bench.py --workload $wl --algo $algo --steps 8 --warmup 3 --no-cpu --no-alt > $E/narrow_bench_${wl}_${algo}.json 2> /dev/null
+    PLS_HIP_TALL_TILES=0 python3 bench.py --workload $wl --algo $algo --steps 8 --warmup 3 --no-cpu --no-alt > $E/narrow_bench_${wl}_${algo}_one_tile_shape.json 2> /dev/null
+  done; done
+  for wl in C4m16 C4m32; do
+    python3 bench.py --workload $wl --algo kernel --steps 3 --warmup 2 --no-cpu --no-alt > $E/narrow_bench_${wl}_kernel.json 2> /dev/null
+    PLS_HIP_MID_UPDATE=0 python3 bench.py --workload $wl --algo kernel --steps 3 --warmup 2 --no-cpu --no-alt > $E/narrow_bench_${wl}_kernel_one_workgroup_update.json 2> /dev/null
+  done
+  python3 - <<'PY'
+import glob, json, os
+E = "gpurun_out/evidence"
+with open(E + "/narrow_and_many_responses_summary.txt", "w") as out:
+    out.write("workload_plan[_variant]  components/s  ms/fit  dominant family: avg launch ms, fraction of 8 TB/s\n")
+    for f in sorted(glob.glob(E + "/narrow_bench_*.json")):
+        try:
+            d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+        except Exception:
+            continue
+        r = d["roofline"]
+        out.write("%-46s %9.1f %9.3f  %s %.4f ms %.4f\n" % (os.path.basename(f)[13:-5], d["value"], d["ms_per_step"], r["kernel"], r["avg_launch_ms"], r["frac"]))
+PY
+  ;;
 group)
   # the two in-process exchanges with virtual members (one hardware queue per member), the cross-process exchange with
   # ranks sharing the GPU, config 5 at its own size
