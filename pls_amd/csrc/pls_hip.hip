@@ -1629,7 +1629,29 @@ int zscores_device(pls_hip_context *c, const T *X, i64 ldx, i64 N, i64 n_total, 
     CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * 8));
     double *part = (double *)c->part.p, *red = (double *)c->red2.p;
     const dim3 grid(G, nkg), blk(plsk::WG);
-    for (int mode = 0; mode < 2; ++mode) {
+    // Single rank: mean and sd from ONE sweep (colmoments_kernel: per-thread shifted sums merged pairwise) -- two sweeps of
+    // X (statistics, scale) for the z-scores instead of the reference's three.  Sharded: the reducer sums, it does not
+    // merge (count, mean, M2) triples; two passes as in the reference.
+    static const bool one_pass = !(getenv("PLS_HIP_ZSCORE_ONE_PASS") && atoi(getenv("PLS_HIP_ZSCORE_ONE_PASS")) == 0);
+    const bool shifted = one_pass && !c->reducer && N > 0 && n_total == N;
+    if (shifted) {
+        // all workgroups resident at once (5 per CU at 84 VGPRs): one round, no tail
+        const int G1 = (int)std::min<i64>(nch, std::max<i64>(1, (5 * c->num_cu) / nkg));
+        CHK(ensure(c, c->part, (size_t)G1 * (3 * K + 1) * 8));
+        part = (double *)c->part.p;
+        double *cnt = part + (i64)G1 * 3 * K;
+        {
+            Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) + 2 * (i64)K * 8);
+            const dim3 g1(G1, nkg);
+            if (wide) hipLaunchKernelGGL((plsk::colmoments_kernel<T, FV, KC>), g1, blk, 0, c->stream, X, ldx, N, K, part, cnt);
+            else hipLaunchKernelGGL((plsk::colmoments_kernel<T, 1, KC>), g1, blk, 0, c->stream, X, ldx, N, K, part, cnt);
+            LAUNCH_CHECK(c);
+        }
+        hipLaunchKernelGGL(plsk::colmoments_finish_kernel, dim3((K + plsk::WG - 1) / plsk::WG), blk, 0, c->stream,
+                           (const double *)part, (const double *)cnt, G1, K, mean, sd);
+        LAUNCH_CHECK(c);
+    }
+    for (int mode = shifted ? 2 : 0; mode < 2; ++mode) {
         if (N > 0) {
             Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) + (i64)K * 8);
 #define CS_CASE(V_, M_) hipLaunchKernelGGL((plsk::colstat_kernel<T, V_, KC, M_>), grid, blk, 0, c->stream, X, ldx, N, K, mean, part)
@@ -1649,7 +1671,10 @@ int zscores_device(pls_hip_context *c, const T *X, i64 ldx, i64 N, i64 n_total, 
     if (Z && N > 0) {
         Scope s(c, PLS_HIP_FAM_DEFLATE, 2 * (i64)N * K * sizeof(T) + 2 * (i64)K * 8);
         const dim3 g2((unsigned)std::min<i64>(nch, std::max<i64>(1, (16 * c->num_cu) / nkg)), nkg);
-        if (wide) hipLaunchKernelGGL((plsk::zscale_kernel<T, FV, KC>), g2, blk, 0, c->stream, X, ldx, Z, ldz, N, K, mean, sd);
+        static const bool piece = !(getenv("PLS_HIP_ZS_PIECE") && atoi(getenv("PLS_HIP_ZS_PIECE")) == 0);
+        if (wide && piece && K <= 65535)
+            hipLaunchKernelGGL((plsk::zscale_piece_kernel<T, FV>), dim3((unsigned)nch, K), blk, 0, c->stream, X, ldx, Z, ldz, N, mean, sd);
+        else if (wide) hipLaunchKernelGGL((plsk::zscale_kernel<T, FV, KC>), g2, blk, 0, c->stream, X, ldx, Z, ldz, N, K, mean, sd);
         else hipLaunchKernelGGL((plsk::zscale_kernel<T, 1, KC>), g2, blk, 0, c->stream, X, ldx, Z, ldz, N, K, mean, sd);
         LAUNCH_CHECK(c);
     }

@@ -601,6 +601,135 @@ __global__ __launch_bounds__(WG) void colstat_kernel(const T *__restrict__ X, i6
     }
 }
 
+// ------------------------------------------------------------------------------------
+// The same statistics in ONE sweep (single rank).  Every WAVE keeps, per column, the sums of (x - s) and (x - s)^2 about
+// the first element s IT reads of that column (a scalar register pair), and turns them into (count, mean, M2 = sum of
+// squared deviations about that mean) of its rows: the cancellation in S2 - S1^2/cnt is eps * ((s - mean)/sd)^2, a few
+// eps for any s drawn from the column -- and at most eps * cnt (a wave's few thousand rows) if s is an outlier, because
+// the outlier's own deviation is then part of M2.  No column offset enters.  The triples are merged pairwise with the
+// update of Chan, Golub & LeVeque (mean += d*nb/n, M2 += M2b + d^2*na*nb/n): waves -> workgroup here, workgroups in
+// colmoments_finish_kernel.  The merge is FIRST order in the error of the two means (the two-pass form is second order
+// in the error of its one mean), so the means travel as unevaluated sums hi + lo (two_sum): with a column offset of 1e8
+// sd a plain fp64 mean would be rounded at 1e-8 sd and every d = mean_b - mean_a with it; hi_b - hi_a is exact there
+// (Sterbenz) and lo carries what the rounding dropped.
+//   part[g][0..2][k] = mean hi, mean lo, M2 of workgroup g's rows;  cnt[g] = its row count.
+// A constant column gives M2 = 0 exactly (every difference is 0), like the two-pass form.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void two_sum(double a, double b, double &s, double &e) {
+    s = a + b;
+    const double bb = s - a;
+    e = (a - (s - bb)) + (b - bb);
+}
+// (na, ah + al, qa) <- merged with (nb, bh + bl, qb); wb = nb / (na + nb), wc = na * wb
+__device__ __forceinline__ void moments_merge(double &ah, double &al, double &qa, double bh, double bl, double qb, double wb,
+                                              double wc) {
+    const double d = (bh - ah) + (bl - al);
+    qa = qa + qb + d * d * wc;
+    double e;
+    two_sum(ah, d * wb, ah, e);
+    al += e;
+}
+__device__ __forceinline__ double wave_first(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+template <typename T, int VEC, int KC>
+__global__ __launch_bounds__(WG) void colmoments_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K,
+                                                        double *__restrict__ part, double *__restrict__ cnt) {
+    __shared__ double red[WG / WAVE][3][KC];
+    __shared__ double redn[WG / WAVE];
+    const int k0 = blockIdx.y * KC;
+    const int kn = min(KC, K - k0);
+    constexpr i64 CH = (i64)WG * VEC;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const i64 wfirst = (i64)blockIdx.x * CH + (i64)w * WAVE * VEC;  // the first row this wave reads (wave-uniform)
+    double s1[KC], s2[KC], mu[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        s1[kc] = 0.0; s2[kc] = 0.0;
+        mu[kc] = wave_first((kc < kn && wfirst < N) ? (double)X[wfirst + (i64)(k0 + kc) * ldx] : 0.0);
+    }
+    double n = 0.0;
+    for (i64 c = blockIdx.x; c * CH < N; c += gridDim.x) {
+        const i64 i0 = c * CH + (i64)threadIdx.x * VEC;
+        if (i0 + VEC <= N) {
+            n += (double)VEC;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+                if (kc < kn) {
+                    const Pack<T, VEC> x = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + kc) * ldx);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double d = (double)x.v[v] - mu[kc];
+                        s1[kc] += d;
+                        s2[kc] = fma(d, d, s2[kc]);
+                    }
+                }
+        } else if (i0 < N) {
+            n += (double)(N - i0);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+                if (kc < kn)
+                    for (int v = 0; v < VEC; ++v)
+                        if (i0 + v < N) {
+                            const double d = (double)X[i0 + v + (i64)(k0 + kc) * ldx] - mu[kc];
+                            s1[kc] += d;
+                            s2[kc] = fma(d, d, s2[kc]);
+                        }
+        }
+    }
+    // the wave's (count, mean hi + lo, M2)
+    n = wave_sum(n);
+    const double rn = n > 0.0 ? 1.0 / n : 0.0;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        const double a = wave_sum(s1[kc]), b = wave_sum(s2[kc]);
+        if (lane == 0) {
+            const double m1 = a * rn;
+            double hi, lo;
+            two_sum(mu[kc], m1, hi, lo);
+            red[w][0][kc] = hi; red[w][1][kc] = lo; red[w][2][kc] = fmax(fma(-a, m1, b), 0.0);
+        }
+    }
+    if (lane == 0) redn[w] = n;
+    __syncthreads();
+    if ((int)threadIdx.x < KC) {
+        double na = redn[0], ah = red[0][0][threadIdx.x], al = red[0][1][threadIdx.x], qa = red[0][2][threadIdx.x];
+#pragma unroll
+        for (int i = 1; i < WG / WAVE; ++i) {
+            const double nb = redn[i], nt = na + nb;
+            const double wb = nt > 0.0 ? nb / nt : 0.0;
+            moments_merge(ah, al, qa, red[i][0][threadIdx.x], red[i][1][threadIdx.x], red[i][2][threadIdx.x], wb, na * wb);
+            na = nt;
+        }
+        if ((int)threadIdx.x < kn) {
+            part[((i64)blockIdx.x * 3 + 0) * K + k0 + threadIdx.x] = ah;
+            part[((i64)blockIdx.x * 3 + 1) * K + k0 + threadIdx.x] = al;
+            part[((i64)blockIdx.x * 3 + 2) * K + k0 + threadIdx.x] = qa;
+        }
+        if (threadIdx.x == 0 && blockIdx.y == 0) cnt[blockIdx.x] = na;
+    }
+}
+
+// merge of the G workgroup triples of a column, in order (G <= a few thousand): mean[k], sd[k] = sqrt(M2 / (n - 1))
+__global__ __launch_bounds__(WG) void colmoments_finish_kernel(const double *__restrict__ part, const double *__restrict__ cnt,
+                                                               int G, int K, double *__restrict__ mean, double *__restrict__ sd) {
+    const int k = blockIdx.x * WG + threadIdx.x;
+    if (k >= K) return;
+    double na = cnt[0], ah = part[k], al = part[(i64)K + k], qa = part[2 * (i64)K + k];
+    for (int g = 1; g < G; ++g) {
+        const double nb = cnt[g], nt = na + nb;
+        const double wb = nt > 0.0 ? nb / nt : 0.0;
+        moments_merge(ah, al, qa, part[((i64)g * 3 + 0) * K + k], part[((i64)g * 3 + 1) * K + k], part[((i64)g * 3 + 2) * K + k], wb,
+                      na * wb);
+        na = nt;
+    }
+    mean[k] = ah + al;
+    sd[k] = sqrt((na < 2.0 ? 0.0 : qa) / (na - 1.0));
+}
+
 // Z[i,k] = (X[i,k] - mean[k]) / sd[k]   (src/pls.cpp:93-105: the division is by the UNGUARDED stdev,
 // so a constant column becomes NaN exactly as in the reference).  grid = (row groups, column groups).
 template <typename T, int VEC, int KC>
@@ -610,20 +739,77 @@ __global__ __launch_bounds__(WG) void zscale_kernel(const T *X, i64 ldx, T *Z, i
     const int k0 = blockIdx.y * KC;
     const int kn = min(KC, K - k0);
     constexpr i64 CH = (i64)WG * VEC;
+    // (mean, sd, 1/sd) of the workgroup's columns: wave-uniform, scalar registers.  The quotient y / sd is formed as
+    // q = y*r, q += fma(-q, sd, y) * r with r = 1/sd correctly rounded: the correctly rounded quotient (Markstein) in 3
+    // full-rate instructions instead of the ~15 of the division sequence with its quarter-rate v_rcp_f64.  sd = 0, NaN or
+    // so large / small that r or the residual could leave the normal range: the plain division (src/pls.cpp:103 divides
+    // by the unguarded sd -- a constant column is NaN / inf there and here).
+    double m[KC], sdev[KC], rinv[KC];
+    bool fast[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        m[kc] = kc < kn ? mean[k0 + kc] : 0.0;
+        sdev[kc] = kc < kn ? sd[k0 + kc] : 1.0;
+        rinv[kc] = 1.0 / sdev[kc];
+        fast[kc] = fabs(sdev[kc]) > 1e-150 && fabs(sdev[kc]) < 1e150;
+    }
+    auto quot = [&](double y, int kc) -> double {
+        if (!fast[kc]) return y / sdev[kc];
+        const double q = y * rinv[kc];
+        const double q1 = fma(fma(-q, sdev[kc], y), rinv[kc], q);
+        return (fabs(q) > 1e-290 && fabs(q) < 1e290) ? q1 : y / sdev[kc];  // (near the subnormals the residual is not exact)
+    };
     for (i64 c = blockIdx.x; c * CH < N; c += gridDim.x) {
         const i64 i0 = c * CH + (i64)threadIdx.x * VEC;
-        for (int kc = 0; kc < kn; ++kc) {
-            const double m = mean[k0 + kc], s = sd[k0 + kc];
-            if (i0 + VEC <= N) {
-                Pack<T, VEC> x = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + kc) * ldx);
+        if (i0 + VEC <= N) {
+            // all KC packs in flight before the first division (X and Z may be the same matrix: a thread only ever
+            // overwrites what it has loaded itself)
+            Pack<T, VEC> x[KC];
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) x.v[v] = (T)(((double)x.v[v] - m) / s);
-                st_pack_nt<T, VEC>(Z + i0 + (i64)(k0 + kc) * ldz, x);
-            } else {
-                for (int v = 0; v < VEC; ++v)
-                    if (i0 + v < N) Z[i0 + v + (i64)(k0 + kc) * ldz] = (T)(((double)X[i0 + v + (i64)(k0 + kc) * ldx] - m) / s);
-            }
+            for (int kc = 0; kc < KC; ++kc)
+                if (kc < kn) x[kc] = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + kc) * ldx);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+                if (kc < kn) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) x[kc].v[v] = (T)quot((double)x[kc].v[v] - m[kc], kc);
+                    st_pack_nt<T, VEC>(Z + i0 + (i64)(k0 + kc) * ldz, x[kc]);
+                }
+        } else {
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+                if (kc < kn)
+                    for (int v = 0; v < VEC; ++v)
+                        if (i0 + v < N)
+                            Z[i0 + v + (i64)(k0 + kc) * ldz] = (T)quot((double)X[i0 + v + (i64)(k0 + kc) * ldx] - m[kc], kc);
         }
+    }
+}
+
+// The same scale pass as one-shot workgroups on ONE contiguous column piece each (grid = (row pieces, K), the shape of
+// deflate_piece_kernel): used for 16-byte aligned columns.
+template <typename T, int VEC>
+__global__ __launch_bounds__(WG) void zscale_piece_kernel(const T *X, i64 ldx, T *Z, i64 ldz, i64 N,
+                                                          const double *__restrict__ mean, const double *__restrict__ sd) {
+    const i64 i0 = ((i64)blockIdx.x * WG + threadIdx.x) * VEC;
+    const int k = blockIdx.y;
+    const double m = mean[k], s = sd[k], r = 1.0 / s;
+    const bool fast = fabs(s) > 1e-150 && fabs(s) < 1e150;
+    auto quot = [&](double y) -> double {
+        if (!fast) return y / s;
+        const double q = y * r;
+        const double q1 = fma(fma(-q, s, y), r, q);
+        return (fabs(q) > 1e-290 && fabs(q) < 1e290) ? q1 : y / s;
+    };
+    const T *xs = X + (i64)k * ldx;
+    T *zs = Z + (i64)k * ldz;
+    if (i0 + VEC <= N) {
+        Pack<T, VEC> x = ld_pack_nt<T, VEC>(xs + i0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x.v[v] = (T)quot((double)x.v[v] - m);
+        st_pack_nt<T, VEC>(zs + i0, x);
+    } else {
+        for (i64 i = i0; i < N; ++i) zs[i] = (T)quot((double)xs[i] - m);
     }
 }
 

@@ -386,6 +386,41 @@ def test_device_z_scores(handle, oracle, po, N, K):
     assert np.abs(Z32.cpu().numpy() - oracle.z_scores(Xh.astype(np.float32).astype(np.float64))).max() < 5e-5
 
 
+@pytest.mark.parametrize("N,K", [(70001, 40), (513, 7), (3, 5), (1, 4), (200003, 33)])
+def test_one_sweep_statistics_are_stable(handle, N, K):
+    """mean and sd from ONE sweep (colmoments_kernel) on columns that break a naive sum-of-squares: offsets of 1e8 sd, an
+    outlier in the first row, a constant column; against the two-pass statistics in extended precision (src/pls.cpp:69-83
+    is two-pass) and against the two-pass kernels of the sharded form"""
+    rng = np.random.default_rng(N + K)
+    Xh = rng.standard_normal((N, K))
+    Xh[:, 0] += 1e8
+    Xh[:, 1 % K] = Xh[:, 1 % K] * 1e-3 - 4e6
+    Xh[0, 2 % K] = 1e7                        # the first row an outlier of 1e7 sd
+    if K > 3:
+        Xh[:, 3] = -17.5
+    Xh = np.asfortranarray(Xh)
+    Z, mean, sd = handle.colwise_z_scores(to_dev(Xh)); handle.synchronize()
+    xl = Xh.astype(np.longdouble)
+    mr = xl.mean(0)
+    sr = np.sqrt(((xl - mr) ** 2).sum(0) / (N - 1)) if N > 1 else np.full(K, np.nan)
+    assert np.allclose(mean.cpu().numpy(), mr.astype(np.float64), rtol=1e-13, atol=1e-15)
+    got = sd.cpu().numpy()
+    if N > 1:
+        assert np.allclose(got, sr.astype(np.float64), rtol=1e-12, atol=0), np.nanmax(np.abs(got / sr.astype(np.float64) - 1))
+        if K > 3:
+            assert got[3] == 0.0
+        zr = ((xl - mr) / sr).astype(np.float64)
+        ok = np.isfinite(zr)
+        assert np.abs(Z.cpu().numpy()[ok] - zr[ok]).max() < 1e-7   # (x - mean) itself is rounded at 1e8 * 2^-53
+        # the scale pass forms the quotient from a reciprocal and one residual step: correctly rounded, i.e. the bits of
+        # the reference's (x - mean) / sd (src/pls.cpp:103) for the same mean and sd
+        with np.errstate(divide="ignore", invalid="ignore"):
+            zq = (Xh - mean.cpu().numpy()) / got
+        assert np.array_equal(Z.cpu().numpy(), zq, equal_nan=True)
+    else:
+        assert np.isnan(got).all()
+
+
 def _random_shapes(count, seed):
     rng = np.random.default_rng(seed)
     shapes = []
