@@ -174,3 +174,31 @@ def test_very_tall_matrix_runs_fused(handle, po):
     for r0 in (0, (1 << 23) + 12345, N - 1000):
         rows = slice(r0, r0 + 1000)
         assert po.rel_fro(T[rows, 1].cpu().numpy(), X[rows].cpu().numpy() @ R[:, 1]) < 1e-11
+
+
+@pytest.mark.parametrize("N,K,dt,ld_extra,base_off", [
+    (1001, 37, "f64", 0, 0), (1001, 37, "f64", 0, 1), (4099, 20, "f64", 1, 0), (70001, 17, "f64", 0, 1),
+    (1001, 37, "f32", 0, 0), (1002, 40, "f32", 0, 1), (2051, 33, "f32", 0, 3), (70003, 5, "f32", 1, 2), (3, 5, "f64", 0, 1),
+])
+def test_z_scores_on_unaligned_layouts(handle, oracle, N, K, dt, ld_extra, base_off):
+    """column statistics and z-scores (src/pls.cpp:69-111) of matrices whose columns are not 16-byte aligned: the
+    element-wise instantiations of the one-sweep statistics and of the scale pass, out of place into an unaligned Z too"""
+    torch = _torch()
+    tdt = torch.float64 if dt == "f64" else torch.float32
+    rng = np.random.default_rng(N * 7 + K)
+    Xh = oracle.synth_x(0, N, K) * rng.uniform(0.1, 30, K) + rng.uniform(-50, 50, K)
+    if dt == "f32":
+        Xh = Xh.astype(np.float32).astype(np.float64)
+    X, keepx = _place(Xh, tdt, ld_extra, base_off)
+    Z, mean, sd = handle.colwise_z_scores(X); handle.synchronize()
+    xl = Xh.astype(np.longdouble)
+    mr = xl.mean(0); sr = np.sqrt(((xl - mr) ** 2).sum(0) / (N - 1))
+    assert np.allclose(mean.cpu().numpy(), mr.astype(np.float64), rtol=1e-13, atol=1e-13)
+    assert np.allclose(sd.cpu().numpy(), sr.astype(np.float64), rtol=1e-12)
+    zr = ((xl - mr) / sr).astype(np.float64)
+    assert np.abs(Z.cpu().numpy() - zr).max() < (1e-10 if dt == "f64" else 5e-6)
+    # in place on the unaligned matrix; nothing outside it is touched (the NaN guard cells stay NaN, the matrix is finite)
+    Z2, _, _ = handle.colwise_z_scores(X, inplace=True); handle.synchronize()
+    assert np.abs(X.cpu().numpy() - zr).max() < (1e-10 if dt == "f64" else 5e-6)
+    n_nan = int(torch.isnan(keepx).sum())
+    assert n_nan == keepx.numel() - N * K
