@@ -1629,27 +1629,43 @@ int zscores_device(pls_hip_context *c, const T *X, i64 ldx, i64 N, i64 n_total, 
     CHK(ensure(c, c->red2, (size_t)plsk::RED_SLICES * K * 8));
     double *part = (double *)c->part.p, *red = (double *)c->red2.p;
     const dim3 grid(G, nkg), blk(plsk::WG);
-    // Single rank: mean and sd from ONE sweep (colmoments_kernel: per-thread shifted sums merged pairwise) -- two sweeps of
-    // X (statistics, scale) for the z-scores instead of the reference's three.  Sharded: the reducer sums, it does not
-    // merge (count, mean, M2) triples; two passes as in the reference.
+    // Mean and sd from ONE sweep (colmoments_kernel: per-wave shifted sums merged pairwise) -- two sweeps of X
+    // (statistics, scale) for the z-scores instead of the reference's three.  Row-sharded: the shards' (count, mean, M2)
+    // triples meet in two all-reduces of K sums (colmoments_shard_kernel), as many as the two-pass form needs.  Every
+    // rank takes this branch or none (the environment decides, not the shard), an empty shard contributes zeros.
     static const bool one_pass = !(getenv("PLS_HIP_ZSCORE_ONE_PASS") && atoi(getenv("PLS_HIP_ZSCORE_ONE_PASS")) == 0);
-    const bool shifted = one_pass && !c->reducer && N > 0 && n_total == N;
+    const bool shifted = one_pass && (c->reducer || (N > 0 && n_total == N));
     if (shifted) {
         // all workgroups resident at once (5 per CU at 84 VGPRs): one round, no tail
         const int G1 = (int)std::min<i64>(nch, std::max<i64>(1, (5 * c->num_cu) / nkg));
-        CHK(ensure(c, c->part, (size_t)G1 * (3 * K + 1) * 8));
+        const bool sharded = c->reducer != nullptr;
+        CHK(ensure(c, c->part, (size_t)(G1 * (3 * (i64)K + 1) + (sharded ? 4 * (i64)K + 1 : 0)) * 8));
         part = (double *)c->part.p;
         double *cnt = part + (i64)G1 * 3 * K;
-        {
-            Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) + 2 * (i64)K * 8);
-            const dim3 g1(G1, nkg);
-            if (wide) hipLaunchKernelGGL((plsk::colmoments_kernel<T, FV, KC>), g1, blk, 0, c->stream, X, ldx, N, K, part, cnt);
-            else hipLaunchKernelGGL((plsk::colmoments_kernel<T, 1, KC>), g1, blk, 0, c->stream, X, ldx, N, K, part, cnt);
+        double *tri = sharded ? cnt + G1 : nullptr, *buf = sharded ? tri + 3 * (i64)K + 1 : nullptr;
+        const dim3 gk((K + plsk::WG - 1) / plsk::WG);
+        if (N > 0) {
+            {
+                Scope s(c, PLS_HIP_FAM_XTY, (i64)N * K * sizeof(T) + 2 * (i64)K * 8);
+                const dim3 g1(G1, nkg);
+                if (wide) hipLaunchKernelGGL((plsk::colmoments_kernel<T, FV, KC>), g1, blk, 0, c->stream, X, ldx, N, K, part, cnt);
+                else hipLaunchKernelGGL((plsk::colmoments_kernel<T, 1, KC>), g1, blk, 0, c->stream, X, ldx, N, K, part, cnt);
+                LAUNCH_CHECK(c);
+            }
+            hipLaunchKernelGGL(plsk::colmoments_finish_kernel, gk, blk, 0, c->stream, (const double *)part, (const double *)cnt, G1, K,
+                               mean, sd, tri);
             LAUNCH_CHECK(c);
+        } else {
+            HIPCHK(c, hipMemsetAsync(tri, 0, (size_t)(3 * (i64)K + 1) * 8, c->stream));
         }
-        hipLaunchKernelGGL(plsk::colmoments_finish_kernel, dim3((K + plsk::WG - 1) / plsk::WG), blk, 0, c->stream,
-                           (const double *)part, (const double *)cnt, G1, K, mean, sd);
-        LAUNCH_CHECK(c);
+        if (sharded) {
+            for (int step = 0; step < 3; ++step) {
+                hipLaunchKernelGGL(plsk::colmoments_shard_kernel, gk, blk, 0, c->stream, (const double *)tri, K, (double)n_total, step,
+                                   buf, mean, sd);
+                LAUNCH_CHECK(c);
+                if (step < 2) CHK(do_allreduce(c, buf, K));
+            }
+        }
     }
     for (int mode = shifted ? 2 : 0; mode < 2; ++mode) {
         if (N > 0) {

@@ -713,9 +713,12 @@ __global__ __launch_bounds__(WG) void colmoments_kernel(const T *__restrict__ X,
     }
 }
 
-// merge of the G workgroup triples of a column, in order (G <= a few thousand): mean[k], sd[k] = sqrt(M2 / (n - 1))
+// merge of the G workgroup triples of a column, in order (G <= a few thousand): mean[k], sd[k] = sqrt(M2 / (n - 1)).
+// With tri given (a row-sharded matrix): the shard's own triple instead, tri[0..2][k] = mean hi, mean lo, M2 and
+// tri[3 K] = its row count, for the two exchanges below.
 __global__ __launch_bounds__(WG) void colmoments_finish_kernel(const double *__restrict__ part, const double *__restrict__ cnt,
-                                                               int G, int K, double *__restrict__ mean, double *__restrict__ sd) {
+                                                               int G, int K, double *__restrict__ mean, double *__restrict__ sd,
+                                                               double *__restrict__ tri) {
     const int k = blockIdx.x * WG + threadIdx.x;
     if (k >= K) return;
     double na = cnt[0], ah = part[k], al = part[(i64)K + k], qa = part[2 * (i64)K + k];
@@ -726,8 +729,37 @@ __global__ __launch_bounds__(WG) void colmoments_finish_kernel(const double *__r
                       na * wb);
         na = nt;
     }
+    if (tri) {
+        tri[k] = ah; tri[(i64)K + k] = al; tri[2 * (i64)K + k] = qa;
+        if (k == 0) tri[3 * (i64)K] = na;
+        return;
+    }
     mean[k] = ah + al;
     sd[k] = sqrt((na < 2.0 ? 0.0 : qa) / (na - 1.0));
+}
+
+// Row-sharded statistics from the shards' triples with TWO all-reduces of K sums (the two-pass form needs two as well,
+// and a second sweep of X):
+//   step 0: buf[k] = n_r * mean_r[k]                         -> sum over ranks / n = the global mean g
+//   step 1: mean[k] = g;  buf[k] = M2_r + n_r (mean_r - g)^2  -> sum over ranks = SST about g
+//           (every term is >= 0, and an error d in g adds n d^2: second order, like the two-pass form)
+//   step 2: sd[k] = sqrt(SST / (n - 1))
+__global__ __launch_bounds__(WG) void colmoments_shard_kernel(const double *__restrict__ tri, int K, double n_total, int step,
+                                                              double *__restrict__ buf, double *__restrict__ mean,
+                                                              double *__restrict__ sd) {
+    const int k = blockIdx.x * WG + threadIdx.x;
+    if (k >= K) return;
+    const double nr = tri[3 * (i64)K];
+    if (step == 0) {
+        buf[k] = nr * (tri[k] + tri[(i64)K + k]);
+    } else if (step == 1) {
+        const double g = buf[k] / n_total;
+        mean[k] = g;
+        const double d = (tri[k] - g) + tri[(i64)K + k];
+        buf[k] = nr > 0.0 ? fma(nr * d, d, tri[2 * (i64)K + k]) : 0.0;
+    } else {
+        sd[k] = sqrt((n_total < 2.0 ? 0.0 : buf[k]) / (n_total - 1.0));
+    }
 }
 
 // Z[i,k] = (X[i,k] - mean[k]) / sd[k]   (src/pls.cpp:93-105: the division is by the UNGUARDED stdev,
