@@ -48,6 +48,10 @@ WORKLOADS = {
     # narrow matrices, 4.3 GB each (few columns per lane in the resident tile)
     "narrow32": (1 << 24, 32, 1, 20, "f64"), "narrow128": (1 << 22, 128, 1, 20, "f64"), "narrow256": (1 << 21, 256, 1, 20, "f64"),
 }
+WORKLOADS.update({
+    # beyond 4096 columns: row-pack tiles (512 column groups), 2.1 / 4.3 GB
+    "wide8k": (65536, 8192, 8, 30, "f32"), "wide6k64": (87381, 6144, 1, 20, "f64"), "wide8k64": (65536, 8192, 2, 20, "f64"),
+})
 TIGHT_LD = {"C3odd-", "C3odd+", "C4odd"}  # leading dimension = N (no padding to 16 bytes)
 
 

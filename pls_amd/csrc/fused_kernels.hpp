@@ -810,6 +810,15 @@ int deflate_score_mode(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) 
     const int e = edge_level<T>(X, ldx, CG, 4);
     return e < 0 ? 0 : (e == 0 ? 1 : 2);
 }
+// Can the caller's matrix be copied into short tiles (launch_retile / launch_retile_xty read it with the 256-byte-segment
+// tile) and every pass then run on the copy?  The checks of deflate_score_mode without its LDS limit on K.
+template <typename T>
+bool wide_source_ok(const T *X, i64 ldx, i64 N, const T *Tm) {
+    constexpr int V = 16 / sizeof(T);
+    constexpr int CG = 512 / ((256 / (int)sizeof(T)) / V);
+    if (N < 1 || !elem_aligned<T>(Tm) || (N + 16) * (i64)sizeof(T) >= (1ll << 31)) return false;
+    return edge_level<T>(X, ldx, CG, 4) >= 0;
+}
 template <typename T>
 bool deflate_score_covers(const T *X, i64 ldx, i64 N, int K, const T *Tm, i64 ldt) {
     return deflate_score_mode<T>(X, ldx, N, K, Tm, ldt) != 0;
@@ -895,7 +904,8 @@ int launch_xty_tiled(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 ts
 //   32  -> 16 lanes along the rows: 256-byte column segments (32 fp64 / 64 fp32 rows), K <= 1024 -- the shape
 //          that can also read the caller's column-major matrices at full rate;
 //   64, 128 -> 8 / 4 lanes along the rows (16 / 8 fp64, 32 / 16 fp32 rows), K <= 2048 / 4096: only for the
-//          row-tile-major working copy, where a tile is contiguous whatever its height.
+//          row-tile-major working copy, where a tile is contiguous whatever its height;
+//   256, 512 -> 2 / 1 lanes along the rows at 16 columns per lane: K <= 4096 / 8192.
 template <typename T, int CGX = 32>
 constexpr int tile_rows() { return (512 / CGX) * (16 / (int)sizeof(T)); }
 
@@ -944,7 +954,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     // 2^31: all CG groups of the workgroup, or -- EDGE -- the WAVE / RP groups of one wave
     int edge = edge_level<T>(X, ldx, CG, WAVE / (R / V));
     if (edge < 0 || (edge == 0 && tsx % V != 0) || (defl && tsd % V != 0)) return 1;
-    if (K > CG * ((CGX == 256 || CGX < 32) ? 16 : 32) || N < 1 || max_rows < 2) return 1;
+    if (K > CG * ((CGX >= 256 || CGX < 32) ? 16 : 32) || N < 1 || max_rows < 2) return 1;
     if ((N + V) * (i64)sizeof(T) >= (1ll << 31)) return 1;  // one descriptor per score column
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if (rdst > 0 && (CGX != 32 || !defl || rdst < V || R % rdst != 0 ||
@@ -962,6 +972,8 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         // passes on the tiled copy: ONE (2.7 % faster than two at 16 columns per lane, 4 % at 4, equal at 8 -- less
         // in flight is better for the read/write mix, tools/fused_grid_sweep.py); 32 columns per lane (256 VGPRs)
         // never fit two.
+        // (512 column groups: the operand vector of a read-only pass is 64 KB of LDS, two workgroups fit; a deflating pass
+        // holds p_prev as well, 128 KB)
         const int per_cu = (K <= CG * 16 && !defl) ? 2 : 1;
         grid = grid_hint > 0 ? grid_hint : per_cu * (i64)num_cu;
         grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows - 1);
@@ -984,7 +996,8 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
 #define FUSED_CASE(CPT_)                                                                                                  \
     do {                                                                                                                  \
         const size_t dyn = ((size_t)2 * CG * CPT_ * sizeof(double) > 48 * 1024) ? (size_t)2 * CG * CPT_ * sizeof(double) : 0; \
-        if (defl) FUSED_EDGE(CPT_, true, dyn); else FUSED_EDGE(CPT_, false, dyn);                                         \
+        if (defl) FUSED_EDGE(CPT_, true, dyn);                                                                            \
+        else FUSED_EDGE(CPT_, false, (CGX >= 512 ? dyn / 2 : dyn));   /* (no p_prev: the second half is never touched) */ \
     } while (0)
         if constexpr (CGX == 32) {
             if (rdst > 0) {  // first deflation into shorter tiles: only the 32-columns-per-lane shape needs it
@@ -1006,7 +1019,9 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         } else if constexpr (CGX == 16) {
             FUSED_CASE(16);
         } else {
-            FUSED_CASE(16);  // 256 column groups x 2 row lanes: K <= 4096 at 16 columns per lane
+            // 256 column groups x 2 row lanes: K <= 4096 at 16 columns per lane;  512 x 1 (a tile = ONE row pack of every
+            // column, 16 bytes per column: the copy is row-pack-major): K <= 8192
+            FUSED_CASE(16);
         }
 #undef FUSED_CASE
 #undef FUSED_EDGE

@@ -792,7 +792,16 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     const int wide_mode = (c->opt_fuse && !fused_fit && N > 0) ? plsk::deflate_score_mode<T>(X, ldx, N, K, Tm, ldt) : 0;
     // wide matrices (no resident tile): deflation + score in one sweep, loading in a second read
     const bool semi_fit = nipals && wide_mode != 0;
-    const bool tiled_work = nipals && (fused_fit || semi_fit) && c->opt_work_layout != 0;
+    // Beyond the semi-fused sweep's reach (its w and p_prev need 16 K bytes of LDS: K <= 4608) and up to 8192 columns the
+    // copy's tiles are ONE row pack high (512 column groups x 16 columns per lane): the copy is made in the X^T Y sweep
+    // (retile_xty) and every component runs fused on it -- instead of 4 N K s (NIPALS) / 2 N K s (KERNEL) per component
+    // through the one-product kernels.
+    static const bool wide16 = !(getenv("PLS_HIP_WIDE16") && atoi(getenv("PLS_HIP_WIDE16")) == 0);
+    static const bool wide512 = !(getenv("PLS_HIP_WIDE512") && atoi(getenv("PLS_HIP_WIDE512")) == 0);  // A/B measurements only
+    const bool wide_src = wide512 && wide16 && c->opt_fuse && !fused_fit && N > 0 && K <= 512 * 16 && plsk::wide_source_ok<T>(X, ldx, N, Tm);
+    const bool wide_only = nipals && wide_src && K > 256 * 16 && M <= 8 && A >= 3 && c->opt_work_layout != 0 &&
+                           !(getenv("PLS_HIP_RETILE_XTY") && atoi(getenv("PLS_HIP_RETILE_XTY")) == 0);
+    const bool tiled_work = nipals && (fused_fit || semi_fit || wide_only) && c->opt_work_layout != 0;
     // Row-tile-major tiles are contiguous whatever their height, so for 1024 < K <= 4096 the working copy uses
     // SHORTER tiles (8-32 rows) that do fit the registers of a CU: from the third component on the fully fused
     // pass runs again (2 N K s per component instead of the semi-fused 3 N K s).  Only the first deflation has
@@ -814,14 +823,14 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     static const int copy_min_al = getenv("PLS_HIP_COPY_MIN_ALIGNED") ? atoi(getenv("PLS_HIP_COPY_MIN_ALIGNED")) : 10;
     const bool copy_fit = fused_fit && M <= 8 &&
                           A >= (vec_ok<T>(X, ldx, FVX) ? (K <= 32 * 16 ? copy_min_al : 3 * copy_min_al + 2) : copy_min);
-    bool retile_fit = !nipals && !type2 && A >= 3 && c->opt_work_layout != 0 && ((wide_mode != 0 && K <= 128 * 32) || copy_fit);
+    bool retile_fit = !nipals && !type2 && A >= 3 && c->opt_work_layout != 0 &&
+                      ((wide_mode != 0 && K <= 128 * 32) || (wide_src && K > 128 * 32) || copy_fit);
     // column groups of the short tiles of a wide matrix (1024 < K <= 4096): 16 columns per lane in 128 / 256 groups
     // (8-row fp32 / 4-row fp64 tiles at K <= 4096) -- the register shape of the headline kernel, two workgroups per CU
     // on read-only passes.  Config 4: read+write pass 0.766 -> 0.710 ms (0.70 -> 0.76 of peak), read-only pass
     // 0.364 -> 0.324 ms (0.74 -> 0.83) against 32 columns per lane in 64 / 128 groups (PLS_HIP_WIDE16=0, the round-1 shape).
-    static const bool wide16 = !(getenv("PLS_HIP_WIDE16") && atoi(getenv("PLS_HIP_WIDE16")) == 0);
     const int wide_groups = fused_fit ? (K <= 32 * 16 ? tall_cg : 64)  // (the copy of a matrix the resident tile covers)
-                            : wide16 ? (K <= 128 * 16 ? 128 : (K <= 256 * 16 ? 256 : 0))
+                            : wide16 ? (K <= 128 * 16 ? 128 : (K <= 256 * 16 ? 256 : ((wide_src && (!nipals || wide_only)) ? 512 : 0)))
                                      : (K <= 64 * 32 ? 64 : (K <= 128 * 32 ? 128 : 0));
     if (retile_fit) {  // the copy is optional: without room for it the one-product kernels do the job
         const i64 wr = (512 / wide_groups) * (i64)(16 / sizeof(T));
@@ -830,7 +839,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             c->err.clear();
         }
     }
-    const int wide_cg = ((semi_fit && tiled_work) || retile_fit) ? wide_groups : 0;
+    const int wide_cg = ((semi_fit && tiled_work) || retile_fit || wide_only) ? wide_groups : 0;
     // 512 < K <= 1024: the resident tile of the caller's layout needs 32 columns per lane (one 8-wave workgroup per
     // CU, 5.7-5.85 TB/s); on the tiled copy the same K fits half-height tiles at 16 columns per lane (6.0 TB/s).
     // Component 0 reads X with the tall tile, the first deflation reads X tall and writes the short tiles (rdst),
@@ -856,7 +865,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // NIPALS on a wide matrix takes the same first sweep: its working copy is then complete before the first component,
     // which runs fused on it, as every later one does in place (instead of two one-product passes over X for component 0
     // and the semi-fused sweep + a loading pass for component 1: config 4 36.6 -> 36.0 ms per fit)
-    const bool nip_copy = nipals && semi_fit && tiled_work && wide_cg != 0 && A >= 3;
+    const bool nip_copy = nipals && (semi_fit || wide_only) && tiled_work && wide_cg != 0 && A >= 3;
     if (!use_pre && N > 0 && (retile_fit || nip_copy) && M <= 8) {
         // the copy into tiles and X^T Y in ONE sweep over the caller's matrix (instead of retile_kernel + the X^T Y pass)
         static const bool rx_on = !(getenv("PLS_HIP_RETILE_XTY") && atoi(getenv("PLS_HIP_RETILE_XTY")) == 0);
@@ -875,6 +884,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             retiled = true;
         }
     }
+    if (wide_only && !retiled && N > 0) return fail(c, PLS_HIP_ERR_DEVICE, "copy into row-pack tiles failed");
     if (retiled) {
     } else if (use_pre) {
         hipLaunchKernelGGL(plsk::fill_slices_kernel, dim3((unsigned)((L0 + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
@@ -1034,7 +1044,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
 #define WIDE_PASS(CG_) plsk::launch_fused_pass<T, CG_>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v, tprev, pprev, \
                                                         Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid, 0, true)
                     rc = wide_cg == 8 ? WIDE_PASS(8) : (wide_cg == 16 ? WIDE_PASS(16) : (wide_cg == 32 ? WIDE_PASS(32)
-                         : (wide_cg == 64 ? WIDE_PASS(64) : (wide_cg == 128 ? WIDE_PASS(128) : WIDE_PASS(256)))));
+                         : (wide_cg == 64 ? WIDE_PASS(64) : (wide_cg == 128 ? WIDE_PASS(128) : (wide_cg == 256 ? WIDE_PASS(256) : WIDE_PASS(512))))));
 #undef WIDE_PASS
                     if (rc != 0) s.on = false;
                 }

@@ -49,7 +49,11 @@ SHAPES = [
     (515, 1500, 2, 5, "f64", 0, 0),     # wide: short tiles of 8 fp64 rows (128 column groups)
     (515, 3000, 1, 5, "f64", 0, 1),     # wide: 4-row tiles (256 column groups)
     (1031, 2500, 2, 4, "f32", 0, 1),    # wide fp32
-    (261, 5000, 1, 4, "f64", 0, 0),     # beyond the resident tiles: semi-fused sweeps on the column-major copy
+    (261, 5000, 1, 4, "f64", 0, 0),     # beyond 4096 columns: row-pack tiles of the copy (512 column groups)
+    (131, 8192, 2, 5, "f64", 0, 1),     # ... the widest they take, unaligned source
+    (263, 6000, 8, 4, "f32", 0, 0),
+    (130, 4100, 3, 3, "f32", 1, 2),
+    (75, 9000, 1, 4, "f64", 0, 0),      # beyond every resident tile: the one-product kernels
     # odd N with every tile height of the working copy and enough components for an error in one row's contribution to
     # show (a lane just behind the swept rows once picked up t_prev of the tail row: 1e-5 in P from the second component on)
     (1365, 1024, 4, 9, "f64", 0, 0),    # 16-row tiles (512 < K <= 1024)
@@ -126,8 +130,11 @@ def test_edge_shapes_take_the_one_sweep_plan(handle, oracle, po, plan, monkeypat
     elif K <= 4096:
         # short tiles: one copy into them (in the same sweep as X^T Y) + A fused passes, read-only (KERNEL) or in place (NIPALS)
         assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
+    elif K <= 8192:
+        # row-pack tiles: the same plan (one copy in the X^T Y sweep + A fused passes)
+        assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
     else:
-        assert (tm["launches"]["deflate"] == A - 1) if nipals else True, tm["launches"]
+        assert tm["launches"]["fused"] == 0, tm["launches"]
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
