@@ -905,7 +905,7 @@ int launch_xty_tiled(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 ts
 //          that can also read the caller's column-major matrices at full rate;
 //   64, 128 -> 8 / 4 lanes along the rows (16 / 8 fp64, 32 / 16 fp32 rows), K <= 2048 / 4096: only for the
 //          row-tile-major working copy, where a tile is contiguous whatever its height;
-//   256, 512 -> 2 / 1 lanes along the rows at 16 columns per lane: K <= 4096 / 8192.
+//   256, 512 -> 2 / 1 lanes along the rows at 16 columns per lane: K <= 4096 / 8192 (512, read-only: 32 per lane, K <= 16384).
 template <typename T, int CGX = 32>
 constexpr int tile_rows() { return (512 / CGX) * (16 / (int)sizeof(T)); }
 
@@ -954,7 +954,8 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     // 2^31: all CG groups of the workgroup, or -- EDGE -- the WAVE / RP groups of one wave
     int edge = edge_level<T>(X, ldx, CG, WAVE / (R / V));
     if (edge < 0 || (edge == 0 && tsx % V != 0) || (defl && tsd % V != 0)) return 1;
-    if (K > CG * ((CGX >= 256 || CGX < 32) ? 16 : 32) || N < 1 || max_rows < 2) return 1;
+    // (512 groups: 32 columns per lane only for read-only passes -- v alone is 128 KB of LDS there, p_prev would not fit)
+    if (K > CG * ((CGX == 256 || CGX < 32 || (CGX == 512 && defl)) ? 16 : 32) || N < 1 || max_rows < 2) return 1;
     if ((N + V) * (i64)sizeof(T) >= (1ll << 31)) return 1;  // one descriptor per score column
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if (rdst > 0 && (CGX != 32 || !defl || rdst < V || R % rdst != 0 ||
@@ -1018,10 +1019,13 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
             else FUSED_CASE(16);
         } else if constexpr (CGX == 16) {
             FUSED_CASE(16);
+        } else if constexpr (CGX == 512) {
+            // 512 x 1: a tile = ONE row pack of every column, 16 bytes per column (the copy is row-pack-major): K <= 8192
+            // at 16 columns per lane; read-only passes up to K = 16384 at 32 (256 VGPRs, one workgroup per CU)
+            if (K <= CG * 16) FUSED_CASE(16);
+            else FUSED_EDGE(32, false, (size_t)CG * 32 * sizeof(double));
         } else {
-            // 256 column groups x 2 row lanes: K <= 4096 at 16 columns per lane;  512 x 1 (a tile = ONE row pack of every
-            // column, 16 bytes per column: the copy is row-pack-major): K <= 8192
-            FUSED_CASE(16);
+            FUSED_CASE(16);  // 256 column groups x 2 row lanes: K <= 4096 at 16 columns per lane
         }
 #undef FUSED_CASE
 #undef FUSED_EDGE

@@ -21,6 +21,7 @@
 #include "defer_kernels.hpp"
 #include "small_kernels.hpp"
 #include "coop_update.hpp"
+#include "wide1_update.hpp"
 #include "largem_kernels.hpp"
 #include "tiny_kernels.hpp"
 #include "stream_kernels.hpp"
@@ -60,7 +61,7 @@ struct pls_hip_context {
     // PLS_HIP_OPT_GRAPH: the last repeated device-memory fit as an executable graph (one entry: a loop of identical fits)
     std::vector<uint64_t> graph_key, graph_seen;
     hipGraphExec_t graph_exec = nullptr;
-    DevBuf zeros, part, sspart, red, red2, xx, xyp, praw, xy, v, cs, coop, lm, gxx, gxy, tab, work, cvidx, cvx, cvy, cvws, cve, cvtx, cvty, cvtt, cvm, cvkeep, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
+    DevBuf zeros, part, sspart, xbpart, wide1, red, red2, xx, xyp, praw, xy, v, cs, coop, lm, gxx, gxy, tab, work, cvidx, cvx, cvy, cvws, cve, cvtx, cvty, cvtt, cvm, cvkeep, hX, hY, hT, hW, hP, hQ, hR, hB, hIn, hOut;
     std::string err;
     // profiling
     std::vector<hipEvent_t> ev_pool;  // grows until pls_hip_get_timing harvests and recycles it
@@ -275,6 +276,35 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
     bool wide = vec_ok<T>(X, ldx, FV) && vec_ok<T>(out, ldo, FV);
     // keep >= ~4 workgroups per CU in flight: narrow the per-lane access on short matrices
     if (wide && N / ((i64)FV * plsk::WG) < 4 * (i64)c->num_cu) wide = false;
+    // One score column of a short, wide matrix: the rows alone give fewer workgroups than there are CUs -- split the
+    // columns as well (xb_split_kernel); ~3 workgroups per CU, at least 128 columns each.
+    static const bool split_on = !(getenv("PLS_HIP_XB_SPLIT") && atoi(getenv("PLS_HIP_XB_SPLIT")) == 0);
+    if (C == 1 && split_on && N > 0 && K >= 1024) {
+        const bool v2 = vec_ok<T>(X, ldx, FV) && (N + (i64)FV * plsk::WG - 1) / ((i64)FV * plsk::WG) >= 8;
+        const i64 per = (i64)plsk::WG * (v2 ? FV : 1);
+        const i64 rg = (N + per - 1) / per;
+        if (rg < 2 * (i64)c->num_cu) {
+            int KS = (int)std::min<i64>(K / 128, (3 * (i64)c->num_cu + rg - 1) / rg);
+            const int kper = (K + KS - 1) / KS;
+            KS = (K + kper - 1) / kper;
+            const i64 ldp = (N + 63) / 64 * 64;
+            if (KS >= 2 && KS <= 65535 && ensure(c, c->xbpart, (size_t)KS * ldp * 8) == PLS_HIP_OK) {
+                Scope s(c, PLS_HIP_FAM_XB, (i64)N * K * sizeof(T) + (i64)N * sizeof(T) + (i64)K * 8);
+                const dim3 g((unsigned)rg, (unsigned)KS), blk(plsk::WG);
+                double *xp = (double *)c->xbpart.p;
+                if (v2) hipLaunchKernelGGL((plsk::xb_split_kernel<T, FV>), g, blk, 0, c->stream, X, ldx, N, K, kper, Bm, xp, ldp);
+                else hipLaunchKernelGGL((plsk::xb_split_kernel<T, 1>), g, blk, 0, c->stream, X, ldx, N, K, kper, Bm, xp, ldp);
+                LAUNCH_CHECK(c);
+                const int fb = (int)((N + 63) / 64);
+                hipLaunchKernelGGL((plsk::xb_split_finish_kernel<T>), dim3(fb), blk, 0, c->stream, (const double *)xp, ldp, KS, N, out,
+                                   sspart);
+                LAUNCH_CHECK(c);
+                if (sspart && nss) *nss = fb;
+                return PLS_HIP_OK;
+            }
+            c->err.clear();
+        }
+    }
     int c0 = 0;
     while (c0 < C) {
         const int rem = C - c0;
@@ -535,6 +565,24 @@ int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, 
     static const bool mid_on = !(getenv("PLS_HIP_MID_UPDATE") && atoi(getenv("PLS_HIP_MID_UPDATE")) == 0);
     if (M > plsk::MMAX || (mid_on && M > 8 && (i64)K * M >= 16384))
         return launch_update_large(c, red, XY, W, P, Q, R, v, K, M, A, a, nip);
+    // One response on very many columns: element-wise work and K-long sums on up to 128 workgroups, two launches
+    // (wide1_update.hpp) instead of one workgroup walking K (+ one workgroup per p_j^T w of the r recurrence)
+    static const int wide1_min = getenv("PLS_HIP_WIDE1_MIN") ? atoi(getenv("PLS_HIP_WIDE1_MIN")) : 8192;
+    int w1g = 0, w1e = 0;
+    if (M == 1 && K >= wide1_min && A <= 4096 && plsk::wide1_geometry(K, &w1g, &w1e)) {
+        CHK(ensure(c, c->wide1, (size_t)((i64)(A + 2) * w1g) * 8));
+        double *w1part = (double *)c->wide1.p, *w1q = w1part + (i64)(A + 1) * w1g;
+        Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * 3 + (i64)K * (2 * (a + 2)) + K) * 8);
+        hipLaunchKernelGGL(plsk::wide1_a_kernel, dim3(w1g), dim3(plsk::W1_WG), (size_t)plsk::W1_WG * w1e * 8, c->stream, red, XY, P, Q,
+                           K, A, a, w1e, (const double *)w1q, w1part);
+        LAUNCH_CHECK(c);
+        if (n < A) {
+            hipLaunchKernelGGL(plsk::wide1_b_kernel, dim3(w1g), dim3(plsk::W1_WG), (size_t)(n + 1) * 8, c->stream, (const double *)XY, W,
+                               R, v, K, n, w1e, nip, (const double *)w1part, w1q);
+            LAUNCH_CHECK(c);
+        }
+        return PLS_HIP_OK;
+    }
     // PLS_HIP_COOP_UPDATE=0 in the environment keeps the single-workgroup kernel (A/B measurements only)
     static const bool coop_on = !(getenv("PLS_HIP_COOP_UPDATE") && atoi(getenv("PLS_HIP_COOP_UPDATE")) == 0);
     if (coop_on && plsk::coop_update_covers(K, M) && A <= 4096) {
@@ -765,7 +813,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     const i64 prow = max_partial_rows(c, N, K);
     CHK(ensure(c, c->part, (size_t)prow * (size_t)std::max<i64>(L0, K) * 8));
     // t^T t partials: one per workgroup of whichever kernel forms the scores (narrow X*v: N/256; tile kernels: their grid)
-    const i64 ssmax = std::max<i64>(std::max<i64>((N + plsk::WG - 1) / plsk::WG, 1), max_partial_rows(c, N, K));
+    // (the split score kernel of short, wide matrices leaves one partial per 64 rows)
+    const i64 ssmax = std::max<i64>(std::max<i64>(K >= 1024 ? (N + 63) / 64 : (N + plsk::WG - 1) / plsk::WG, 1), max_partial_rows(c, N, K));
     CHK(ensure(c, c->sspart, (size_t)ssmax * 8));
     CHK(ensure(c, c->xy, (size_t)L0 * 8));
     CHK(ensure(c, c->v, (size_t)K * 8));
@@ -798,8 +847,10 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // through the one-product kernels.
     static const bool wide16 = !(getenv("PLS_HIP_WIDE16") && atoi(getenv("PLS_HIP_WIDE16")) == 0);
     static const bool wide512 = !(getenv("PLS_HIP_WIDE512") && atoi(getenv("PLS_HIP_WIDE512")) == 0);  // A/B measurements only
-    const bool wide_src = wide512 && wide16 && c->opt_fuse && !fused_fit && N > 0 && K <= 512 * 16 && plsk::wide_source_ok<T>(X, ldx, N, Tm);
-    const bool wide_only = nipals && wide_src && K > 256 * 16 && M <= 8 && A >= 3 && c->opt_work_layout != 0 &&
+    // (read-only passes take 32 columns per lane there: the KERNEL plan up to 16384 columns)
+    const bool wide_src = wide512 && wide16 && c->opt_fuse && !fused_fit && N > 0 && K <= 512 * (nipals ? 16 : 32) &&
+                          plsk::wide_source_ok<T>(X, ldx, N, Tm);
+    const bool wide_only = nipals && wide_src && K > 256 * 16 && K <= 512 * 16 && M <= 8 && A >= 3 && c->opt_work_layout != 0 &&
                            !(getenv("PLS_HIP_RETILE_XTY") && atoi(getenv("PLS_HIP_RETILE_XTY")) == 0);
     const bool tiled_work = nipals && (fused_fit || semi_fit || wide_only) && c->opt_work_layout != 0;
     // Row-tile-major tiles are contiguous whatever their height, so for 1024 < K <= 4096 the working copy uses
@@ -1265,7 +1316,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->red, &h->red2, &h->xx, &h->xyp, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
+    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->xbpart, &h->wide1, &h->red, &h->red2, &h->xx, &h->xyp, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
                       &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->cvtx, &h->cvty, &h->cvtt, &h->cvm, &h->cvkeep, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)

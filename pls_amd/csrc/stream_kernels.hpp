@@ -105,6 +105,92 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
 }
 
 // ------------------------------------------------------------------------------------
+// t = X v for SHORT, WIDE matrices (few rows, very many columns: N = 512, K = 50,000 is a usual shape of the method).
+// xb_kernel parallelises over rows only -- N / 256 workgroups, TWO of them for 512 rows, each walking all K columns: 3.5 ms
+// for 200 MB.  Here the columns are split as well: grid = (row groups, KS column ranges), a thread owns VEC rows over the
+// columns [k_lo, k_hi) of its range and leaves a partial score, part[ks * ldp + i]; xb_split_finish_kernel sums the KS
+// partials of a row in range order (bit-reproducible), rounds to the storage type and forms the t^T t partials.
+// ------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(WG) void xb_split_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int kper,
+                                                      const double *__restrict__ v, double *__restrict__ part, i64 ldp) {
+    const i64 i0 = ((i64)blockIdx.x * WG + threadIdx.x) * VEC;
+    const int k_lo = blockIdx.y * kper, k_hi = min(K, k_lo + kper);
+    double acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
+    if (i0 + VEC <= N) {
+        const T *xp = X + i0;
+        constexpr int U = 8;
+        int k = k_lo;
+        for (; k + U <= k_hi; k += U) {
+            Pack<T, VEC> x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = ld_pack_nt<T, VEC>(xp + (i64)(k + u) * ldx);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double b = v[k + u];  // wave-uniform: scalar load
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fma((double)x[u].v[e], b, acc[e]);
+            }
+        }
+        for (; k < k_hi; ++k) {
+            const Pack<T, VEC> x = ld_pack_nt<T, VEC>(xp + (i64)k * ldx);
+            const double b = v[k];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = fma((double)x.v[e], b, acc[e]);
+        }
+    } else if (i0 < N) {
+        for (int k = k_lo; k < k_hi; ++k) {
+            const double b = v[k];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (i0 + e < N) acc[e] = fma((double)X[i0 + e + (i64)k * ldx], b, acc[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+        if (i0 + e < N) part[(i64)blockIdx.y * ldp + i0 + e] = acc[e];
+}
+
+// t[i] = sum over the KS ranges, in order; workgroup = 64 rows x 4 interleaved sets of ranges (LDS for the last step).
+// sspart[blockIdx.x] = sum of the workgroup's t^2 (as stored), when asked for.
+template <typename T>
+__global__ __launch_bounds__(WG) void xb_split_finish_kernel(const double *__restrict__ part, i64 ldp, int KS, i64 N,
+                                                             T *__restrict__ out, double *__restrict__ sspart) {
+    __shared__ double sh[4][64];
+    __shared__ double red[WG / WAVE];
+    const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const i64 i = (i64)blockIdx.x * 64 + r;
+    // set q sums the ranges [q * per, (q + 1) * per): contiguous, so that the order of the whole sum is the range order
+    const int per = (KS + 3) / 4, lo = q * per, hi = min(KS, lo + per);
+    double s = 0.0;
+    if (i < N) {
+        int ks = lo;
+        for (; ks + 8 <= hi; ks += 8) {  // 8 loads in flight, added in range order
+            double pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pv[u] = part[(i64)(ks + u) * ldp + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += pv[u];
+        }
+        for (; ks < hi; ++ks) s += part[(i64)ks * ldp + i];
+    }
+    sh[q][r] = s;
+    __syncthreads();
+    double ss = 0.0;
+    if (q == 0 && i < N) {
+        const T t = (T)(((sh[0][r] + sh[1][r]) + sh[2][r]) + sh[3][r]);
+        out[i] = t;
+        ss = (double)t * (double)t;
+    }
+    if (sspart) {
+        ss = block_sum<WG / WAVE>(ss, red);
+        if (threadIdx.x == 0) sspart[blockIdx.x] = ss;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // out(N x ncols) = X * Bm for 4 < ncols <= 16 NB columns on the matrix cores (scores T = X R,
 // src/pls.cpp:439-442; fitted values X B :449-451).  X*Bm -- unlike X^T Y -- is MFMA-shaped as it lies in
 // memory: the M dimension of v_mfma_f64_16x16x4_f64 runs along the ROWS of X, the contiguous direction, so

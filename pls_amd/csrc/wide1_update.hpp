@@ -1,0 +1,129 @@
+// Component update of a SINGLE-response fit on very many columns (src/pls.cpp:403-416, :427-429 with M = 1), spread over
+// the chip.  component_update_kernel walks the K-sized vectors through ONE workgroup and the r recurrence needs its n
+// dot products p_j^T w on top (rotate_dots_kernel: one workgroup per j): 143 + 57 us per component at K = 50,000 -- more
+// than the two passes over a 512 x 50,000 matrix (35 + 48 us).  With one response the eigenproblem of :405-408 is 1 x 1,
+// w = XY / |XY|, and the update is element-wise work plus three kinds of K-long sums, which fall on the two launch
+// boundaries of a two-kernel form (no in-launch exchange, no co-residency requirement):
+//
+//   wide1_a_kernel   q_a = (sum of the q partials the PREVIOUS launch left) / tt                       (:428)
+//                    p_a = red / tt (:427),  XY -= (p q) tt (:429)
+//                    partials of |XY|^2 and of p_j^T XY, j <= a      -> part[(1 + j) * G + workgroup]
+//   wide1_b_kernel   totals (every workgroup, same order, same bits),  w = XY / |XY| (:404, :411),
+//                    c_j = (p_j^T XY) / |XY| = p_j^T w (:415),  r = w - sum_j c_j r_j in the reference's order (:412-416),
+//                    q partial r^T XY for the next component        -> qpart[workgroup]
+//
+// A workgroup owns a contiguous slice of 256 E columns (G <= 128 workgroups); the slice of XY stays in LDS between the
+// element-wise step and the n dot products, which the four waves share out by j.  Every total is an index-ordered sum of
+// workgroup partials: bit-reproducible, identical on every rank of a sharded fit.
+#pragma once
+#include "small_kernels.hpp"
+
+namespace plsk {
+
+constexpr int W1_WG = 256, W1_MAXG = 128;
+
+// a, red, nipals: as component_update_kernel (a = -1: prologue, XY = reduced X^T Y).  E: columns per thread.
+__global__ __launch_bounds__(W1_WG) void wide1_a_kernel(const double *__restrict__ red, double *__restrict__ XY, double *P,
+                                                        double *__restrict__ Q, int K, int A, int a, int E,
+                                                        const double *__restrict__ qpart, double *__restrict__ part) {
+    extern __shared__ double xs[];  // [W1_WG * E] this workgroup's slice of the new XY
+    __shared__ double sred[W1_WG / WAVE];
+    const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int k0 = wg * W1_WG * E, kn = min(W1_WG * E, K - k0);  // the slice [k0, k0 + kn)
+    const int n = a + 1;
+    double ss = 0.0;
+    if (a >= 0) {
+        const double tt = red_sum(red, K + 1, K);
+        const double qs = block_sum<W1_WG / WAVE>(tid < G ? qpart[tid] : 0.0, sred);
+        const double q = qs / tt;
+        if (wg == 0 && tid == 0) Q[a] = q;
+        for (int i = tid; i < kn; i += W1_WG) {
+            const int k = k0 + i;
+            const double p = red_sum(red, K + 1, k) / tt;
+            P[k + (i64)a * K] = p;
+            const double x = XY[k] - (p * q) * tt;
+            XY[k] = x;
+            xs[i] = x;
+            ss = fma(x, x, ss);
+        }
+    } else {
+        for (int i = tid; i < kn; i += W1_WG) {
+            const double x = red_sum(red, K, k0 + i);
+            XY[k0 + i] = x;
+            xs[i] = x;
+            ss = fma(x, x, ss);
+        }
+    }
+    if (n >= A) return;
+    ss = block_sum<W1_WG / WAVE>(ss, sred);  // (its barriers also publish xs and this launch's column of P to the workgroup)
+    if (tid == 0) part[wg] = ss;
+    for (int j = wv; j < n; j += W1_WG / WAVE) {
+        const double *pj = P + (i64)j * K + k0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int i = lane;
+        for (; i + 3 * WAVE < kn; i += 4 * WAVE) {
+            s0 = fma(pj[i], xs[i], s0);
+            s1 = fma(pj[i + WAVE], xs[i + WAVE], s1);
+            s2 = fma(pj[i + 2 * WAVE], xs[i + 2 * WAVE], s2);
+            s3 = fma(pj[i + 3 * WAVE], xs[i + 3 * WAVE], s3);
+        }
+        for (; i < kn; i += WAVE) s0 = fma(pj[i], xs[i], s0);
+        const double s = wave_sum((s0 + s1) + (s2 + s3));
+        if (lane == 0) part[(i64)(1 + j) * G + wg] = s;
+    }
+}
+
+// n = a + 1 >= 0 is the component whose w and r are formed (n < A).  cs: dynamic LDS, n + 1 doubles.
+__global__ __launch_bounds__(W1_WG) void wide1_b_kernel(const double *__restrict__ XY, double *__restrict__ W, double *R,
+                                                        double *__restrict__ vnext, int K, int n, int E, int nipals,
+                                                        const double *__restrict__ part, double *__restrict__ qpart) {
+    extern __shared__ double cs[];  // [n + 1]: |XY|^2, then p_j^T XY
+    __shared__ double sred[W1_WG / WAVE];
+    const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
+    const int k0 = wg * W1_WG * E, kn = min(W1_WG * E, K - k0);
+    for (int t = tid; t <= n; t += W1_WG) {
+        double s = 0.0;
+        for (int g = 0; g < G; ++g) s += part[(i64)t * G + g];
+        cs[t] = s;
+    }
+    __syncthreads();
+    const double nrm = sqrt(cs[0]);
+    __syncthreads();
+    for (int t = tid; t < n; t += W1_WG) cs[1 + t] /= nrm;  // c_j = p_j^T w
+    __syncthreads();
+    double qa = 0.0;
+    double *wn = W + (i64)n * K, *rn = R + (i64)n * K;
+    for (int i = tid; i < kn; i += W1_WG) {
+        const int k = k0 + i;
+        const double x = XY[k];
+        const double w = x / nrm;
+        wn[k] = w;
+        double r = w;
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {  // same subtraction order as the reference, loads issued together
+            const double r0 = R[k + (i64)j * K], r1 = R[k + (i64)(j + 1) * K];
+            const double r2 = R[k + (i64)(j + 2) * K], r3 = R[k + (i64)(j + 3) * K];
+            r -= cs[1 + j] * r0;
+            r -= cs[2 + j] * r1;
+            r -= cs[3 + j] * r2;
+            r -= cs[4 + j] * r3;
+        }
+        for (; j < n; ++j) r -= cs[1 + j] * R[k + (i64)j * K];
+        rn[k] = r;
+        vnext[k] = nipals ? w : r;
+        qa = fma(r, x, qa);
+    }
+    qa = block_sum<W1_WG / WAVE>(qa, sred);
+    if (tid == 0) qpart[wg] = qa;
+}
+
+// geometry: E columns per thread so that at most W1_MAXG workgroups cover K; false = not this path (LDS slice too large)
+inline bool wide1_geometry(int K, int *G, int *E) {
+    const int e = (K + W1_WG * W1_MAXG - 1) / (W1_WG * W1_MAXG);
+    if ((size_t)W1_WG * e * 8 > 48 * 1024) return false;
+    *E = e;
+    *G = (K + W1_WG * e - 1) / (W1_WG * e);
+    return true;
+}
+
+}  // namespace plsk

@@ -53,7 +53,13 @@ SHAPES = [
     (131, 8192, 2, 5, "f64", 0, 1),     # ... the widest they take, unaligned source
     (263, 6000, 8, 4, "f32", 0, 0),
     (130, 4100, 3, 3, "f32", 1, 2),
-    (75, 9000, 1, 4, "f64", 0, 0),      # beyond every resident tile: the one-product kernels
+    (75, 9000, 1, 4, "f64", 0, 0),      # 8192 < K <= 16384: the KERNEL plan still fuses (32 columns per lane, read-only)
+    (67, 16384, 2, 3, "f32", 0, 1),
+    (41, 17000, 1, 3, "f64", 0, 0),     # beyond every resident tile: the one-product kernels
+    (512, 20000, 1, 3, "f64", 0, 0),    # ... short and wide: the score kernel splits the columns as well as the rows
+    (301, 40000, 2, 3, "f32", 0, 1),
+    (2100, 18000, 1, 2, "f64", 1, 0),   # (16-byte accesses from 8 row groups on)
+    (4100, 9000, 1, 3, "f32", 0, 0),    # NIPALS beyond 8192 columns / KERNEL fused
     # odd N with every tile height of the working copy and enough components for an error in one row's contribution to
     # show (a lane just behind the swept rows once picked up t_prev of the tail row: 1e-5 in P from the second component on)
     (1365, 1024, 4, 9, "f64", 0, 0),    # 16-row tiles (512 < K <= 1024)
@@ -132,6 +138,8 @@ def test_edge_shapes_take_the_one_sweep_plan(handle, oracle, po, plan, monkeypat
         assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
     elif K <= 8192:
         # row-pack tiles: the same plan (one copy in the X^T Y sweep + A fused passes)
+        assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
+    elif K <= 16384 and not nipals:
         assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
     else:
         assert tm["launches"]["fused"] == 0, tm["launches"]
