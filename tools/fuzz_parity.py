@@ -16,7 +16,7 @@ bad = 0
 widened = 0
 t0 = time.time()
 for case in range(ncases):
-    kind = rng.choice(["tiny", "small", "gram", "wide", "cv"])
+    kind = rng.choice(["tiny", "small", "gram", "wide", "cv"] + (["xwide"] * 5 if os.environ.get("FUZZ_XWIDE") else ["xwide"]))
     M = int(rng.choice([1, 1, 2, 3, 4, 8]))
     if kind == "tiny":
         N = int(rng.integers(1, 1025)); S = 16 // ((N + 63) // 64); K = int(rng.integers(1, max(2, 26 * S + 1))); M = 1
@@ -26,6 +26,8 @@ for case in range(ncases):
         N = int(rng.integers(4096, 40000)); K = int(rng.integers(1, 700))
     elif kind == "wide":
         N = int(rng.integers(64, 4000)); K = int(rng.integers(1025, 5000))
+    elif kind == "xwide":  # row-pack tiles (K <= 8192 / 16384), the split score kernel and the many-workgroup update beyond
+        N = int(rng.integers(8, 1500)); K = int(rng.choice([rng.integers(4097, 8193), rng.integers(8193, 16385), rng.integers(16385, 40000)]))
     else:
         N = int(rng.integers(5, 400)); K = int(rng.integers(1, 120))
     A = int(rng.integers(1, min(K, 12) + 1))
