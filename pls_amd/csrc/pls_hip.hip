@@ -583,6 +583,28 @@ int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, 
         }
         return PLS_HIP_OK;
     }
+    // 2..8 responses beyond the cooperative kernel's 16,384 columns: the same arithmetic cut at its two exchanges, three launches
+    static const bool widem_on = !(getenv("PLS_HIP_WIDEM_UPDATE") && atoi(getenv("PLS_HIP_WIDEM_UPDATE")) == 0);
+    if (widem_on && M >= 2 && M <= 8 && K > plsk::COOP_MAXG * plsk::COOP_WG && A <= 4096 && plsk::wide1_geometry(K, &w1g, &w1e)) {
+        CHK(ensure(c, c->wide1, (size_t)((i64)(A + plsk::WM_GSTRIDE + plsk::WM_QSTRIDE) * w1g) * 8));
+        double *gp = (double *)c->wide1.p, *cp = gp + (i64)plsk::WM_GSTRIDE * w1g, *qp = cp + (i64)A * w1g;
+        const dim3 g(w1g), b(plsk::W1_WG);
+        Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * M * 3 + (i64)K * (2 * (a + 2)) + K) * 8);
+#define WM_CASE(MM_)                                                                                                              \
+    do {                                                                                                                          \
+        hipLaunchKernelGGL((plsk::widem_a_kernel<MM_>), g, b, 0, c->stream, red, XY, P, Q, K, M, A, a, w1e, (const double *)qp, gp);  \
+        if (n < A) {                                                                                                              \
+            hipLaunchKernelGGL((plsk::widem_b_kernel<MM_>), g, b, (size_t)plsk::W1_WG * w1e * 8, c->stream, (const double *)XY, W,      \
+                               (const double *)P, K, M, n, w1e, (int)c->opt_power_iters, (const double *)gp, cp);                  \
+            hipLaunchKernelGGL((plsk::widem_c_kernel<MM_>), g, b, (size_t)(n + 1) * 8, c->stream, (const double *)XY,                  \
+                               (const double *)W, R, v, K, M, n, w1e, nip, (const double *)cp, qp);                                \
+        }                                                                                                                         \
+    } while (0)
+        if (M <= 2) WM_CASE(2); else if (M <= 4) WM_CASE(4); else WM_CASE(8);
+#undef WM_CASE
+        LAUNCH_CHECK(c);
+        return PLS_HIP_OK;
+    }
     // PLS_HIP_COOP_UPDATE=0 in the environment keeps the single-workgroup kernel (A/B measurements only)
     static const bool coop_on = !(getenv("PLS_HIP_COOP_UPDATE") && atoi(getenv("PLS_HIP_COOP_UPDATE")) == 0);
     if (coop_on && plsk::coop_update_covers(K, M) && A <= 4096) {

@@ -16,6 +16,7 @@
 // element-wise step and the n dot products, which the four waves share out by j.  Every total is an index-ordered sum of
 // workgroup partials: bit-reproducible, identical on every rank of a sharded fit.
 #pragma once
+#include "coop_update.hpp"  // wg_totals, gram_add, the one-wave eigenvector
 #include "small_kernels.hpp"
 
 namespace plsk {
@@ -124,6 +125,170 @@ inline bool wide1_geometry(int K, int *G, int *E) {
     *E = e;
     *G = (K + W1_WG * e - 1) / (W1_WG * e);
     return true;
+}
+
+// ---- 2 <= M <= 8 responses beyond the cooperative kernel's 16,384 columns --------------------------------------------
+// coop_update_kernel (coop_update.hpp) needs all its workgroups co-resident and one thread per column; past that the
+// update fell back to ONE workgroup walking K x M values.  The same arithmetic with the kernel cut at its two grid-wide
+// exchanges -- three launches, a slice of 256 E columns per workgroup, G <= 128:
+//   widem_a_kernel   q_a from the previous launch's partials (:428), p_a (:427), XY -= (p q^T) tt (:429), Gram partials (:405)
+//   widem_b_kernel   G = XY^T XY, its dominant eigenvector qe (every workgroup, same bits; :405-408),
+//                    w = XY qe / sqrt(qe^T G qe) (:408-411), partials of c_j = p_j^T w (:415)
+//   widem_c_kernel   r = w - sum_j c_j r_j (:412-416), partials of r^T XY for the next component's q
+constexpr int WM_GSTRIDE = 36, WM_QSTRIDE = 8;
+
+template <int MM>
+__global__ __launch_bounds__(W1_WG) void widem_a_kernel(const double *__restrict__ red, double *__restrict__ XY,
+                                                        double *__restrict__ P, double *__restrict__ Q, int K, int M, int A,
+                                                        int a, int E, const double *__restrict__ qpart, double *__restrict__ gpart) {
+    constexpr int NP = MM * (MM + 1) / 2;
+    __shared__ double sp[4][COOP_SP];
+    __shared__ double qs[MM];
+    const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int k0 = wg * W1_WG * E, kn = min(W1_WG * E, K - k0);
+    double g[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) g[i] = 0.0;
+    double tt = 1.0;
+    if (a >= 0) {
+        tt = red_sum(red, K + 1, K);
+        if (tid < MM) {
+            double s = 0.0;
+            if (tid < M)
+                for (int w = 0; w < G; ++w) s += qpart[(i64)w * WM_QSTRIDE + tid];
+            qs[tid] = s / tt;
+            if (wg == 0 && tid < M) Q[tid + (i64)a * M] = s / tt;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < kn; i += W1_WG) {
+        const int k = k0 + i;
+        double x[MM];
+        if (a >= 0) {
+            const double p = red_sum(red, K + 1, k) / tt;
+            P[k + (i64)a * K] = p;
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                x[m] = 0.0;
+                if (m < M) {
+                    x[m] = XY[k + (i64)m * K] - (p * qs[m]) * tt;
+                    XY[k + (i64)m * K] = x[m];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                x[m] = 0.0;
+                if (m < M) {
+                    x[m] = red_sum(red, K * M, k + m * K);
+                    XY[k + (i64)m * K] = x[m];
+                }
+            }
+        }
+        gram_add<MM>(x, g);
+    }
+    if (a + 1 >= A) return;
+    const double tot = wg_totals<NP>(g, sp, lane, wv);
+    if (tid < NP) gpart[(i64)tid * G + wg] = tot;
+}
+
+template <int MM>
+__global__ __launch_bounds__(W1_WG) void widem_b_kernel(const double *__restrict__ XY, double *__restrict__ W,
+                                                        const double *__restrict__ P, int K, int M, int n, int E, int power_iters,
+                                                        const double *__restrict__ gpart, double *__restrict__ cpart) {
+    constexpr int NP = MM * (MM + 1) / 2;
+    extern __shared__ double ws[];  // [W1_WG * E] this workgroup's slice of w
+    __shared__ double Gs[MM * MM], Bs[MM * MM], Cs[MM * MM], qs[MM], lam_s;
+    const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int k0 = wg * W1_WG * E, kn = min(W1_WG * E, K - k0);
+    if (tid < NP) {
+        double s = 0.0;
+        for (int w = 0; w < G; ++w) s += gpart[(i64)tid * G + w];
+        int i = 0, rem = tid;
+        while (rem >= MM - i) { rem -= MM - i; ++i; }
+        const int j = i + rem;
+        Gs[i + j * MM] = s;
+        Gs[j + i * MM] = s;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        dominant_eigvec_wave<MM>(Gs, Bs, Cs, qs, power_iters);
+        const int ea = lane % MM, eb = lane / MM;
+        const double term = (lane < MM * MM) ? qs[ea] * Gs[ea + eb * MM] * qs[eb] : 0.0;
+        const double lam = wave_sum(term);  // |XY qe|^2 = qe^T G qe
+        if (lane == 0) lam_s = lam;
+    }
+    __syncthreads();
+    const double nrm = sqrt(lam_s);
+    double *wn = W + (i64)n * K;
+    for (int i = tid; i < kn; i += W1_WG) {
+        const int k = k0 + i;
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+            if (m < M) s = fma(XY[k + (i64)m * K], qs[m], s);
+        const double w = s / nrm;
+        wn[k] = w;
+        ws[i] = w;
+    }
+    __syncthreads();
+    for (int j = wv; j < n; j += W1_WG / WAVE) {
+        const double *pj = P + (i64)j * K + k0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int i = lane;
+        for (; i + 3 * WAVE < kn; i += 4 * WAVE) {
+            s0 = fma(pj[i], ws[i], s0);
+            s1 = fma(pj[i + WAVE], ws[i + WAVE], s1);
+            s2 = fma(pj[i + 2 * WAVE], ws[i + 2 * WAVE], s2);
+            s3 = fma(pj[i + 3 * WAVE], ws[i + 3 * WAVE], s3);
+        }
+        for (; i < kn; i += WAVE) s0 = fma(pj[i], ws[i], s0);
+        const double s = wave_sum((s0 + s1) + (s2 + s3));
+        if (lane == 0) cpart[(i64)j * G + wg] = s;
+    }
+}
+
+template <int MM>
+__global__ __launch_bounds__(W1_WG) void widem_c_kernel(const double *__restrict__ XY, const double *__restrict__ W, double *R,
+                                                        double *__restrict__ vnext, int K, int M, int n, int E, int nipals,
+                                                        const double *__restrict__ cpart, double *__restrict__ qpart) {
+    extern __shared__ double cs[];  // [n]
+    __shared__ double sp[4][COOP_SP];
+    const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int k0 = wg * W1_WG * E, kn = min(W1_WG * E, K - k0);
+    for (int t = tid; t < n; t += W1_WG) {
+        double s = 0.0;
+        for (int g = 0; g < G; ++g) s += cpart[(i64)t * G + g];
+        cs[t] = s;
+    }
+    __syncthreads();
+    double qa[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) qa[m] = 0.0;
+    const double *wn = W + (i64)n * K;
+    double *rn = R + (i64)n * K;
+    for (int i = tid; i < kn; i += W1_WG) {
+        const int k = k0 + i;
+        const double w = wn[k];
+        double r = w;
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {  // same subtraction order as the reference, loads issued together
+            const double r0 = R[k + (i64)j * K], r1 = R[k + (i64)(j + 1) * K];
+            const double r2 = R[k + (i64)(j + 2) * K], r3 = R[k + (i64)(j + 3) * K];
+            r -= cs[j] * r0;
+            r -= cs[j + 1] * r1;
+            r -= cs[j + 2] * r2;
+            r -= cs[j + 3] * r3;
+        }
+        for (; j < n; ++j) r -= cs[j] * R[k + (i64)j * K];
+        rn[k] = r;
+        vnext[k] = nipals ? w : r;
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+            if (m < M) qa[m] = fma(r, XY[k + (i64)m * K], qa[m]);
+    }
+    const double tot = wg_totals<MM>(qa, sp, lane, wv);
+    if (tid < MM) qpart[(i64)wg * WM_QSTRIDE + tid] = tot;
 }
 
 }  // namespace plsk

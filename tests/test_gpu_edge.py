@@ -59,6 +59,9 @@ SHAPES = [
     (512, 20000, 1, 3, "f64", 0, 0),    # ... short and wide: the score kernel splits the columns as well as the rows
     (301, 40000, 2, 3, "f32", 0, 1),
     (2100, 18000, 1, 2, "f64", 1, 0),   # (16-byte accesses from 8 row groups on)
+    (100, 20000, 5, 4, "f64", 0, 0),    # several responses beyond the cooperative update's 16,384 columns: three launches
+    (64, 17000, 8, 3, "f64", 0, 1),
+    (90, 33000, 3, 5, "f32", 0, 0),
     (4100, 9000, 1, 3, "f32", 0, 0),    # NIPALS beyond 8192 columns / KERNEL fused
     # odd N with every tile height of the working copy and enough components for an error in one row's contribution to
     # show (a lane just behind the swept rows once picked up t_prev of the tail row: 1e-5 in P from the second component on)
