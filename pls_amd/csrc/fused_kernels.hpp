@@ -516,7 +516,11 @@ void launch_tail_rows(hipStream_t stream, const TailArgs<T> &a) {
 // (the 32 column-group lanes of a row pack all fetch the same Y values): 2.9 instead of 0.9 ms at config 4.
 // EDGE as in fused_pass_kernel (2: unaligned columns -- plain loads; the consecutive tiles of a workgroup re-read the
 // line a segment shares with the next tile from L2).  N % V == 0 (the tail rows are the launcher's).
-template <typename T, int V, int R, int NT, int CPTB, int MT, int EDGE = 0>
+// LT (destination tiles of one or two row packs, rdst <= 2 V: the copy of a matrix beyond 2048 columns): a source lane's pack
+// belongs to a destination tile of its own, and stored directly a wave writes 64- or 128-byte runs (2.7 TB/s for the copy
+// into row-pack tiles).  Instead the tile block is transposed through LDS -- [row pack][column] with the column index XORed
+// by the row pack: conflict-free both ways -- and written out in the destination's order, 1 KB per wave-store.
+template <typename T, int V, int R, int NT, int CPTB, int MT, int EDGE = 0, bool LT = false>
 __global__ __launch_bounds__(NT, (NT / 256) * 2) void retile_xty_kernel(const T *src, i64 lds_, const T *__restrict__ Y,
                                                                         i64 ldy, T *dst, i64 ldd, i64 tsd, int rdst, i64 N,
                                                                         int K, int M, double *__restrict__ part, int tpw) {
@@ -528,6 +532,10 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void retile_xty_kernel(const T 
     constexpr int TU = (CPTB < 8) ? 2 : 1;
     constexpr int YE = (TU * R * MT + NT - 1) / NT;  // Y elements per thread and iteration (YLDS)
     __shared__ alignas(16) T ys[2][YLDS ? TU * MT : 1][YLDS ? R : V];
+    extern __shared__ __attribute__((aligned(16))) unsigned char retile_dyn[];  // LT: [RP][CG * CPTB] packs
+    Pack<T, V> *trans = reinterpret_cast<Pack<T, V> *>(retile_dyn);
+    constexpr int W = CG * CPTB;  // columns of this workgroup's block
+    static_assert(!LT || (W % 16 == 0 && (RP * W) % NT == 0 && RP <= 16), "transposed store shape");
     const int rp = threadIdx.x % RP, cg = threadIdx.x / RP;
     const int g0 = blockIdx.y * CPTB;  // first column group of this block
     constexpr int CGD = EDGE ? WAVE / RP : CG;
@@ -575,12 +583,35 @@ __global__ __launch_bounds__(NT, (NT / 256) * 2) void retile_xty_kernel(const T 
             const i64 i0 = (tile + u) * R + (i64)rp * V;
             const bool rowok = (tile + u < tile1) && (i0 < N);
             const uint32_t dof = rowok ? doff : OOR;
+            if constexpr (!LT) {
 #pragma unroll
-            for (int j = 0; j < CPTB; ++j) {
-                const int k = cg + CG * (g0 + j);
-                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-                    dst + (tile + u) * dtiles * tsd + (i64)(g0 + j) * CG * ldd, (short)0, 0x7fffffff, BUF_WORD3);
-                buf_st<T, V, AUX_NT>(rd, (k < K) ? dof : OOR, x[u][j]);
+                for (int j = 0; j < CPTB; ++j) {
+                    const int k = cg + CG * (g0 + j);
+                    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+                        dst + (tile + u) * dtiles * tsd + (i64)(g0 + j) * CG * ldd, (short)0, 0x7fffffff, BUF_WORD3);
+                    buf_st<T, V, AUX_NT>(rd, (k < K) ? dof : OOR, x[u][j]);
+                }
+            } else {
+                __syncthreads();  // the previous block has been read out
+#pragma unroll
+                for (int j = 0; j < CPTB; ++j) trans[rp * W + ((cg + CG * j) ^ rp)] = x[u][j];
+                __syncthreads();
+                const __amdgpu_buffer_rsrc_t rd =
+                    __builtin_amdgcn_make_buffer_rsrc(dst + (tile + u) * dtiles * tsd, (short)0, 0x7fffffff, BUF_WORD3);
+                const int Q = rdst / V;  // row packs per destination tile: 1 or 2
+#pragma unroll
+                for (int jj = 0; jj < RP * W / NT; ++jj) {
+                    // destination order: tile d, column c, row pack q of the tile
+                    const int L = jj * NT + (int)threadIdx.x;
+                    const int d = L / (W * Q), rem = L - d * (W * Q);
+                    const int c = (Q == 1) ? rem : (rem >> 1), q = (Q == 1) ? 0 : (rem & 1);
+                    const int rp2 = d * Q + q;
+                    const Pack<T, V> pk = trans[rp2 * W + (c ^ rp2)];
+                    const int k = g0 * CG + c;
+                    const bool ok = (tile + u < tile1) && ((tile + u) * R + (i64)rp2 * V < N) && (k < K);
+                    const uint32_t off = (uint32_t)(((i64)d * tsd + (i64)q * V + (i64)k * ldd) * (i64)sizeof(T));
+                    buf_st<T, V, AUX_NT>(rd, ok ? off : OOR, pk);
+                }
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -661,16 +692,37 @@ int launch_retile_xty(hipStream_t stream, int num_cu, const T *src, i64 lds_, co
         const i64 tpw = (ntiles + want - 1) / want;
         gx = (int)((ntiles + tpw - 1) / tpw);
         const dim3 g((unsigned)gx, (unsigned)nkb), b(NT);
+        // destination tiles of ONE row pack, one or two responses: transposed through LDS (the 32-group source tile only).
+        // Measured: 87,381 x 6,144 fp64 3.14 -> 2.17 ms; with 8 responses (4 columns per lane, two tiles in flight) no gain,
+        // and two-pack tiles (config 4: 128-byte runs already) lose, 0.82 -> 1.10 ms -- those keep the direct stores.
+        static const bool lt_on = !(getenv("PLS_HIP_RETILE_LT") && atoi(getenv("PLS_HIP_RETILE_LT")) == 0);
+        const bool lt = lt_on && CGX == 32 && rdst == V && M <= 2;
 #define RX_LAUNCH(CPTB_, MT_, E_) \
     hipLaunchKernelGGL((retile_xty_kernel<T, V, R, NT, CPTB_, MT_, E_>), g, b, 0, stream, src, lds_, Y, ldy, dst, ldd, tsd, rdst, Nf, K, M, part, (int)tpw)
-#define RX_CASE(CPTB_, MT_) \
+#define RX_LAUNCH_LT(CPTB_, MT_, E_)                                                                                      \
+    do {                                                                                                                  \
+        if constexpr (CGX == 32) {                                                                                        \
+            auto kfn = &retile_xty_kernel<T, V, R, NT, CPTB_, MT_, E_, true>;                                             \
+            const int dynb = (R / V) * CG * CPTB_ * 16;                                                                   \
+            if (dynb > 48 * 1024 && !raise_dynamic_lds(reinterpret_cast<const void *>(kfn), dynb)) return 1;              \
+            hipLaunchKernelGGL(kfn, g, b, dynb, stream, src, lds_, Y, ldy, dst, ldd, tsd, rdst, Nf, K, M, part, (int)tpw); \
+        }                                                                                                                 \
+    } while (0)
+#define RX_CASE(CPTB_, MT_)                                                                                               \
+    do {                                                                                                                  \
+        if (lt) { if (edge == 2) RX_LAUNCH_LT(CPTB_, MT_, 2); else if (edge) RX_LAUNCH_LT(CPTB_, MT_, 1); else RX_LAUNCH_LT(CPTB_, MT_, 0); } \
+        else if (edge == 2) RX_LAUNCH(CPTB_, MT_, 2); else if (edge) RX_LAUNCH(CPTB_, MT_, 1); else RX_LAUNCH(CPTB_, MT_, 0); \
+    } while (0)
+#define RX_CASE_D(CPTB_, MT_) \
     do { if (edge == 2) RX_LAUNCH(CPTB_, MT_, 2); else if (edge) RX_LAUNCH(CPTB_, MT_, 1); else RX_LAUNCH(CPTB_, MT_, 0); } while (0)
-        if (M > 4) RX_CASE(4, 8);
-        else if (M > 2 && cptb == 4) RX_CASE(4, 4);
-        else if (M > 2) RX_CASE(8, 4);
+        if (M > 4) RX_CASE_D(4, 8);
+        else if (M > 2 && cptb == 4) RX_CASE_D(4, 4);
+        else if (M > 2) RX_CASE_D(8, 4);
         else if (M > 1) RX_CASE(8, 2);
         else RX_CASE(8, 1);
+#undef RX_CASE_D
 #undef RX_CASE
+#undef RX_LAUNCH_LT
 #undef RX_LAUNCH
     }
     if (Nf < N) {
