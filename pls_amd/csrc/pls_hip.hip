@@ -585,7 +585,8 @@ int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, 
     }
     // 2..8 responses beyond the cooperative kernel's 16,384 columns: the same arithmetic cut at its two exchanges, three launches
     static const bool widem_on = !(getenv("PLS_HIP_WIDEM_UPDATE") && atoi(getenv("PLS_HIP_WIDEM_UPDATE")) == 0);
-    if (widem_on && M >= 2 && M <= 8 && K > plsk::COOP_MAXG * plsk::COOP_WG && A <= 4096 && plsk::wide1_geometry(K, &w1g, &w1e)) {
+    static const int widem_min = getenv("PLS_HIP_WIDEM_MIN") ? atoi(getenv("PLS_HIP_WIDEM_MIN")) : plsk::COOP_MAXG * plsk::COOP_WG + 1;
+    if (widem_on && M >= 2 && M <= 8 && K >= widem_min && (i64)K * M >= 16384 && A <= 4096 && plsk::wide1_geometry(K, &w1g, &w1e)) {
         CHK(ensure(c, c->wide1, (size_t)((i64)(A + plsk::WM_GSTRIDE + plsk::WM_QSTRIDE) * w1g) * 8));
         double *gp = (double *)c->wide1.p, *cp = gp + (i64)plsk::WM_GSTRIDE * w1g, *qp = cp + (i64)A * w1g;
         const dim3 g(w1g), b(plsk::W1_WG);
