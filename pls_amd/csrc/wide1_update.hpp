@@ -23,6 +23,19 @@ namespace plsk {
 
 constexpr int W1_WG = 256, W1_MAXG = 128;
 
+// out[t] (LDS) = sum over the G workgroups of the value-major partials part[t * stride_t + g * stride_g], t < nv: a wave per
+// value, its lanes over the workgroups (G <= 128: two loads per lane), then the fixed-order wave sum -- every workgroup
+// forms the same bits.  (One thread per value walking G partials one after the other: 15 us of a 20 us kernel.)
+__device__ __forceinline__ void w1_totals(const double *__restrict__ part, int nv, int G, i64 stride_t, i64 stride_g, double *out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int t = wv; t < nv; t += W1_WG / WAVE) {
+        double s = 0.0;
+        for (int g = lane; g < G; g += WAVE) s += part[(i64)t * stride_t + (i64)g * stride_g];
+        s = wave_sum(s);
+        if (lane == 0) out[t] = s;
+    }
+}
+
 // a, red, nipals: as component_update_kernel (a = -1: prologue, XY = reduced X^T Y).  E: columns per thread.
 __global__ __launch_bounds__(W1_WG) void wide1_a_kernel(const double *__restrict__ red, double *__restrict__ XY, double *P,
                                                         double *__restrict__ Q, int K, int A, int a, int E,
@@ -82,11 +95,7 @@ __global__ __launch_bounds__(W1_WG) void wide1_b_kernel(const double *__restrict
     __shared__ double sred[W1_WG / WAVE];
     const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
     const int k0 = wg * W1_WG * E, kn = min(W1_WG * E, K - k0);
-    for (int t = tid; t <= n; t += W1_WG) {
-        double s = 0.0;
-        for (int g = 0; g < G; ++g) s += part[(i64)t * G + g];
-        cs[t] = s;
-    }
+    w1_totals(part, n + 1, G, G, 1, cs);
     __syncthreads();
     const double nrm = sqrt(cs[0]);
     __syncthreads();
@@ -152,12 +161,14 @@ __global__ __launch_bounds__(W1_WG) void widem_a_kernel(const double *__restrict
     double tt = 1.0;
     if (a >= 0) {
         tt = red_sum(red, K + 1, K);
-        if (tid < MM) {
-            double s = 0.0;
-            if (tid < M)
-                for (int w = 0; w < G; ++w) s += qpart[(i64)w * WM_QSTRIDE + tid];
-            qs[tid] = s / tt;
-            if (wg == 0 && tid < M) Q[tid + (i64)a * M] = s / tt;
+        if (tid < MM) qs[tid] = 0.0;
+        __syncthreads();
+        w1_totals(qpart, M, G, 1, WM_QSTRIDE, qs);
+        __syncthreads();
+        if (tid < M) {
+            const double q = qs[tid] / tt;
+            qs[tid] = q;
+            if (wg == 0) Q[tid + (i64)a * M] = q;
         }
         __syncthreads();
     }
@@ -201,9 +212,10 @@ __global__ __launch_bounds__(W1_WG) void widem_b_kernel(const double *__restrict
     __shared__ double Gs[MM * MM], Bs[MM * MM], Cs[MM * MM], qs[MM], lam_s;
     const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int k0 = wg * W1_WG * E, kn = min(W1_WG * E, K - k0);
+    w1_totals(gpart, NP, G, G, 1, Cs);  // (Cs: free until the eigenvector iteration)
+    __syncthreads();
     if (tid < NP) {
-        double s = 0.0;
-        for (int w = 0; w < G; ++w) s += gpart[(i64)tid * G + w];
+        const double s = Cs[tid];
         int i = 0, rem = tid;
         while (rem >= MM - i) { rem -= MM - i; ++i; }
         const int j = i + rem;
@@ -256,11 +268,7 @@ __global__ __launch_bounds__(W1_WG) void widem_c_kernel(const double *__restrict
     __shared__ double sp[4][COOP_SP];
     const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int k0 = wg * W1_WG * E, kn = min(W1_WG * E, K - k0);
-    for (int t = tid; t < n; t += W1_WG) {
-        double s = 0.0;
-        for (int g = 0; g < G; ++g) s += cpart[(i64)t * G + g];
-        cs[t] = s;
-    }
+    w1_totals(cpart, n, G, G, 1, cs);
     __syncthreads();
     double qa[MM];
 #pragma unroll
