@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collects the measurement evidence of a round on the GPU box into gpurun_out/evidence/ (copy what is to be judged
 # into profiles/rNN/ afterwards).  rocprofv3: the program goes directly after `--`; counters in their own passes.
-# usage: bash tools/collect_evidence.sh [part ...]   parts: c3 deflate c4 c5 eighth edge narrow group host roctx small fuzz   (default: all but fuzz)
+# usage: bash tools/collect_evidence.sh [part ...]   parts: c3 deflate c4 c5 eighth edge narrow wide group host roctx small fuzz   (default: all but fuzz)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 E=gpurun_out/evidence; mkdir -p $E
-PARTS="${*:-c3 deflate c4 c5 eighth edge narrow group host roctx small}"
+PARTS="${*:-c3 deflate c4 c5 eighth edge narrow wide group host roctx small}"
 stats() {  # name, command...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $E/tmp_$name -o p -- "$@" > $E/${name}_bench_under_rocprof.json 2> $E/tmp_$name.err
@@ -95,6 +95,24 @@ with open(E + "/narrow_and_many_responses_summary.txt", "w") as out:
         out.write("%-46s %9.1f %9.3f  %s %.4f ms %.4f\n" % (os.path.basename(f)[13:-5], d["value"], d["ms_per_step"], r["kernel"], r["avg_launch_ms"], r["frac"]))
 PY
   ;;
+wide)
+  # beyond 4096 columns (row-pack tiles) and few-rows-many-columns shapes, with the previous forms beside them; z-scores
+  for wl in wide8k wide6k64 wide8k64; do for algo in kernel nipals; do
+    python3 bench.py --workload $wl --algo $algo --steps 6 --warmup 2 --no-cpu --no-alt > $E/wide512_bench_${wl}_${algo}.json 2> /dev/null
+    PLS_HIP_WIDE512=0 python3 bench.py --workload $wl --algo $algo --steps 6 --warmup 2 --no-cpu --no-alt > $E/wide512_bench_${wl}_${algo}_one_product_kernels.json 2> /dev/null
+  done; done
+  for wl in wide16k wide12k64; do
+    python3 bench.py --workload $wl --algo kernel --steps 6 --warmup 2 --no-cpu --no-alt > $E/wide512_bench_${wl}_kernel.json 2> /dev/null
+    PLS_HIP_WIDE512=0 python3 bench.py --workload $wl --algo kernel --steps 6 --warmup 2 --no-cpu --no-alt > $E/wide512_bench_${wl}_kernel_one_product_kernels.json 2> /dev/null
+  done
+  for wl in shortwide genes genes4; do for algo in kernel nipals; do
+    python3 bench.py --workload $wl --algo $algo --steps 6 --warmup 2 --no-cpu --no-alt > $E/shortwide_bench_${wl}_${algo}.json 2> /dev/null
+    PLS_HIP_XB_SPLIT=0 PLS_HIP_WIDE1_MIN=2000000000 PLS_HIP_WIDEM_UPDATE=0 python3 bench.py --workload $wl --algo $algo --steps 6 --warmup 2 --no-cpu --no-alt > $E/shortwide_bench_${wl}_${algo}_one_workgroup_kernels.json 2> /dev/null
+  done; done
+  rm -f $E/zscore_time_raw.txt
+  for op in 1 0; do for shape in "1048576 512" "1048576 512 f32" "4000000 64"; do
+    PLS_HIP_ZSCORE_ONE_PASS=$op PLS_HIP_ZS_PIECE=$op python3 tools/zscore_time.py $shape 2> /dev/null >> $E/zscore_time_raw.txt
+  done; done ;;
 group)
   # the two in-process exchanges with virtual members (one hardware queue per member), the cross-process exchange with
   # ranks sharing the GPU, config 5 at its own size
