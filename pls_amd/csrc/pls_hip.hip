@@ -283,7 +283,10 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
         const bool v2 = vec_ok<T>(X, ldx, FV) && (N + (i64)FV * plsk::WG - 1) / ((i64)FV * plsk::WG) >= 8;
         const i64 per = (i64)plsk::WG * (v2 ? FV : 1);
         const i64 rg = (N + per - 1) / per;
-        if (rg < 2 * (i64)c->num_cu) {
+        // taken while one row per lane cannot give every CU a workgroup (fp32: two -- its 4-byte accesses stream worse);
+        // measured per shape, tools/xb_split_sweep.py: beyond that the row-parallel kernel is as fast or faster
+        const i64 rg1 = (N + plsk::WG - 1) / plsk::WG;
+        if (rg1 <= (i64)(sizeof(T) == 4 ? 2 : 1) * c->num_cu) {
             int KS = (int)std::min<i64>(K / 128, (3 * (i64)c->num_cu + rg - 1) / rg);
             const int kper = (K + KS - 1) / KS;
             KS = (K + kper - 1) / kper;

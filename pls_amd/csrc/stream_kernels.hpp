@@ -857,49 +857,31 @@ __global__ __launch_bounds__(WG) void zscale_kernel(const T *X, i64 ldx, T *Z, i
     const int k0 = blockIdx.y * KC;
     const int kn = min(KC, K - k0);
     constexpr i64 CH = (i64)WG * VEC;
-    // (mean, sd, 1/sd) of the workgroup's columns: wave-uniform, scalar registers.  The quotient y / sd is formed as
-    // q = y*r, q += fma(-q, sd, y) * r with r = 1/sd correctly rounded: the correctly rounded quotient (Markstein) in 3
-    // full-rate instructions instead of the ~15 of the division sequence with its quarter-rate v_rcp_f64.  sd = 0, NaN or
-    // so large / small that r or the residual could leave the normal range: the plain division (src/pls.cpp:103 divides
-    // by the unguarded sd -- a constant column is NaN / inf there and here).
-    double m[KC], sdev[KC], rinv[KC];
-    bool fast[KC];
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-        m[kc] = kc < kn ? mean[k0 + kc] : 0.0;
-        sdev[kc] = kc < kn ? sd[k0 + kc] : 1.0;
-        rinv[kc] = 1.0 / sdev[kc];
-        fast[kc] = fabs(sdev[kc]) > 1e-150 && fabs(sdev[kc]) < 1e150;
-    }
-    auto quot = [&](double y, int kc) -> double {
-        if (!fast[kc]) return y / sdev[kc];
-        const double q = y * rinv[kc];
-        const double q1 = fma(fma(-q, sdev[kc], y), rinv[kc], q);
-        return (fabs(q) > 1e-290 && fabs(q) < 1e290) ? q1 : y / sdev[kc];  // (near the subnormals the residual is not exact)
-    };
+    // The quotient y / sd is formed as q = y*r, q += fma(-q, sd, y) * r with r = 1/sd correctly rounded: the correctly
+    // rounded quotient (Markstein) in 3 full-rate instructions instead of the ~15 of the division sequence with its
+    // quarter-rate v_rcp_f64.  sd = 0, NaN or so large / small that r or the residual could leave the normal range: the
+    // plain division (src/pls.cpp:103 divides by the unguarded sd -- a constant column is NaN / inf there and here).
+    // (One column at a time, eight waves per SIMD: measured faster than all KC packs in flight at four.)
     for (i64 c = blockIdx.x; c * CH < N; c += gridDim.x) {
         const i64 i0 = c * CH + (i64)threadIdx.x * VEC;
-        if (i0 + VEC <= N) {
-            // all KC packs in flight before the first division (X and Z may be the same matrix: a thread only ever
-            // overwrites what it has loaded itself)
-            Pack<T, VEC> x[KC];
+        for (int kc = 0; kc < kn; ++kc) {
+            const double m = mean[k0 + kc], sdev = sd[k0 + kc], rinv = 1.0 / sdev;
+            const bool fast = fabs(sdev) > 1e-150 && fabs(sdev) < 1e150;
+            auto quot = [&](double y) -> double {
+                if (!fast) return y / sdev;
+                const double q = y * rinv;
+                const double q1 = fma(fma(-q, sdev, y), rinv, q);
+                return (fabs(q) > 1e-290 && fabs(q) < 1e290) ? q1 : y / sdev;  // (near the subnormals the residual is not exact)
+            };
+            if (i0 + VEC <= N) {
+                Pack<T, VEC> x = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + kc) * ldx);
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-                if (kc < kn) x[kc] = ld_pack_nt<T, VEC>(X + i0 + (i64)(k0 + kc) * ldx);
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-                if (kc < kn) {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) x[kc].v[v] = (T)quot((double)x[kc].v[v] - m[kc], kc);
-                    st_pack_nt<T, VEC>(Z + i0 + (i64)(k0 + kc) * ldz, x[kc]);
-                }
-        } else {
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-                if (kc < kn)
-                    for (int v = 0; v < VEC; ++v)
-                        if (i0 + v < N)
-                            Z[i0 + v + (i64)(k0 + kc) * ldz] = (T)quot((double)X[i0 + v + (i64)(k0 + kc) * ldx] - m[kc], kc);
+                for (int v = 0; v < VEC; ++v) x.v[v] = (T)quot((double)x.v[v] - m);
+                st_pack_nt<T, VEC>(Z + i0 + (i64)(k0 + kc) * ldz, x);
+            } else {
+                for (int v = 0; v < VEC; ++v)
+                    if (i0 + v < N) Z[i0 + v + (i64)(k0 + kc) * ldz] = (T)quot((double)X[i0 + v + (i64)(k0 + kc) * ldx] - m);
+            }
         }
     }
 }
