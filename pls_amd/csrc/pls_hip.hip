@@ -570,18 +570,24 @@ int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, 
         return launch_update_large(c, red, XY, W, P, Q, R, v, K, M, A, a, nip);
     // One response on very many columns: element-wise work and K-long sums on up to 128 workgroups, two launches
     // (wide1_update.hpp) instead of one workgroup walking K (+ one workgroup per p_j^T w of the r recurrence)
-    static const int wide1_min = getenv("PLS_HIP_WIDE1_MIN") ? atoi(getenv("PLS_HIP_WIDE1_MIN")) : 8192;
+    static const int wide1_min = getenv("PLS_HIP_WIDE1_MIN") ? atoi(getenv("PLS_HIP_WIDE1_MIN")) : 4097;  // (up to 4096 columns the one-workgroup kernel keeps XY in registers)
     int w1g = 0, w1e = 0;
-    if (M == 1 && K >= wide1_min && A <= 4096 && plsk::wide1_geometry(K, &w1g, &w1e)) {
-        CHK(ensure(c, c->wide1, (size_t)((i64)(A + 2) * w1g) * 8));
-        double *w1part = (double *)c->wide1.p, *w1q = w1part + (i64)(A + 1) * w1g;
+    if (M == 1 && K >= wide1_min && plsk::wide1_geometry(K, &w1g, &w1e)) {
+        CHK(ensure(c, c->wide1, (size_t)((i64)(A + 2) * w1g + A + 1) * 8));
+        double *w1part = (double *)c->wide1.p, *w1q = w1part + (i64)(A + 1) * w1g, *w1tot = w1q + w1g;
         Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * 3 + (i64)K * (2 * (a + 2)) + K) * 8);
         hipLaunchKernelGGL(plsk::wide1_a_kernel, dim3(w1g), dim3(plsk::W1_WG), (size_t)plsk::W1_WG * w1e * 8, c->stream, red, XY, P, Q,
                            K, A, a, w1e, (const double *)w1q, w1part);
         LAUNCH_CHECK(c);
-        if (n < A) {
-            hipLaunchKernelGGL(plsk::wide1_b_kernel, dim3(w1g), dim3(plsk::W1_WG), (size_t)(n + 1) * 8, c->stream, (const double *)XY, W,
-                               R, v, K, n, w1e, nip, (const double *)w1part, w1q);
+        if (n < A && n + 1 <= 4096) {
+            hipLaunchKernelGGL(plsk::wide1_b_kernel<false>, dim3(w1g), dim3(plsk::W1_WG), (size_t)(n + 1) * 8, c->stream,
+                               (const double *)XY, W, R, v, K, n, w1e, nip, (const double *)w1part, w1q, (const double *)nullptr);
+            LAUNCH_CHECK(c);
+        } else if (n < A) {  // more totals than a workgroup's LDS holds: formed once, read from global memory
+            hipLaunchKernelGGL(plsk::wide1_totals_kernel, dim3((n + 4) / 4), dim3(plsk::W1_WG), 0, c->stream, (const double *)w1part, n,
+                               w1g, w1tot);
+            hipLaunchKernelGGL(plsk::wide1_b_kernel<true>, dim3(w1g), dim3(plsk::W1_WG), 0, c->stream, (const double *)XY, W, R, v, K,
+                               n, w1e, nip, (const double *)w1part, w1q, (const double *)w1tot);
             LAUNCH_CHECK(c);
         }
         return PLS_HIP_OK;

@@ -87,20 +87,50 @@ __global__ __launch_bounds__(W1_WG) void wide1_a_kernel(const double *__restrict
     }
 }
 
-// n = a + 1 >= 0 is the component whose w and r are formed (n < A).  cs: dynamic LDS, n + 1 doubles.
+// More than 4096 components (hence K > 4096): the totals no longer fit a workgroup's LDS (and n x G loads per workgroup
+// would be repeated G times) -- one launch forms them once: tot[0] = |XY|, tot[1 + j] = c_j.  grid = ceil((n + 1) / 4).
+__global__ __launch_bounds__(W1_WG) void wide1_totals_kernel(const double *__restrict__ part, int n, int G, double *__restrict__ tot) {
+    __shared__ double v[1 + W1_WG / WAVE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    w1_totals(part, 1, G, G, 1, v);  // |XY|^2 (wave 0)
+    {
+        const int t = 1 + blockIdx.x * (W1_WG / WAVE) + wv;  // this wave's value
+        double s = 0.0;
+        if (t <= n)
+            for (int g = lane; g < G; g += WAVE) s += part[(i64)t * G + g];
+        s = wave_sum(s);
+        if (lane == 0) v[1 + wv] = s;
+    }
+    __syncthreads();
+    const double nrm = sqrt(v[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) tot[0] = nrm;
+    const int t = 1 + blockIdx.x * (W1_WG / WAVE) + (int)threadIdx.x;
+    if (threadIdx.x < W1_WG / WAVE && t <= n) tot[t] = v[1 + threadIdx.x] / nrm;
+}
+
+// n = a + 1 >= 0 is the component whose w and r are formed (n < A).  cs: dynamic LDS, n + 1 doubles -- or, GCS, the
+// totals wide1_totals_kernel left in global memory (wave-uniform reads: the scalar cache).
+template <bool GCS>
 __global__ __launch_bounds__(W1_WG) void wide1_b_kernel(const double *__restrict__ XY, double *__restrict__ W, double *R,
                                                         double *__restrict__ vnext, int K, int n, int E, int nipals,
-                                                        const double *__restrict__ part, double *__restrict__ qpart) {
-    extern __shared__ double cs[];  // [n + 1]: |XY|^2, then p_j^T XY
+                                                        const double *__restrict__ part, double *__restrict__ qpart,
+                                                        const double *__restrict__ tot) {
+    extern __shared__ double cs_lds[];  // [n + 1]: |XY|^2, then p_j^T XY
     __shared__ double sred[W1_WG / WAVE];
     const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x;
     const int k0 = wg * W1_WG * E, kn = min(W1_WG * E, K - k0);
-    w1_totals(part, n + 1, G, G, 1, cs);
-    __syncthreads();
-    const double nrm = sqrt(cs[0]);
-    __syncthreads();
-    for (int t = tid; t < n; t += W1_WG) cs[1 + t] /= nrm;  // c_j = p_j^T w
-    __syncthreads();
+    const double *cs = GCS ? tot : cs_lds;
+    double nrm;
+    if constexpr (GCS) {
+        nrm = tot[0];
+    } else {
+        w1_totals(part, n + 1, G, G, 1, cs_lds);
+        __syncthreads();
+        nrm = sqrt(cs_lds[0]);
+        __syncthreads();
+        for (int t = tid; t < n; t += W1_WG) cs_lds[1 + t] /= nrm;  // c_j = p_j^T w
+        __syncthreads();
+    }
     double qa = 0.0;
     double *wn = W + (i64)n * K, *rn = R + (i64)n * K;
     for (int i = tid; i < kn; i += W1_WG) {
