@@ -60,3 +60,28 @@ def test_sharded_equals_unsharded(N, K, M, A, world):
             assert np.array_equal(out[k], res[0][2][k]), k
     s = po.sign_align(ref["W"], res[0][2]["W"])
     assert po.rel_fro(T * s, ref["T"]) < 1e-9
+
+
+def test_sharded_column_statistics_recipe():
+    """The row-sharded z-score statistics of the device path (colmoments_shard_kernel, src/pls.cpp:69-83) restated in
+    numpy: every shard holds (count, mean, M2) of its rows; all-reduce 1 sums n_r * mean_r (-> the global mean g),
+    all-reduce 2 sums M2_r + n_r (mean_r - g)^2 (-> SST about g).  Checked against the two-pass statistics of the whole
+    matrix on columns with a large offset, with an empty shard and a one-row shard among the ranks."""
+    rng = np.random.default_rng(4)
+    N, K = 5003, 7
+    X = rng.standard_normal((N, K)) * rng.uniform(0.1, 30, K) + np.array([0, 1e6, -3e8, 5, 0.1, 1e3, -40])
+    for splits in ([2050, 2044, 909], [2500, 0, 2503], [1, 5001, 1], [N]):
+        assert sum(splits) == N
+        tri, row0 = [], 0
+        for n_r in splits:
+            blk = X[row0:row0 + n_r]; row0 += n_r
+            mean_r = blk.mean(0) if n_r else np.zeros(K)
+            m2_r = ((blk - mean_r) ** 2).sum(0) if n_r else np.zeros(K)
+            tri.append((float(n_r), mean_r, m2_r))
+        g = sum(n * m for n, m, _ in tri) / N                                    # all-reduce 1
+        sst = sum(q + n * (m - g) ** 2 for n, m, q in tri)                       # all-reduce 2
+        sd = np.sqrt(sst / (N - 1))
+        xl = X.astype(np.longdouble)
+        ref_mean = xl.mean(0); ref_sd = np.sqrt(((xl - ref_mean) ** 2).sum(0) / (N - 1))
+        assert np.allclose(g, ref_mean.astype(np.float64), rtol=1e-13, atol=1e-15)   # (a mean near 0 cancels)
+        assert np.allclose(sd, ref_sd.astype(np.float64), rtol=1e-12, atol=0), splits
