@@ -75,11 +75,14 @@ def test_sharded_column_statistics_recipe():
         tri, row0 = [], 0
         for n_r in splits:
             blk = X[row0:row0 + n_r]; row0 += n_r
-            mean_r = blk.mean(0) if n_r else np.zeros(K)
-            m2_r = ((blk - mean_r) ** 2).sum(0) if n_r else np.zeros(K)
+            # (the device carries a shard's mean as an unevaluated sum hi + lo: the merge is FIRST order in its error, and at an
+            # offset of 1e8 sd a plain fp64 mean would cost 1e-10 in the sd -- extended precision stands in for hi + lo here)
+            bl = blk.astype(np.longdouble)
+            mean_r = bl.mean(0) if n_r else np.zeros(K, dtype=np.longdouble)
+            m2_r = (((bl - mean_r) ** 2).sum(0)).astype(np.float64) if n_r else np.zeros(K)
             tri.append((float(n_r), mean_r, m2_r))
-        g = sum(n * m for n, m, _ in tri) / N                                    # all-reduce 1
-        sst = sum(q + n * (m - g) ** 2 for n, m, q in tri)                       # all-reduce 2
+        g = (sum(n * m.astype(np.float64) for n, m, _ in tri) / N)               # all-reduce 1 (plain fp64 sums)
+        sst = sum(q + n * ((m - g) ** 2).astype(np.float64) for n, m, q in tri)  # all-reduce 2 (second order in the error of g)
         sd = np.sqrt(sst / (N - 1))
         xl = X.astype(np.longdouble)
         ref_mean = xl.mean(0); ref_sd = np.sqrt(((xl - ref_mean) ** 2).sum(0) / (N - 1))
