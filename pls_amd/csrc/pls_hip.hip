@@ -279,7 +279,7 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
     // One score column of a short, wide matrix: the rows alone give fewer workgroups than there are CUs -- split the
     // columns as well (xb_split_kernel); ~3 workgroups per CU, at least 128 columns each.
     static const bool split_on = !(getenv("PLS_HIP_XB_SPLIT") && atoi(getenv("PLS_HIP_XB_SPLIT")) == 0);
-    if (C == 1 && split_on && N > 0 && K >= 1024) {
+    if (split_on && N > 0 && K >= 1024 && C <= 32) {
         const bool v2 = vec_ok<T>(X, ldx, FV) && (N + (i64)FV * plsk::WG - 1) / ((i64)FV * plsk::WG) >= 8;
         const i64 per = (i64)plsk::WG * (v2 ? FV : 1);
         const i64 rg = (N + per - 1) / per;
@@ -291,18 +291,25 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
             const int kper = (K + KS - 1) / KS;
             KS = (K + kper - 1) / kper;
             const i64 ldp = (N + 63) / 64 * 64;
-            if (KS >= 2 && KS <= 65535 && ensure(c, c->xbpart, (size_t)KS * ldp * 8) == PLS_HIP_OK) {
-                Scope s(c, PLS_HIP_FAM_XB, (i64)N * K * sizeof(T) + (i64)N * sizeof(T) + (i64)K * 8);
-                const dim3 g((unsigned)rg, (unsigned)KS), blk(plsk::WG);
+            const int mt = C > 2 ? 4 : (C > 1 ? 2 : 1);  // columns per sweep of X
+            if (KS >= 2 && KS <= 65535 && ensure(c, c->xbpart, (size_t)KS * mt * ldp * 8) == PLS_HIP_OK) {
                 double *xp = (double *)c->xbpart.p;
-                if (v2) hipLaunchKernelGGL((plsk::xb_split_kernel<T, FV>), g, blk, 0, c->stream, X, ldx, N, K, kper, Bm, xp, ldp);
-                else hipLaunchKernelGGL((plsk::xb_split_kernel<T, 1>), g, blk, 0, c->stream, X, ldx, N, K, kper, Bm, xp, ldp);
-                LAUNCH_CHECK(c);
                 const int fb = (int)((N + 63) / 64);
-                hipLaunchKernelGGL((plsk::xb_split_finish_kernel<T>), dim3(fb), blk, 0, c->stream, (const double *)xp, ldp, KS, N, out,
-                                   sspart);
-                LAUNCH_CHECK(c);
-                if (sspart && nss) *nss = fb;
+                for (int c0 = 0; c0 < C; c0 += mt) {
+                    const int use = std::min(mt, C - c0);
+                    const double *b = Bm + (i64)c0 * ldb;
+                    Scope s(c, PLS_HIP_FAM_XB, (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8);
+                    const dim3 g((unsigned)rg, (unsigned)KS), blk(plsk::WG);
+#define XS_CASE(V_, M_) hipLaunchKernelGGL((plsk::xb_split_kernel<T, V_, M_>), g, blk, 0, c->stream, X, ldx, N, K, kper, b, ldb, use, xp, ldp)
+                    if (v2) { if (mt == 4) XS_CASE(FV, 4); else if (mt == 2) XS_CASE(FV, 2); else XS_CASE(FV, 1); }
+                    else { if (mt == 4) XS_CASE(1, 4); else if (mt == 2) XS_CASE(1, 2); else XS_CASE(1, 1); }
+#undef XS_CASE
+                    LAUNCH_CHECK(c);
+                    hipLaunchKernelGGL((plsk::xb_split_finish_kernel<T>), dim3(fb, use), blk, 0, c->stream, (const double *)xp, ldp, KS, mt,
+                                       N, out + (i64)c0 * ldo, ldo, C == 1 ? sspart : (double *)nullptr);
+                    LAUNCH_CHECK(c);
+                }
+                if (C == 1 && sspart && nss) *nss = fb;
                 return PLS_HIP_OK;
             }
             c->err.clear();

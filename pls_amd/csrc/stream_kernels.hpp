@@ -111,14 +111,21 @@ __global__ __launch_bounds__(WG) void xb_kernel(const T *__restrict__ X, i64 ldx
 // columns [k_lo, k_hi) of its range and leaves a partial score, part[ks * ldp + i]; xb_split_finish_kernel sums the KS
 // partials of a row in range order (bit-reproducible), rounds to the storage type and forms the t^T t partials.
 // ------------------------------------------------------------------------------------
-template <typename T, int VEC>
+// MT columns of Bm (ldb) at a time: part[(ks * MT + m) * ldp + i].
+template <typename T, int VEC, int MT>
 __global__ __launch_bounds__(WG) void xb_split_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int kper,
-                                                      const double *__restrict__ v, double *__restrict__ part, i64 ldp) {
+                                                      const double *__restrict__ v, i64 ldb, int ncols, double *__restrict__ part,
+                                                      i64 ldp) {
     const i64 i0 = ((i64)blockIdx.x * WG + threadIdx.x) * VEC;
     const int k_lo = blockIdx.y * kper, k_hi = min(K, k_lo + kper);
-    double acc[VEC];
+    double acc[VEC][MT];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[e][m] = 0.0;
+    i64 boff[MT];  // columns m >= ncols read a valid column again and are never stored
+#pragma unroll
+    for (int m = 0; m < MT; ++m) boff[m] = (i64)min(m, ncols - 1) * ldb;
     if (i0 + VEC <= N) {
         const T *xp = X + i0;
         constexpr int U = 8;
@@ -128,39 +135,50 @@ __global__ __launch_bounds__(WG) void xb_split_kernel(const T *__restrict__ X, i
 #pragma unroll
             for (int u = 0; u < U; ++u) x[u] = ld_pack_nt<T, VEC>(xp + (i64)(k + u) * ldx);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const double b = v[k + u];  // wave-uniform: scalar load
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] = fma((double)x[u].v[e], b, acc[e]);
-            }
+                for (int m = 0; m < MT; ++m) {
+                    const double b = v[k + u + boff[m]];  // wave-uniform: scalar load
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e][m] = fma((double)x[u].v[e], b, acc[e][m]);
+                }
         }
         for (; k < k_hi; ++k) {
             const Pack<T, VEC> x = ld_pack_nt<T, VEC>(xp + (i64)k * ldx);
-            const double b = v[k];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] = fma((double)x.v[e], b, acc[e]);
+            for (int m = 0; m < MT; ++m) {
+                const double b = v[k + boff[m]];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e][m] = fma((double)x.v[e], b, acc[e][m]);
+            }
         }
     } else if (i0 < N) {
-        for (int k = k_lo; k < k_hi; ++k) {
-            const double b = v[k];
+        for (int k = k_lo; k < k_hi; ++k)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e)
-                if (i0 + e < N) acc[e] = fma((double)X[i0 + e + (i64)k * ldx], b, acc[e]);
-        }
+            for (int m = 0; m < MT; ++m) {
+                const double b = v[k + boff[m]];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (i0 + e < N) acc[e][m] = fma((double)X[i0 + e + (i64)k * ldx], b, acc[e][m]);
+            }
     }
 #pragma unroll
-    for (int e = 0; e < VEC; ++e)
-        if (i0 + e < N) part[(i64)blockIdx.y * ldp + i0 + e] = acc[e];
+    for (int m = 0; m < MT; ++m)
+        if (m < ncols)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (i0 + e < N) part[((i64)blockIdx.y * MT + m) * ldp + i0 + e] = acc[e][m];
 }
 
-// t[i] = sum over the KS ranges, in order; workgroup = 64 rows x 4 interleaved sets of ranges (LDS for the last step).
-// sspart[blockIdx.x] = sum of the workgroup's t^2 (as stored), when asked for.
+// t[i] = sum over the KS ranges, in order; workgroup = 64 rows x 4 interleaved sets of ranges (LDS for the last step);
+// blockIdx.y = column m of the MT the split kernel formed.
+// sspart[blockIdx.x] = sum of the workgroup's t^2 (as stored), when asked for (one column only).
 template <typename T>
-__global__ __launch_bounds__(WG) void xb_split_finish_kernel(const double *__restrict__ part, i64 ldp, int KS, i64 N,
-                                                             T *__restrict__ out, double *__restrict__ sspart) {
+__global__ __launch_bounds__(WG) void xb_split_finish_kernel(const double *__restrict__ part, i64 ldp, int KS, int MT, i64 N,
+                                                             T *__restrict__ out, i64 ldo, double *__restrict__ sspart) {
     __shared__ double sh[4][64];
     __shared__ double red[WG / WAVE];
-    const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int r = threadIdx.x & 63, q = threadIdx.x >> 6, m = blockIdx.y;
     const i64 i = (i64)blockIdx.x * 64 + r;
     // set q sums the ranges [q * per, (q + 1) * per): contiguous, so that the order of the whole sum is the range order
     const int per = (KS + 3) / 4, lo = q * per, hi = min(KS, lo + per);
@@ -170,18 +188,18 @@ __global__ __launch_bounds__(WG) void xb_split_finish_kernel(const double *__res
         for (; ks + 8 <= hi; ks += 8) {  // 8 loads in flight, added in range order
             double pv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) pv[u] = part[(i64)(ks + u) * ldp + i];
+            for (int u = 0; u < 8; ++u) pv[u] = part[((i64)(ks + u) * MT + m) * ldp + i];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += pv[u];
         }
-        for (; ks < hi; ++ks) s += part[(i64)ks * ldp + i];
+        for (; ks < hi; ++ks) s += part[((i64)ks * MT + m) * ldp + i];
     }
     sh[q][r] = s;
     __syncthreads();
     double ss = 0.0;
     if (q == 0 && i < N) {
         const T t = (T)(((sh[0][r] + sh[1][r]) + sh[2][r]) + sh[3][r]);
-        out[i] = t;
+        out[i + (i64)m * ldo] = t;
         ss = (double)t * (double)t;
     }
     if (sspart) {

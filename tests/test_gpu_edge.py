@@ -220,3 +220,24 @@ def test_z_scores_on_unaligned_layouts(handle, oracle, N, K, dt, ld_extra, base_
     assert np.abs(X.cpu().numpy() - zr).max() < (1e-10 if dt == "f64" else 5e-6)
     n_nan = int(torch.isnan(keepx).sum())
     assert n_nan == keepx.numel() - N * K
+
+
+@pytest.mark.parametrize("N,K,C,dt,ld_extra,base_off", [
+    (512, 20000, 1, "f64", 0, 0), (300, 9000, 3, "f64", 0, 1), (1000, 5000, 4, "f64", 1, 0), (77, 33000, 7, "f64", 0, 0),
+    (2100, 3000, 2, "f32", 0, 0), (515, 12000, 5, "f32", 0, 3), (40000, 1500, 3, "f64", 0, 0), (9, 70000, 2, "f64", 0, 0),
+])
+def test_scores_of_short_wide_matrices(handle, oracle, N, K, C, dt, ld_extra, base_off):
+    """X * B (scores and fitted values, src/pls.cpp:439-451) of matrices with few rows and many columns: the columns
+    are split over workgroups as well as the rows (xb_split_kernel), several columns of B per sweep"""
+    torch = _torch()
+    tdt = torch.float64 if dt == "f64" else torch.float32
+    rng = np.random.default_rng(N + K + C)
+    Xh = oracle.synth_x(0, N, K)
+    if dt == "f32":
+        Xh = Xh.astype(np.float32).astype(np.float64)
+    Bh = np.asfortranarray(rng.standard_normal((K, C)))
+    X, keep = _place(Xh, tdt, ld_extra, base_off)
+    out = handle.xb(X, torch.from_numpy(Bh).cuda()); handle.synchronize()
+    ref = Xh @ Bh
+    err = np.abs(out.cpu().numpy().astype(np.float64) - ref).max() / np.abs(ref).max()
+    assert err < (1e-13 if dt == "f64" else 2e-7), err

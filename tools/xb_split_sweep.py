@@ -18,3 +18,14 @@ for dt in (torch.float64, torch.float32):
         gb = N * K * X.element_size() / 1e9
         print(f"{str(dt)[6:]} N={N} K={K}: {ms:.3f} ms {gb / ms:.2f} TB/s  split={os.environ.get('PLS_HIP_XB_SPLIT', '1')}", flush=True)
         del X
+
+# several columns of B on short, wide matrices (scores / fitted values)
+for N, K, C in ((512, 50000, 4), (512, 50000, 10), (4096, 32768, 4), (2048, 8192, 20)):
+    X = h.synth_x(0, N, K, 1)
+    Bm = torch.randn(K, C, dtype=torch.float64, device="cuda")
+    for _ in range(3): h.xb(X, Bm)
+    h.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): h.xb(X, Bm)
+    h.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
+    print(f"float64 N={N} K={K} C={C}: {ms:.3f} ms  split={os.environ.get('PLS_HIP_XB_SPLIT', '1')}", flush=True)
+    del X
