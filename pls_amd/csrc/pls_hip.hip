@@ -279,7 +279,7 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
     // One score column of a short, wide matrix: the rows alone give fewer workgroups than there are CUs -- split the
     // columns as well (xb_split_kernel); ~3 workgroups per CU, at least 128 columns each.
     static const bool split_on = !(getenv("PLS_HIP_XB_SPLIT") && atoi(getenv("PLS_HIP_XB_SPLIT")) == 0);
-    if (split_on && N > 0 && K >= 1024 && C <= 32) {
+    if (split_on && N > 0 && K >= 1024) {
         const bool v2 = vec_ok<T>(X, ldx, FV) && (N + (i64)FV * plsk::WG - 1) / ((i64)FV * plsk::WG) >= 8;
         const i64 per = (i64)plsk::WG * (v2 ? FV : 1);
         const i64 rg = (N + per - 1) / per;

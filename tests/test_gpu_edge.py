@@ -224,7 +224,7 @@ def test_z_scores_on_unaligned_layouts(handle, oracle, N, K, dt, ld_extra, base_
 
 @pytest.mark.parametrize("N,K,C,dt,ld_extra,base_off", [
     (512, 20000, 1, "f64", 0, 0), (300, 9000, 3, "f64", 0, 1), (1000, 5000, 4, "f64", 1, 0), (77, 33000, 7, "f64", 0, 0),
-    (2100, 3000, 2, "f32", 0, 0), (515, 12000, 5, "f32", 0, 3), (40000, 1500, 3, "f64", 0, 0), (9, 70000, 2, "f64", 0, 0),
+    (2100, 3000, 2, "f32", 0, 0), (515, 12000, 5, "f32", 0, 3), (40000, 1500, 3, "f64", 0, 0), (9, 70000, 2, "f64", 0, 0), (130, 6000, 45, "f64", 0, 0),
 ])
 def test_scores_of_short_wide_matrices(handle, oracle, N, K, C, dt, ld_extra, base_off):
     """X * B (scores and fitted values, src/pls.cpp:439-451) of matrices with few rows and many columns: the columns
