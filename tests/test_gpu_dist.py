@@ -117,6 +117,29 @@ def test_sharded_config5_shape(world, splits, algo):
     assert (po.column_errors(ref, got) <= lim).all()
 
 
+@pytest.mark.parametrize("N,K,M,A,algo,splits", [(600, 6000, 1, 5, 0, [301, 299]), (600, 6000, 1, 5, 1, [300, 0, 300]),
+                                                 (400, 20000, 3, 4, 0, [150, 250]), (900, 9000, 1, 4, 1, [450, 450])],
+                         ids=["kernel-row-pack-tiles", "nipals-empty-rank", "several-responses-beyond-16384-columns", "nipals-beyond-8192"])
+def test_sharded_wide_matrices(N, K, M, A, algo, splits):
+    """Row-sharded fits on matrices beyond 4096 columns: the ranks copy their shards into row-pack tiles (or, beyond the
+    tiles' reach, take the split score kernel), an odd or empty shard takes another local path than its peers -- the
+    sequence of collectives is the same on every rank, the K-sized update (on many workgroups here) runs on identical
+    reduced sums: replicas bit-identical, coefficients at the oracle's."""
+    from oracle import pls_oracle as po
+    res = _run(len(splits), N, K, M, A, algo, 1, splits=splits)
+    ora = po.OracleLib()
+    X = ora.synth_x(0, N, K); Y = ora.synth_y(0, N, M)
+    ref = ora.plsr(X, Y, A)
+    Bref = ora.coefficients(ref["R"], ref["Q"])
+    for rank, out in res:
+        assert po.rel_fro(out["B"], Bref) < 1e-10, rank
+        for k in "WPQRB":
+            assert np.array_equal(out[k], res[0][1][k]), (rank, k)
+    T = np.concatenate([out["T"] for _, out in res], axis=0)
+    s = po.sign_align(ref["W"], res[0][1]["W"])
+    assert np.abs(T * s - ref["T"]).max() / np.abs(ref["T"]).max() < 1e-8
+
+
 @pytest.mark.parametrize("algo,method,splits", [(2, 0, [1500, 0, 1500]), (0, 1, [1500, 0, 1500]), (2, 0, [1001, 998, 1001]),
                                                 (0, 1, [1001, 998, 1001])],
                          ids=["gram-empty-rank", "type2-empty-rank", "gram-odd-shards", "type2-odd-shards"])
