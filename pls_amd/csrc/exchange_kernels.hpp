@@ -74,7 +74,57 @@ __global__ __launch_bounds__(256) void xchg_gather_kernel(const double *inbox, c
     }
 }
 
-// the two launches of one collective piece; seq: the member's running collective number (already incremented)
+// Push and gather of one SHORT piece in ONE launch: block 0 pushes to every member (the body of xchg_push_kernel with the
+// destinations in a loop), the blocks behind it gather (xchg_gather_kernel).  The gather blocks wait for the member's own
+// flag like for every other; block 0 publishes its flags only after it has read all of buf and issued every store, so a
+// gather block never overwrites an element the push still has to read.  Block 0 is dispatched first; the grid is at most
+// 5 workgroups.  One launch boundary fewer per collective (PLS_HIP_XCHG_FUSED=0: the two launches; long pieces take those
+// anyway, one push workgroup per destination).
+constexpr int XCHG_FUSED_MAX = 4096;  // doubles
+__global__ __launch_bounds__(XCHG_THREADS) void xchg_push_gather_kernel(XchgPeers peers, int do_push, const double *inbox,
+                                                                        const unsigned long long *flags, int n, i64 cap, i64 Ltot,
+                                                                        i64 j0, int L, int slices, unsigned long long seq, double *buf,
+                                                                        int *status, int *host_status, long long limit) {
+    if (blockIdx.x == 0) {
+        if (!do_push) return;
+        for (int j = threadIdx.x; j < L; j += XCHG_THREADS) {
+            double sum = buf[j0 + j];
+            for (int sl = 1; sl < slices; ++sl) sum += buf[(i64)sl * Ltot + j0 + j];
+            for (int d = 0; d < n; ++d) __hip_atomic_store(peers.slot[d] + j, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __threadfence_system();
+        __syncthreads();
+        if ((int)threadIdx.x < n) __hip_atomic_store(peers.flag[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    const int gb = blockIdx.x - 1, ngb = gridDim.x - 1;
+    __shared__ int ok;
+    if (threadIdx.x == 0) ok = (*status == 0);
+    __syncthreads();
+    if ((int)threadIdx.x < n && ok) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            if (wall_clock64() - t0 > limit) {
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (!ok && threadIdx.x == 0 && gb == 0) {
+        *status = 1;
+        __hip_atomic_store(host_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (int j = gb * XCHG_THREADS + threadIdx.x; j < L; j += ngb * XCHG_THREADS) {
+        double sum = ok ? __hip_atomic_load(inbox + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __builtin_nan("");
+        for (int m = 1; m < n && ok; ++m) sum += __hip_atomic_load(inbox + (i64)m * cap + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        buf[j0 + j] = sum;
+        for (int sl = 1; sl < slices; ++sl) buf[(i64)sl * Ltot + j0 + j] = 0.0;
+    }
+}
+
+// the launch(es) of one collective piece; seq: the member's running collective number (already incremented)
 inline int xchg_launch_piece(hipStream_t stream, int n, int rank, double *const *inboxes, unsigned long long *const *flagsv,
                              double *buf, i64 Ltot, i64 j0, int L, int slices, unsigned long long seq, int *status,
                              int *host_status, long long limit) {
@@ -93,6 +143,14 @@ inline int xchg_launch_piece(hipStream_t stream, int n, int rank, double *const 
         int dr = -1;
         unsigned long long dq = 0;
         if (sscanf(drop, "%d:%llu", &dr, &dq) == 2) skip = dropped = (dr == rank && dq == seq);
+    }
+    static const bool fused = !(getenv("PLS_HIP_XCHG_FUSED") && atoi(getenv("PLS_HIP_XCHG_FUSED")) == 0);
+    if (fused && L <= XCHG_FUSED_MAX) {
+        const int ngb = (int)std::min<i64>(4, (L + XCHG_THREADS - 1) / XCHG_THREADS);
+        hipLaunchKernelGGL(xchg_push_gather_kernel, dim3(1 + ngb), dim3(XCHG_THREADS), 0, stream, peers, skip ? 0 : 1,
+                           (const double *)(inboxes[rank] + (i64)par * n * XCHG_CAP), (const unsigned long long *)(flagsv[rank] + par * n),
+                           n, XCHG_CAP, Ltot, j0, L, slices, seq, buf, status, host_status, limit);
+        return hipGetLastError() == hipSuccess ? 0 : 13;
     }
     if (!skip)
         hipLaunchKernelGGL(xchg_push_kernel, dim3(n), dim3(XCHG_THREADS), 0, stream, peers, (const double *)buf, Ltot, j0, L, slices, seq);
