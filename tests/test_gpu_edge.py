@@ -63,6 +63,11 @@ SHAPES = [
     (64, 17000, 8, 3, "f64", 0, 1),
     (90, 33000, 3, 5, "f32", 0, 0),
     (4100, 9000, 1, 3, "f32", 0, 0),    # NIPALS beyond 8192 columns / KERNEL fused
+    (1, 4097, 1, 1, "f64", 0, 0),       # the smallest cases of the wide paths: one row, one component
+    (2, 8193, 2, 1, "f64", 0, 1),
+    (3, 16385, 1, 2, "f64", 0, 0),
+    (5, 8192, 2, 3, "f32", 0, 1),
+    (6, 16384, 1, 4, "f32", 0, 0),
     # odd N with every tile height of the working copy and enough components for an error in one row's contribution to
     # show (a lane just behind the swept rows once picked up t_prev of the tail row: 1e-5 in P from the second component on)
     (1365, 1024, 4, 9, "f64", 0, 0),    # 16-row tiles (512 < K <= 1024)
@@ -136,6 +141,8 @@ def test_edge_shapes_take_the_one_sweep_plan(handle, oracle, po, plan, monkeypat
             assert tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
         else:
             assert tm["launches"]["deflate"] == 0, tm["launches"]
+    elif A < 3:
+        pass   # (the copy into short tiles is taken from the third component on; values checked above)
     elif K <= 4096:
         # short tiles: one copy into them (in the same sweep as X^T Y) + A fused passes, read-only (KERNEL) or in place (NIPALS)
         assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
