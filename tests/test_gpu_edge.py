@@ -248,3 +248,17 @@ def test_scores_of_short_wide_matrices(handle, oracle, N, K, C, dt, ld_extra, ba
     ref = Xh @ Bh
     err = np.abs(out.cpu().numpy().astype(np.float64) - ref).max() / np.abs(ref).max()
     assert err < (1e-13 if dt == "f64" else 2e-7), err
+
+
+@pytest.mark.parametrize("N,K,M,A,dt", [(300, 9000, 1, 4, "f64"), (64, 20000, 3, 3, "f64"), (501, 6000, 2, 5, "f32"), (33, 16384, 1, 3, "f64")])
+def test_host_memory_entry_on_wide_matrices(handle, oracle, po, N, K, M, A, dt):
+    """pls_hip_fit on HOST matrices (the entry PLS::Model uses) beyond 4096 columns: staging, the copy into row-pack tiles /
+    the split score kernel, results back in host memory -- against the oracle"""
+    Xh, Yh = oracle.synth_x(0, N, K, seed=N + K), oracle.synth_y(0, N, M, seed=N + K)
+    npdt = np.float64 if dt == "f64" else np.float32
+    if dt == "f32":
+        Xh = Xh.astype(np.float32).astype(np.float64); Yh = Yh.astype(np.float32).astype(np.float64)
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    out = handle.fit_host(Xh.astype(npdt), Yh.astype(npdt), A, dtype=npdt)
+    tol = 1e-10 if dt == "f64" else 2e-5
+    assert po.rel_fro(np.asarray(out["B"], dtype=np.float64), Bref) < max(tol, 50 * float(np.max(cerr)))
