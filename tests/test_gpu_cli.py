@@ -49,10 +49,17 @@ def _oracle_loo(oracle, X, Y, A):
 
 
 @pytest.mark.parametrize("devices", [None, "0,0,0"], ids=["one-device", "three-virtual-members"])
-@pytest.mark.parametrize("fx,fy,A", [("toyX.csv", "toyY.csv", 2), ("nir.csv", "octane.csv", 4)])
-def test_model_api(oracle, po, fx, fy, A, devices):
+@pytest.mark.parametrize("fx,fy,A", [("toyX.csv", "toyY.csv", 2), ("nir.csv", "octane.csv", 4), ("gen:36x5000", "gen:36x2", 4)])
+def test_model_api(oracle, po, fx, fy, A, devices, tmp_path):
     """devices = "0,0,0": PLS_HIP_DEVICES spreads the rows of every matrix the Model touches over three members of a
-    pls_hip_group (virtual shards on the one GPU of the test box) -- same public API, same numbers."""
+    pls_hip_group (virtual shards on the one GPU of the test box) -- same public API, same numbers.
+    gen:NxK: a generated matrix written as CSV (few rows, 5000 columns: the copy into row-pack tiles, the split score
+    kernel and the many-workgroup update behind the C++ API)."""
+    if fx.startswith("gen:"):
+        for name, spec, gen in (("x.csv", fx, oracle.synth_x), ("y.csv", fy, oracle.synth_y)):
+            n, k = (int(v) for v in spec[4:].split("x"))
+            np.savetxt(tmp_path / name, gen(0, n, k, seed=99), delimiter=",", fmt="%.17g")
+        fx, fy = str(tmp_path / "x.csv"), str(tmp_path / "y.csv")
     env = dict(os.environ)
     env.pop("PLS_HIP_DEVICES", None)
     if devices:
