@@ -381,6 +381,251 @@ __global__ __launch_bounds__(256, 2) void syrk_glds_kernel(const T *__restrict__
     }
 }
 
+// ---- eight waves per workgroup (round 3) ---------------------------------------------------------------------------------
+// Same LDS image, DMA and swizzle as above; 512 threads = 8 waves, 64 accumulator registers per lane instead of 128, so that
+// two workgroups per CU are FOUR waves per SIMD instead of two: with two, the MFMA pipe idles whenever both waves of a SIMD
+// sit at their slab barriers (the four SIMDs of a workgroup drift apart by up to one 16-MFMA burst).  Full blocks, 4-wave
+// form 5.61 ms -> 8-wave form 5.13 ms on config 3 (`tools/syrk_ab.sh`).
+//   off-diagonal blocks: waves in a 4 x 2 arrangement, wave tile 32 x 64: 8 MFMAs and 6 operand reads per 4-row step;
+//   diagonal blocks: the 36 tiles (16 x 16) on or above the diagonal of the 8 x 8 tile grid dealt out to the 8 waves in
+//   enumeration order (5 or 4 each -- 5/8 of a full block's time per slab), every tile with its own two operand reads;
+//   X^T Y rides along as before (thread = (column, quarter of the slab's rows)).
+template <typename T>
+__device__ __forceinline__ void syrk8_dma(T *lds, int buf, const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, int bj, bool diag,
+                                          i64 s, const T *__restrict__ zeros, int wv, int scol, int spos) {
+    constexpr int V = 16 / sizeof(T), RB = 8 * V, CS = 8 * V, PANEL = SYRK_TB * CS;
+    T *Ab = lds + (size_t)buf * 2 * PANEL, *Bb = Ab + PANEL;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = wv + 8 * j;
+        const int col = 8 * i + scol;
+        const int q = spos ^ ((col >> 1) & 7);
+        const i64 row = s * RB + (i64)q * V;
+        const bool ok = row < N;
+        const int ca = min(bi * SYRK_TB + col, K - 1);
+        glds16(ok ? X + row + (i64)ca * ldx : zeros, Ab + i * (8 * CS));
+        if (!diag) {
+            const int cb = min(bj * SYRK_TB + col, K - 1);
+            glds16(ok ? X + row + (i64)cb * ldx : zeros, Bb + i * (8 * CS));
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void syrk8_full_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, int bj, i64 s0, int nsplit,
+                                             const T *__restrict__ zeros, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
+    T *lds = reinterpret_cast<T *>(slab_raw);
+    constexpr int V = 16 / sizeof(T), RB = 8 * V, CS = 8 * V, PANEL = SYRK_TB * CS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int a0 = (wv >> 1) * 32, b0 = (wv & 1) * 64;
+    const int fl = li >> 1;
+    const int scol = lane >> 3, spos = lane & 7;
+    f64x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const i64 nslabs = (N + RB - 1) / RB;
+    i64 s = s0;
+    int buf = 0;
+    if (s < nslabs) syrk8_dma<T>(lds, 0, X, ldx, N, K, bi, bj, false, s, zeros, wv, scol, spos);
+    for (; s < nslabs; s += nsplit, buf ^= 1) {
+        __syncthreads();
+        const T *As = lds + (size_t)buf * 2 * PANEL, *Bs = As + PANEL;
+        if (s + nsplit < nslabs) syrk8_dma<T>(lds, buf ^ 1, X, ldx, N, K, bi, bj, false, s + nsplit, zeros, wv, scol, spos);
+#pragma unroll
+        for (int kk = 0; kk < RB; kk += 4) {
+            const int r = kk + lq;
+            const int off = (((r / V) ^ fl) * V) + (r % V);
+            double a[2], b[4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[m] = (double)As[(a0 + 16 * m + li) * CS + off];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[n] = (double)Bs[(b0 + 16 * n + li) * CS + off];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ga_ = bi * SYRK_TB + a0 + 16 * m + lq + 4 * r;
+                const int gb_ = bj * SYRK_TB + b0 + 16 * n + li;
+                if (ga_ < K && gb_ < K) {
+                    const double v = acc[m][n][r];
+                    out[ga_ + (i64)gb_ * K] = v;
+                    out[gb_ + (i64)ga_ * K] = v;
+                }
+            }
+}
+
+// tile t of the upper triangle of the 8 x 8 tile grid, row by row: (i, j), i <= j
+__device__ __forceinline__ void syrk8_tri_tile(int t, int &i, int &j) {
+    i = 0;
+    while (t >= 8 - i) { t -= 8 - i; ++i; }
+    j = i + t;
+}
+
+template <typename T, bool WITH_Y>
+__device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, i64 s0, int nsplit,
+                                             const T *__restrict__ zeros, double *__restrict__ out, const T *__restrict__ Y, i64 ldy,
+                                             int M, double *__restrict__ xy_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
+    T *lds = reinterpret_cast<T *>(slab_raw);
+    constexpr int V = 16 / sizeof(T), RB = 8 * V, CS = 8 * V, PANEL = SYRK_TB * CS;
+    constexpr int NT5 = 5;  // tiles per wave at most: 36 tiles over 8 waves
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int fl = li >> 1;
+    const int scol = lane >> 3, spos = lane & 7;
+    // this wave's tiles: numbers wv, wv + 8, ... < 36 (wave-uniform: scalar registers)
+    int ti[NT5], tj[NT5];
+#pragma unroll
+    for (int t = 0; t < NT5; ++t) {
+        const int id = wv + 8 * t;
+        syrk8_tri_tile(id < 36 ? id : 0, ti[t], tj[t]);
+        ti[t] = __builtin_amdgcn_readfirstlane(ti[t]);
+        tj[t] = __builtin_amdgcn_readfirstlane(tj[t]);
+    }
+    const bool last = (wv + 8 * (NT5 - 1) < 36);  // does the fifth tile exist?
+    f64x4 acc[NT5];
+#pragma unroll
+    for (int t = 0; t < NT5; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    double accy[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) accy[m] = 0.0;
+    const int yc = tid >> 2, yh = tid & 3;  // X^T Y: column of the panel, quarter of the slab's 8 row positions
+    const int ykey = (yc >> 1) & 7;
+    const i64 nslabs = (N + RB - 1) / RB;
+    auto issue = [&](i64 s, int buf) {
+        syrk8_dma<T>(lds, buf, X, ldx, N, K, bi, bi, true, s, zeros, wv, scol, spos);
+        if constexpr (WITH_Y) {
+            if (wv == 0) {
+                const int m = lane >> 3, pos = lane & 7;
+                const i64 row = s * RB + (i64)pos * V;
+                const T *gy = (row < N && m < M) ? Y + row + (i64)m * ldy : zeros;
+                glds16(gy, lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS));
+            }
+        }
+    };
+    i64 s = s0;
+    int buf = 0;
+    if (s < nslabs) issue(s, 0);
+    for (; s < nslabs; s += nsplit, buf ^= 1) {
+        __syncthreads();
+        const T *As = lds + (size_t)buf * 2 * PANEL;
+        if constexpr (WITH_Y) {  // (before the next slab's DMA is issued, as in the 4-wave form)
+            const T *Ys = lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS);
+            Pack<T, V> xv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) xv[q] = *reinterpret_cast<const Pack<T, V> *>(As + yc * CS + (((2 * yh + q) ^ ykey) * V));
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                if (m < M) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const Pack<T, V> yv = *reinterpret_cast<const Pack<T, V> *>(Ys + (m * 8 + 2 * yh + q) * V);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) accy[m] = fma((double)xv[q].v[e], (double)yv.v[e], accy[m]);
+                    }
+                }
+        }
+        if (s + nsplit < nslabs) issue(s + nsplit, buf ^ 1);
+#pragma unroll
+        for (int kk = 0; kk < RB; kk += 4) {
+            const int r = kk + lq;
+            const int off = (((r / V) ^ fl) * V) + (r % V);
+            double a[NT5], b[NT5];
+#pragma unroll
+            for (int t = 0; t < NT5; ++t) {
+                a[t] = (double)As[(16 * ti[t] + li) * CS + off];
+                b[t] = (double)As[(16 * tj[t] + li) * CS + off];
+            }
+#pragma unroll
+            for (int t = 0; t < NT5 - 1; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[t], acc[t], 0, 0, 0);
+            if (last) acc[NT5 - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[NT5 - 1], b[NT5 - 1], acc[NT5 - 1], 0, 0, 0);
+        }
+    }
+    if constexpr (WITH_Y) {
+        __syncthreads();  // the panels have been read
+        double *ysh = reinterpret_cast<double *>(slab_raw);  // [4][128][8]
+#pragma unroll
+        for (int m = 0; m < 8; ++m) ysh[(yh * SYRK_TB + yc) * 8 + m] = accy[m];
+        __syncthreads();
+        const int col = bi * SYRK_TB + yc;
+        if (yh == 0 && col < K)
+            for (int m = 0; m < M; ++m)
+                xy_out[col + (i64)m * K] = (ysh[yc * 8 + m] + ysh[(SYRK_TB + yc) * 8 + m]) +
+                                           (ysh[(2 * SYRK_TB + yc) * 8 + m] + ysh[(3 * SYRK_TB + yc) * 8 + m]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT5; ++t) {
+        if (t == NT5 - 1 && !last) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ga_ = bi * SYRK_TB + 16 * ti[t] + lq + 4 * r;
+            const int gb_ = bi * SYRK_TB + 16 * tj[t] + li;
+            if (ga_ < K && gb_ < K) {
+                const double v = acc[t][r];
+                out[ga_ + (i64)gb_ * K] = v;
+                out[gb_ + (i64)ga_ * K] = v;
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void syrk_glds8_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
+                                                            const T *__restrict__ zeros, double *__restrict__ part, int so, int sd,
+                                                            const T *__restrict__ Y, i64 ldy, int M, double *__restrict__ xypart) {
+    // grid layout as syrk_glds_kernel: first so splits of every off-diagonal block, then sd of every diagonal block
+    const int ndiag = nbk, noff = nbk * (nbk + 1) / 2 - nbk;
+    int id = blockIdx.x, split, blk;
+    bool diag;
+    if (id < noff * so) {
+        diag = false;
+        blk = id % noff;
+        split = id / noff;
+    } else {
+        diag = true;
+        id -= noff * so;
+        blk = id % ndiag;
+        split = id / ndiag;
+    }
+    int bi, bj;
+    if (diag) {
+        bi = bj = blk;
+    } else {
+        bi = 0;
+        int rem = blk;
+        while (rem >= nbk - 1 - bi) { rem -= nbk - 1 - bi; ++bi; }
+        bj = bi + 1 + rem;
+    }
+    double *out = part + (i64)split * ((i64)K * K);
+    if (diag) {
+        for (int z = split + sd; z < so; z += sd) {
+            double *zo = part + (i64)z * ((i64)K * K);
+            for (int e = threadIdx.x; e < SYRK_TB * SYRK_TB; e += 512) {
+                const int ga_ = bi * SYRK_TB + (e & (SYRK_TB - 1)), gb_ = bj * SYRK_TB + e / SYRK_TB;
+                if (ga_ < K && gb_ < K) zo[ga_ + (i64)gb_ * K] = 0.0;
+            }
+        }
+        if (Y)
+            syrk8_diag_body<T, true>(X, ldx, N, K, bi, split, sd, zeros, out, Y, ldy, M, xypart + (i64)split * ((i64)K * M));
+        else
+            syrk8_diag_body<T, false>(X, ldx, N, K, bi, split, sd, zeros, out, nullptr, 0, 0, nullptr);
+    } else {
+        syrk8_full_body<T>(X, ldx, N, K, bi, bj, split, so, zeros, out);
+    }
+}
+
 // rc: 0 launched (part holds *nb partial K x K matrices), 1 shape not covered
 // zeros: >= 16 bytes of device zeros (source of the rows beyond N in the LDS-DMA variant); nullptr = register-staged kernel
 template <typename T>
@@ -415,7 +660,10 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         if (tri && nblocks <= slots) {  // one residency wave: a diagonal workgroup costs 10/16 per slab (more with X^T Y on board)
             static const double wenv = getenv("PLS_HIP_SYRK_DIAGW") ? atof(getenv("PLS_HIP_SYRK_DIAGW")) : 0.0;
             // measured optima with X^T Y on board: 0.70 for one response (branch-free step), 0.78-0.80 for several
-            const double dw = wenv > 0.0 ? wenv : (fuse_y0 ? (M == 1 ? 0.70 : 0.78) : 0.625);
+            // (the 8-wave form: a diagonal workgroup's tiles each read their own two operands -- 0.74 measured for one response)
+            static const bool w8w = !(getenv("PLS_HIP_SYRK_W8") && atoi(getenv("PLS_HIP_SYRK_W8")) == 0);
+            const double dw = wenv > 0.0 ? wenv
+                                         : (w8w ? (fuse_y0 ? (M == 1 ? 0.74 : 0.80) : 0.66) : (fuse_y0 ? (M == 1 ? 0.70 : 0.78) : 0.625));
             const double units = (nblocks - nbk) + dw * nbk;
             Sg = (i64)(slots / units);
             Sd = std::max<i64>(1, (i64)(dw * Sg));
@@ -426,6 +674,17 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         if (Sg < 1) return 1;
         Sd = Sd ? std::min<i64>(Sd, Sg) : Sg;
         if (!tri) Sd = Sg;
+        static const bool w8 = !(getenv("PLS_HIP_SYRK_W8") && atoi(getenv("PLS_HIP_SYRK_W8")) == 0);  // 0: the 4-wave form (A/B)
+        if (w8) {
+            if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_glds8_kernel<T>), (int)LDS_G)) return 1;
+            const i64 nwg8 = (i64)(nblocks - nbk) * Sg + (i64)nbk * Sd;
+            const bool fuse_y8 = fuse_y0 && Sd * (i64)K * M <= xypart_capacity_doubles;
+            hipLaunchKernelGGL(syrk_glds8_kernel<T>, dim3((unsigned)nwg8), dim3(512), LDS_G, stream, X, ldx, N, K, nbk,
+                               static_cast<const T *>(zeros), part, (int)Sg, (int)Sd, fuse_y8 ? Y : nullptr, ldy, M, xypart);
+            if (fuse_y8) *nb_xy = (int)Sd;
+            *nb = (int)Sg;
+            return 0;
+        }
         if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_glds_kernel<T>), (int)LDS_G)) return 1;
         const i64 nwg = (i64)(nblocks - nbk) * Sg + (i64)nbk * Sd;
         const bool fuse_y = fuse_y0 && Sd * (i64)K * M <= xypart_capacity_doubles;
