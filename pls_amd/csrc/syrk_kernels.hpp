@@ -485,16 +485,27 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
     const int li = lane & 15, lq = lane >> 4;
     const int fl = li >> 1;
     const int scol = lane >> 3, spos = lane & 7;
-    // this wave's tiles: numbers wv, wv + 8, ... < 36 (wave-uniform: scalar registers)
+    // This wave's tiles: up to two ROW SEGMENTS of the upper triangle of the 8 x 8 tile grid -- (ra; columns ca .. ca+na-1)
+    // and (rb; cb .. cb+nb-1), na + nb = 5 or 4 -- so that a 4-row step reads 2 row operands + 5 column operands instead of
+    // two per tile:   w0-w3: row w, columns w .. w+4;   w4: (0; 5-7) + (7; 7);   w5: (1; 6-7) + (6; 6-7);
+    //                 w6: (2; 7) + (5; 5-7);   w7: (4; 4-7).   5 5 5 5 4 4 4 4 = 36 tiles.  (wave-uniform: scalar registers)
+    const int wq = wv & 3;
+    const bool hi = wv >= 4;
+    const int ra = __builtin_amdgcn_readfirstlane(hi ? (wv == 7 ? 4 : wq) : wq);
+    const int ca = __builtin_amdgcn_readfirstlane(hi ? (wv == 7 ? 4 : 5 + wq) : wq);
+    const int na = __builtin_amdgcn_readfirstlane(hi ? (wv == 7 ? 4 : 3 - wq) : 5);
+    const int rb = __builtin_amdgcn_readfirstlane(hi ? 7 - wq : 0);
+    const int cb = __builtin_amdgcn_readfirstlane(hi ? 7 - wq : 0);
+    const int nb = __builtin_amdgcn_readfirstlane((hi && wv != 7) ? 1 + wq : 0);
     int ti[NT5], tj[NT5];
 #pragma unroll
     for (int t = 0; t < NT5; ++t) {
-        const int id = wv + 8 * t;
-        syrk8_tri_tile(id < 36 ? id : 0, ti[t], tj[t]);
-        ti[t] = __builtin_amdgcn_readfirstlane(ti[t]);
-        tj[t] = __builtin_amdgcn_readfirstlane(tj[t]);
+        const bool inA = t < na;
+        ti[t] = inA ? ra : rb;
+        tj[t] = inA ? ca + t : cb + (t - na);
+        if (t >= na + nb) { ti[t] = 0; tj[t] = 0; }
     }
-    const bool last = (wv + 8 * (NT5 - 1) < 36);  // does the fifth tile exist?
+    const bool last = (na + nb == NT5);  // does the fifth tile exist?
     f64x4 acc[NT5];
 #pragma unroll
     for (int t = 0; t < NT5; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -543,9 +554,10 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
             const int r = kk + lq;
             const int off = (((r / V) ^ fl) * V) + (r % V);
             double a[NT5], b[NT5];
+            const double opa = (double)As[(16 * ra + li) * CS + off], opb = (double)As[(16 * rb + li) * CS + off];
 #pragma unroll
             for (int t = 0; t < NT5; ++t) {
-                a[t] = (double)As[(16 * ti[t] + li) * CS + off];
+                a[t] = (t < na) ? opa : opb;
                 b[t] = (double)As[(16 * tj[t] + li) * CS + off];
             }
 #pragma unroll

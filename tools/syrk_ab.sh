@@ -7,3 +7,4 @@ for i in 1 2 3; do
 PLS_HIP_SYRK_W8=1 t eight_waves
 PLS_HIP_SYRK_W8=0 t four_waves
 done
+for dw in 0.66 0.70 0.74; do PLS_HIP_SYRK_DIAGW=$dw PLS_HIP_SYRK_W8=1 t eight_waves_diagw_$dw; done
