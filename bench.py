@@ -149,11 +149,13 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet, fp64 matrix cores (the guide h
 
 def syrk_roofline(N, K, syrk_ms):
     """The X^T X launch of the GRAM / KERNEL_TYPE2 plans on the MFMA roofline: flops the kernel EXECUTES (16 x 16 tiles:
-    the 128 x 128 blocks above the diagonal in full, 40 of 64 tiles of every diagonal block) / launch time."""
+    the 128 x 128 blocks above the diagonal in full, of every diagonal block the 36 of 64 tiles on or above its diagonal
+    -- 40 with PLS_HIP_SYRK_W8=0, the 4-wave form) / launch time."""
     if not syrk_ms or syrk_ms <= 0:
         return None
     nbk = (K + 127) // 128
-    tiles = 64 * (nbk * (nbk - 1) // 2) + 40 * nbk
+    diag_tiles = 40 if os.environ.get("PLS_HIP_SYRK_W8") == "0" else 36
+    tiles = 64 * (nbk * (nbk - 1) // 2) + diag_tiles * nbk
     executed = 2.0 * N * 16 * 16 * tiles
     ach = executed / (syrk_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "syrk (X^T X, fp64 MFMA 16x16x4)", "achieved": round(ach, 2), "peak": FP64_MFMA_PEAK_TFLOPS,
