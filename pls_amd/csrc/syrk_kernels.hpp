@@ -677,7 +677,7 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
             // (the 8-wave form: a diagonal workgroup's tiles each read their own two operands -- 0.74 measured for one response)
             static const bool w8w = !(getenv("PLS_HIP_SYRK_W8") && atoi(getenv("PLS_HIP_SYRK_W8")) == 0);
             const double dw = wenv > 0.0 ? wenv
-                                         : (w8w ? (fuse_y0 ? (M == 1 ? 0.74 : 0.80) : 0.66) : (fuse_y0 ? (M == 1 ? 0.70 : 0.78) : 0.625));
+                                         : (w8w ? (fuse_y0 ? (M == 1 ? 0.74 : 0.82) : 0.66) : (fuse_y0 ? (M == 1 ? 0.70 : 0.78) : 0.625));
             const double units = (nblocks - nbk) + dw * nbk;
             Sg = (i64)(slots / units);
             Sd = std::max<i64>(1, (i64)(dw * Sg));
