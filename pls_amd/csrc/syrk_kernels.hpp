@@ -596,7 +596,7 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
 }
 
 template <typename T>
-__global__ __launch_bounds__(512, 2) void syrk_glds8_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
+__global__ __launch_bounds__(512, 4) void syrk_glds8_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
                                                             const T *__restrict__ zeros, double *__restrict__ part, int so, int sd,
                                                             const T *__restrict__ Y, i64 ldy, int M, double *__restrict__ xypart) {
     // grid layout as syrk_glds_kernel: first so splits of every off-diagonal block, then sd of every diagonal block
