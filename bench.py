@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--defer", type=int, default=1, choices=[1, 2, 3, 4],
                     help="NIPALS plan: write the deflated matrix back every D-th component only (default 1 = explicit "
                          "deflation every component, the headline)")
+    ap.add_argument("--alt-timeout", type=float, default=90.0, help="N > 1: seconds the RCCL leg (alt.rccl) may take before the "
+                    "line is printed without it")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=1 << 20, help="rows of the CPU baseline sample (default: the whole workload, ~10 s on one core)")
     return ap.parse_args()
@@ -187,6 +189,42 @@ def cpu_baseline(N, K, M, A, rows):
     omp = {"value": round(A / tn * scale, 4), "unit": "components/s", "cores": gen.num_threads(), "kind": "port",
            "sample": f"same sample, -O3 -march=x86-64-v3 -fopenmp, one fit = {tn:.2f} s"}
     return base, omp
+
+
+def rccl_leg(h, a, torch, dist, world, X, Y, A, out, reducer_used):
+    """N > 1: a short second leg of the same sharded fit under the library's RCCL reducer (ncclAllReduce issued on the
+    launch stream between the kernels -- the north star's "RCCL all-reduce over xGMI"), whatever reducer the headline ran
+    with, so that every scaling run carries an RCCL figure and the rank count RCCL itself reports.  Every rank takes
+    the same branches (the outcome of each step is agreed through torch.distributed).  Returns the dict for alt.rccl."""
+    from pls_amd.distributed import attach_rccl_reducer, detach_ipc_exchange, detach_rccl_reducer, rccl_comm_count
+    if a.backend != "nccl":
+        return {"unavailable": "rehearsal backend gloo: the ranks share one GPU, which RCCL refuses (one rank per device)"}
+    import pls_amd
+    already = reducer_used.startswith("rccl")
+    try:
+        if reducer_used.startswith("ipc"):
+            detach_ipc_exchange(h)
+        if not already:
+            if reducer_used.startswith("torch"):
+                h.clear_reducer()
+            attach_rccl_reducer(h)
+        ok, why = 1, ""
+    except Exception as e:  # noqa: BLE001
+        ok, why = 0, repr(e)
+    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if ok and not already:
+            detach_rccl_reducer(h)
+        return {"unavailable": "library RCCL communicator could not be set up" + (": " + why if why else " on another rank")}
+    nranks = rccl_comm_count(h)
+    h.set_option(pls_amd.OPT_PROFILE, 0)
+    steps = min(a.steps, 3)
+    el, _ = timed_fits(h, torch, dist, world, X, Y, A, steps, 1, out)
+    h.synchronize()
+    return {"components_per_s": round(A * steps / el, 2), "ms_per_fit": round(el / steps * 1e3, 3), "steps": steps,
+            "nranks_reported_by_rccl": nranks, "reducer": "ncclAllReduce(ncclDouble, ncclSum) on the launch stream, "
+            "8*K*M values once + 8*(K+1) values per component (include/pls_hip_rccl.h)"}
 
 
 def spawn_ranks(a):
@@ -393,6 +431,24 @@ def main():
             alt["deflate_kernel"] = roofline_of(td)
             del W
         line["alt"] = alt
+
+    if world > 1 and not a.no_alt:
+        # The RCCL leg must never cost the run its line: if it does not finish in time (a communicator that hangs in its
+        # set-up on one rank) rank 0 prints the headline as measured and every rank leaves.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line.setdefault("alt", {})["rccl"] = {"unavailable": f"RCCL leg did not finish within {a.alt_timeout} s"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(a.alt_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        res = rccl_leg(h, a, torch, dist, world, X, Y, A, out, reducer_used)
+        dog.cancel()
+        line.setdefault("alt", {})["rccl"] = res
 
     if rank == 0:
         if not a.no_cpu and world == 1:  # the CPU leg runs on rank 0 at N = 1 only

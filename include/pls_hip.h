@@ -105,10 +105,21 @@ typedef enum {
 
 /*
  * In-place sum over ranks of `count` fp64 values at DEVICE address `buf`, ordered on
- * `stream` (a hipStream_t).  Must leave bit-identical results on every rank.  Called
- * 1 + A times per fit: once with count = 8*K*M (the X^T Y partial, in PLS_HIP_REDUCE_SLICES
- * fixed-order slices), then once per component with count = 8*(K+1) (slices of the packed
- * [X^T t, t^T t]).  Return 0 on success.
+ * `stream` (a hipStream_t).  Must leave bit-identical results on every rank.
+ * EVERY message is SLICED: `count` is a multiple of PLS_HIP_REDUCE_SLICES, the buffer is
+ * PLS_HIP_REDUCE_SLICES slices of count / 8 values, and the library's consumers add the
+ * slices of a value in index order.  A reducer may therefore either sum element by element
+ * (RCCL, torch.distributed) or leave the total of the 8 slices in slice 0 and zeros in
+ * slices 1..7 (the library's device-side exchanges); the library never calls it with an
+ * unsliced count.
+ * Calls per KERNEL_TYPE1 fit: once with count = 8*K*M (the X^T Y partial), once per
+ * component with count = 8*(K+1) (the packed [X^T t, t^T t]), and -- on every fit of a
+ * handle with nranks > 1 -- once more with count = 8*8 after the component loop: the
+ * replica-divergence guard (checksums of W, P, Q, R, B; the environment switch
+ * PLS_HIP_REPLICA_GUARD=0, which must be set identically on EVERY rank, removes it).
+ * KERNEL_TYPE2 / GRAM add one message of 8*K*K (X^T X); pls_hip_colwise_z_scores sends two
+ * of 8*K, pls_hip_sse_by_components one of 8*A*M per range of component counts.
+ * Return 0 on success.
  */
 #define PLS_HIP_REDUCE_SLICES 8
 typedef int (*pls_hip_allreduce_fn)(void *user, void *buf, int64_t count, void *stream);

@@ -27,6 +27,8 @@ extern "C" {
 PLS_HIP_API int pls_hip_rccl_unique_id(void *id);
 /* creates the communicator for (rank, nranks) on the handle's device and installs it as the reducer */
 PLS_HIP_API int pls_hip_rccl_attach(pls_hip_handle h, int device, const void *id, int rank, int nranks, void **comm_out);
+/* the number of ranks the communicator itself reports (ncclCommCount): evidence that RCCL saw every rank */
+PLS_HIP_API int pls_hip_rccl_comm_count(void *comm, int *nranks);
 /* removes the reducer (back to a single-rank handle) and destroys the communicator */
 PLS_HIP_API int pls_hip_rccl_detach(pls_hip_handle h, void *comm);
 

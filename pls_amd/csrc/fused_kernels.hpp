@@ -48,6 +48,22 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
     __builtin_memcpy(&raw, &p, 16);
     __builtin_amdgcn_raw_buffer_store_b128(raw, r, voff, 0, AUX);
 }
+// the same with a wave-uniform byte offset beside the lane offset (the instruction's scalar offset operand): one
+// descriptor serves every column group of a contiguous tile
+template <typename T, int V, int AUX = 0>
+__device__ __forceinline__ Pack<T, V> buf_ld_so(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff) {
+    static_assert(sizeof(Pack<T, V>) == 16, "16-byte accesses");
+    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
+    Pack<T, V> p;
+    __builtin_memcpy(&p, &raw, 16);
+    return p;
+}
+template <typename T, int V, int AUX = 0>
+__device__ __forceinline__ void buf_st_so(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff, const Pack<T, V> &p) {
+    u32x4 raw;
+    __builtin_memcpy(&raw, &p, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(raw, r, voff, soff, AUX);
+}
 
 // 16-byte access to a score column (t_prev in, t out): the caller's T may have any leading dimension, so its columns are
 // only element-aligned; global memory accesses need dword alignment, nothing more.
@@ -134,9 +150,15 @@ struct TileWalk<true, R> {
 //      round-robin dispatch, every XCD takes one contiguous eighth of the tiles and its workgroups walk it cyclically, so
 //      the two tiles that share a line are read at about the same time behind the SAME L2 -- and the loads drop the
 //      streaming (nt) policy, so that the line is still there.  Per-wave descriptors as in 1.
+// TILED: X (and dst, when DEFL) are the library's row-tile-major copy in THIS tile shape -- ld = R, ts = R K: a tile is
+// one contiguous R K s-byte block, so ONE descriptor per tile (num_records = K R s: columns >= K are out of range) serves
+// all CPT loads and all CPT stores, the column group chosen by the instruction's scalar offset j CG R s.  With a
+// descriptor per column group (the caller's column-major matrix needs those: a column group spans CG ld s bytes) the
+// compiler carried 2 x 16 descriptors across the tile loop as running pointers -- 141 spilled SGPRs and 11 spilled VGPRs
+// in the headline kernel, 0.29 GB of scratch stores per launch at config 3 (profiles/r3/pmc_traffic_C3_nipals_fused.txt).
 template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX_ = AUX_NT, int STAUX = AUX_NT, bool RDST = false,
-          int EDGE = 0>
-__global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pass_kernel(
+          int EDGE = 0, bool TILED = false>
+__global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !(DEFL && TILED)) ? 2 : 1)) void fused_pass_kernel(
     const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd, i64 N, int K,  // dst may alias X (in-place deflation)
     const double *__restrict__ v, const T *__restrict__ tprev, const double *__restrict__ pprev,
     T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart, int rdst, i64 NV) {
@@ -147,6 +169,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
     constexpr int NW = NT / WAVE;
     constexpr int LDAUX = (EDGE == 2) ? 0 : LDAUX_;
     static_assert(RP <= WAVE && WAVE % RP == 0 && NT % RP == 0, "tile shape");
+    static_assert(!TILED || (EDGE == 0 && !RDST), "the tiled copy is aligned and keeps one tile shape");
     // LDS: the operand vectors v [CG*CPT] and, when DEFL, p_prev [CG*CPT], the score exchange, the block-sum
     // scratch.  One static block with a fixed layout (p_prev first): the instruction schedule of the headline
     // kernel turned out to depend on these addresses (1.3 % slower with the vectors after the exchange buffer or
@@ -204,15 +227,29 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
         // loop-invariant keeps 2*CPT fp64 values out of the register file
         int cgz = cg;
         asm volatile("" : "+v"(cgz));
+        if constexpr (TILED && DEFL) {
+            // pacing: `rdst` x 64 cycles of s_sleep before a tile's loads go out (launcher: fused_pace)
+            for (int q = 0; q < rdst; ++q) __builtin_amdgcn_s_sleep(1);
+        }
         Pack<T, V> x[CPT];
+        constexpr int GSTEP = CG * R * (int)sizeof(T);  // TILED: bytes between the column groups of a tile
+        const int trec = K * R * (int)sizeof(T);        // TILED: bytes of a tile
+        if constexpr (TILED) {
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X + tile * tsx), (short)0, trec, BUF_WORD3);
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int cols = min(CGD, K - CG * j - cgw);  // columns of this group that exist (may be <= 0)
-            const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldx * (i64)sizeof(T)) : 0u;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<T *>(X + tile * tsx + (i64)(j * CG + cgw) * ldx), (short)0, (int)nrec, BUF_WORD3);
-            x[j] = buf_ld<T, V, LDAUX>(rs, xo);
-            __builtin_amdgcn_sched_barrier(0);  // build one descriptor, issue its load, repeat
+            for (int j = 0; j < CPT; ++j) x[j] = buf_ld_so<T, V, LDAUX>(rs, xo, j * GSTEP);
+            __builtin_amdgcn_sched_barrier(0);  // all CPT loads in flight before anything consumes the first
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int cols = min(CGD, K - CG * j - cgw);  // columns of this group that exist (may be <= 0)
+                const uint32_t nrec = cols > 0 ? (uint32_t)((i64)cols * ldx * (i64)sizeof(T)) : 0u;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<T *>(X + tile * tsx + (i64)(j * CG + cgw) * ldx), (short)0, (int)nrec, BUF_WORD3);
+                x[j] = buf_ld<T, V, LDAUX>(rs, xo);
+                __builtin_amdgcn_sched_barrier(0);  // build one descriptor, issue its load, repeat
+            }
         }
         if (DEFL) {
             double tp[V];
@@ -238,7 +275,11 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
                 const double pk = ps[cgz + CG * j];
 #pragma unroll
                 for (int e = 0; e < V; ++e) x[j].v[e] = (T)fma(tp[e], pk, (double)x[j].v[e]);
-                if constexpr (RDST) {  // lane offsets span several destination tiles: columns >= K masked per lane
+                if constexpr (TILED) {
+                    const __amdgpu_buffer_rsrc_t rd =
+                        __builtin_amdgcn_make_buffer_rsrc(dst + tile * tsd, (short)0, trec, BUF_WORD3);
+                    buf_st_so<T, V, STAUX>(rd, dof, j * GSTEP, x[j]);
+                } else if constexpr (RDST) {  // lane offsets span several destination tiles: columns >= K masked per lane
                     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
                         dst + tile * dtile + (i64)j * CG * ldd, (short)0, 0x7fffffff, BUF_WORD3);
                     buf_st<T, V, STAUX>(rd, (cg + CG * j < K) ? dof : OOR, x[j]);
@@ -251,6 +292,9 @@ __global__ __launch_bounds__(NT, (NT / 256) * (CPT <= 16 ? 2 : 1)) void fused_pa
                 }
             }
         }
+        // the deflated tile goes out BEFORE the score arithmetic (left to itself the compiler sinks the stores behind the
+        // score FMAs and the first butterfly level: 1.387 instead of 1.354 ms per launch at config 3)
+        if constexpr (TILED && DEFL) __builtin_amdgcn_sched_barrier(0);
         // score: partial over this lane's columns, then over the lanes / waves sharing the rows
         double tp2[V];
 #pragma unroll
@@ -1032,19 +1076,29 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows - 1);
         if (grid < 1) return 1;
         const dim3 g((unsigned)grid), b(NT);
-#define FUSED_LAUNCH(CPT_, DEFL_, EDGE_, dyn_)                                                                            \
+        // a deflating pass IN the library's tiled copy (source and destination in this tile shape: ld = R, ts = R K): the
+        // one-descriptor-per-tile form (TILED); the short tiles (CGX > 32) only ever hold that copy
+        static const int pace_env = getenv("PLS_HIP_PACE") ? atoi(getenv("PLS_HIP_PACE")) : 0;  // EXPERIMENT
+        static const int tiled_env = getenv("PLS_HIP_TILED") ? atoi(getenv("PLS_HIP_TILED")) : 1;  // A/B measurements only (CGX <= 32)
+        const bool tiled = defl && edge == 0 && rdst == 0 && ldx == R && ldd == R && tsx == (i64)R * K && tsd == (i64)R * K &&
+                           (tiled_env != 0 || CGX > 32);
+        if (CGX > 32 && defl && !tiled) return 1;
+#define FUSED_LAUNCH(CPT_, DEFL_, EDGE_, TILED_, dyn_)                                                                    \
     do {                                                                                                                  \
-        auto kfn = &fused_pass_kernel<T, V, R, NT, CPT_, DEFL_, AUX_NT, AUX_NT, false, EDGE_>;                           \
+        auto kfn = &fused_pass_kernel<T, V, R, NT, CPT_, DEFL_, AUX_NT, AUX_NT, false, EDGE_, TILED_>;                   \
         if ((dyn_) > 48 * 1024 && !raise_dynamic_lds(reinterpret_cast<const void *>(kfn), (int)(dyn_))) return 1;         \
-        hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, 0, N); \
+        hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, (TILED_) ? pace_env : 0, N); \
     } while (0)
 #define FUSED_EDGE(CPT_, DEFL_, dyn_)                                                                                     \
     do {                                                                                                                  \
-        if constexpr (CGX <= 32) {                                                                                        \
-            if (edge == 2) { FUSED_LAUNCH(CPT_, DEFL_, 2, dyn_); break; }                                                 \
-            if (edge == 1) { FUSED_LAUNCH(CPT_, DEFL_, 1, dyn_); break; }                                                 \
+        if constexpr (DEFL_) {                                                                                            \
+            if (tiled) { FUSED_LAUNCH(CPT_, DEFL_, 0, true, dyn_); break; }                                               \
         }                                                                                                                 \
-        FUSED_LAUNCH(CPT_, DEFL_, 0, dyn_);                                                                               \
+        if constexpr (CGX <= 32) {                                                                                        \
+            if (edge == 2) { FUSED_LAUNCH(CPT_, DEFL_, 2, false, dyn_); break; }                                          \
+            if (edge == 1) { FUSED_LAUNCH(CPT_, DEFL_, 1, false, dyn_); break; }                                          \
+        }                                                                                                                 \
+        if constexpr (CGX <= 32 || !DEFL_) FUSED_LAUNCH(CPT_, DEFL_, 0, false, dyn_);                                     \
     } while (0)
 #define FUSED_CASE(CPT_)                                                                                                  \
     do {                                                                                                                  \

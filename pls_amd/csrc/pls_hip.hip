@@ -664,8 +664,12 @@ int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, 
     return PLS_HIP_OK;
 }
 
+// Every collective of the library is a SLICED message: RED_SLICES slices of count / RED_SLICES values each, whose
+// consumers add the slices in index order (an element-wise all-reduce keeps that layout; the device-side exchanges
+// leave the total in slice 0 and zeros behind it) -- include/pls_hip.h, pls_hip_allreduce_fn.
 int do_allreduce(pls_hip_context *c, double *buf, i64 count) {
     if (!c->reducer) return PLS_HIP_OK;  // an installed reducer is called even for one rank
+    if (count % plsk::RED_SLICES != 0) return fail(c, PLS_HIP_ERR_REDUCER, "internal: collective of " + std::to_string(count) + " values is not sliced");
     const int rc = c->reducer(c->reducer_user, buf, count, (void *)c->stream);
     if (rc != 0) return fail(c, PLS_HIP_ERR_REDUCER, "all-reduce callback returned " + std::to_string(rc));
     return PLS_HIP_OK;
@@ -1739,10 +1743,13 @@ int zscores_device(pls_hip_context *c, const T *X, i64 ldx, i64 N, i64 n_total, 
         // all workgroups resident at once (5 per CU at 84 VGPRs): one round, no tail
         const int G1 = (int)std::min<i64>(nch, std::max<i64>(1, (5 * c->num_cu) / nkg));
         const bool sharded = c->reducer != nullptr;
-        CHK(ensure(c, c->part, (size_t)(G1 * (3 * (i64)K + 1) + (sharded ? 4 * (i64)K + 1 : 0)) * 8));
+        // (the shards' sums travel in the layout every collective of the library has -- RED_SLICES slices of K values, the
+        // values in slice 0, zeros behind: the device-side exchanges sum the slices of a message into slice 0)
+        CHK(ensure(c, c->part, (size_t)(G1 * (3 * (i64)K + 1) + (sharded ? (3 + (i64)plsk::RED_SLICES) * K + 1 : 0)) * 8));
         part = (double *)c->part.p;
         double *cnt = part + (i64)G1 * 3 * K;
         double *tri = sharded ? cnt + G1 : nullptr, *buf = sharded ? tri + 3 * (i64)K + 1 : nullptr;
+        if (sharded) HIPCHK(c, hipMemsetAsync(buf + K, 0, (size_t)(plsk::RED_SLICES - 1) * K * 8, c->stream));
         const dim3 gk((K + plsk::WG - 1) / plsk::WG);
         if (N > 0) {
             {
@@ -1763,7 +1770,7 @@ int zscores_device(pls_hip_context *c, const T *X, i64 ldx, i64 N, i64 n_total, 
                 hipLaunchKernelGGL(plsk::colmoments_shard_kernel, gk, blk, 0, c->stream, (const double *)tri, K, (double)n_total, step,
                                    buf, mean, sd);
                 LAUNCH_CHECK(c);
-                if (step < 2) CHK(do_allreduce(c, buf, K));
+                if (step < 2) CHK(do_allreduce(c, buf, (i64)plsk::RED_SLICES * K));
             }
         }
     }

@@ -47,6 +47,11 @@ int pls_hip_rccl_attach(pls_hip_handle h, int device, const void *id, int rank, 
     return PLS_HIP_OK;
 }
 
+int pls_hip_rccl_comm_count(void *comm, int *nranks) {
+    if (!comm || !nranks) return PLS_HIP_ERR_INVALID;
+    return ncclCommCount(static_cast<ncclComm_t>(comm), nranks) == ncclSuccess ? PLS_HIP_OK : PLS_HIP_ERR_DEVICE;
+}
+
 int pls_hip_rccl_detach(pls_hip_handle h, void *comm) {
     if (!h) return PLS_HIP_ERR_INVALID;
     (void)pls_hip_synchronize(h);

@@ -150,6 +150,15 @@ def attach_rccl_reducer(handle, group=None):
     return comm
 
 
+def rccl_comm_count(handle) -> int:
+    """ranks of the attached RCCL communicator as RCCL reports them (ncclCommCount)"""
+    lib, comm = handle._rccl
+    lib.pls_hip_rccl_comm_count.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    n = ctypes.c_int(0)
+    L.check(lib.pls_hip_rccl_comm_count(comm, ctypes.byref(n)), handle.h)
+    return int(n.value)
+
+
 def detach_rccl_reducer(handle):
     lib, comm = handle._rccl
     L.check(lib.pls_hip_rccl_detach(handle.h, comm), handle.h)

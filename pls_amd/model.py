@@ -119,6 +119,12 @@ class Handle:
     def synchronize(self):
         L.check(self._lib.pls_hip_synchronize(self.h), self.h)
 
+    def clear_reducer(self):
+        """back to a single-rank handle (the reducer installed by pls_amd.distributed.attach_reducer is dropped)"""
+        self.synchronize()
+        L.check(self._lib.pls_hip_set_reduce_buffer(self.h, None, 0), self.h)
+        L.check(self._lib.pls_hip_set_reducer(self.h, L.ALLREDUCE_FN(), None, 0, 1), self.h)
+
     def timing(self) -> dict:
         t = L.Timing()
         L.check(self._lib.pls_hip_get_timing(self.h, ctypes.byref(t)), self.h)

@@ -39,7 +39,7 @@ def test_rccl_helper_exports():
     out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
     src = open(os.path.join(ROOT, "include", "pls_hip_rccl.h")).read()
     declared = sorted(set(re.findall(r"PLS_HIP_API\s+int\s+(pls_hip_rccl_\w+)\s*\(", src)))
-    assert sorted(set(re.findall(r" T (pls_hip_rccl_\w+)", out))) == declared and len(declared) == 3
+    assert sorted(set(re.findall(r" T (pls_hip_rccl_\w+)", out))) == declared and len(declared) == 4
 
 
 def test_header_is_plain_c():

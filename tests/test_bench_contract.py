@@ -68,6 +68,9 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["parallelism"] == "row-shard x2"
     assert d["roofline"]["measured_over"].startswith("separate profiled steps")
+    # the RCCL leg: a figure with the rank count RCCL reports, or the reason there is none (two ranks on ONE GPU here)
+    rl = d["alt"]["rccl"]
+    assert ("components_per_s" in rl and rl["nranks_reported_by_rccl"] == 2) or "one rank per device" in rl["unavailable"], rl
 
 
 @pytest.mark.gpu

@@ -370,10 +370,15 @@ def test_sharded_fit_over_the_ipc_exchange(world, splits, algo, method):
     g = np.load(os.path.join(GOLDEN, "c5twin_4096x1024_m4_A20.npz"))
     N, K, M, A = (int(g[k]) for k in ("N", "K", "M", "A"))
     res = _run(world, N, K, M, A, algo, 1, method=method, splits=splits, reducer="ipc")
+    X = po.OracleLib().synth_x(0, N, K)
     for rank, out in res:
         assert po.rel_fro(out["B"], g["B"]) < 1e-10, rank
         for k in "WPQRB":
             assert np.array_equal(out[k], res[0][1][k]), (rank, k)
+        # the column statistics of ALL rows went through the same exchange (sliced messages: K % 8 == 0 here, the case in
+        # which an unsliced message would have been folded silently)
+        assert np.allclose(out["mean"], X.mean(0), rtol=1e-12, atol=1e-13), rank
+        assert np.allclose(out["sd"], X.std(0, ddof=1), rtol=1e-11), rank
     if method == 0:
         T = np.concatenate([out["T"] for _, out in res], axis=0)
         G = T.T @ T
