@@ -15,6 +15,9 @@ typedef int64_t i64;
 
 constexpr int WAVE = 64;
 constexpr int WG = 256;
+// slices of every reduced vector (reduce_partials_kernel, slice_tail): enough workgroups take part in a reduction, and the
+// consumers add the slices of a value in index order
+constexpr int RED_SLICES = 8;
 
 // VEC consecutive rows of one column = one 16-byte (or narrower) global access per lane.
 template <typename T, int V>
@@ -146,6 +149,13 @@ __device__ __forceinline__ double block_sum(double x, double *smem) {
 #pragma unroll
     for (int i = 0; i < NW; ++i) s += smem[i];
     return s;
+}
+
+// 8-byte store that leaves this XCD's L2 at once (global_store_dwordx2 sc1): the producer side of a hand-off to another
+// workgroup of the same launch (MI355X_MICROARCH.md, "Valid forms")
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): a process that drives several

@@ -28,10 +28,6 @@ namespace plsk {
 constexpr int COOP_WG = 256, COOP_MAXG = 64, COOP_CH = 32, COOP_SP = 40;
 constexpr int COOP_QSTRIDE = 8, COOP_GSTRIDE = 36;
 
-__device__ __forceinline__ void st_agent(double *p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
 // Every partial this workgroup publishes has been stored by wave 0 (agent scope) before the call.
 __device__ __forceinline__ void grid_exchange(unsigned *cnt, unsigned G) {
     if (threadIdx.x < WAVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -49,7 +45,6 @@ __device__ __forceinline__ void grid_exchange(unsigned *cnt, unsigned G) {
 // not by L2: lane-scattered rows cost one fabric read per lane and instruction -- 10 us for 36 values x 16
 // workgroups -- and relaxed ATOMIC loads are issued one at a time).  All threads of the workgroup call it; the total
 // of value t is returned in thread t (t < nv <= COOP_SP) as the index-ordered sum over the workgroups.
-constexpr int AUX_SC1 = 16;
 constexpr int COOP_LBUF = COOP_SP * COOP_MAXG;  // doubles of LDS staging
 __device__ __forceinline__ double gather_totals(const double *part, int nv, unsigned G, double *lbuf) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(part), (short)0, 0x7fffffff, BUF_WORD3);

@@ -14,6 +14,7 @@
 // that failed or fell out of step) sets the member's status words and leaves the loop; later waits of the same member
 // return at once.  Messages longer than XCHG_CAP go in pieces (or, in the group, through the host-synchronised path).
 #pragma once
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -29,6 +30,18 @@ constexpr double XCHG_TIMEOUT_S = 30.0;  // (a peer's first fit may still be loa
 struct XchgPeers {
     double *slot[XCHG_MAX];                 // inbox slot [parity][my rank] of every member
     unsigned long long *flag[XCHG_MAX];     // its flag
+};
+
+// The consumer side of one collective as kernel arguments: what a kernel needs to wait for the members' pushes of
+// collective `seq` and to read their vectors (the gather as the PROLOGUE of the component update, small_kernels.hpp)
+struct XchgGather {
+    const double *inbox = nullptr;              // this member's slots of the parity seq & 1: [n][cap]
+    const unsigned long long *flags = nullptr;  // its n flags of that parity
+    int n = 0;                                  // 0: no gather (the reduced slices are in `red`)
+    i64 cap = 0;
+    unsigned long long seq = 0;
+    int *status = nullptr, *host_status = nullptr;
+    long long limit = 0;
 };
 
 // buf: `slices` slices of Ltot doubles; the piece [j0, j0 + L) of their sum goes out
@@ -136,13 +149,15 @@ inline int xchg_launch_piece(hipStream_t stream, int n, int rank, double *const 
     }
     // fault injection for the tests of the time-out path: PLS_HIP_TEST_DROP_PUSH="rank:collective" makes that rank skip
     // that one push, once per process (its peers -- and itself -- then wait for a flag that never comes)
+    // (UNSUPPORTED outside the test-suite: a stray value ends a production fit in a time-out.  The flag is atomic: the
+    // members of a group call this from concurrent host threads.)
     static const char *drop = getenv("PLS_HIP_TEST_DROP_PUSH");
-    static bool dropped = false;  // (once per process)
+    static std::atomic<bool> dropped{false};  // (once per process)
     bool skip = false;
-    if (drop && !dropped) {
+    if (drop && !dropped.load(std::memory_order_relaxed)) {
         int dr = -1;
         unsigned long long dq = 0;
-        if (sscanf(drop, "%d:%llu", &dr, &dq) == 2) skip = dropped = (dr == rank && dq == seq);
+        if (sscanf(drop, "%d:%llu", &dr, &dq) == 2 && dr == rank && dq == seq) skip = !dropped.exchange(true);
     }
     static const bool fused = !(getenv("PLS_HIP_XCHG_FUSED") && atoi(getenv("PLS_HIP_XCHG_FUSED")) == 0);
     if (fused && L <= XCHG_FUSED_MAX) {

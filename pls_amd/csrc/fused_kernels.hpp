@@ -23,6 +23,7 @@
 // an in-wave butterfly -- no atomics anywhere, results are bit-reproducible.
 #pragma once
 #include "common.hpp"
+#include "exchange_kernels.hpp"  // XchgPeers: the push of a sharded fit's sums rides in the tail of the pass
 
 namespace plsk {
 
@@ -32,6 +33,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // offsets are plain byte offsets, range-checked against num_records -- an out-of-range load
 // returns 0 and an out-of-range store is dropped, which is how the ragged edges are handled.
 constexpr int BUF_WORD3 = 0x00020000;
+constexpr int AUX_SC1 = 16;  // cache-policy bit sc1: served by the fabric, not by this XCD's L2 (what another XCD's sc1 stores wrote)
 
 // AUX: cache-policy bits of the buffer instruction (gfx94x/gfx950: bit0 sc0, bit1 nt, bit4 sc1)
 template <typename T, int V, int AUX = 0>
@@ -87,6 +89,150 @@ __device__ __forceinline__ void st_pack_u(T *p, const Pack<T, V> &x) {
 template <typename T>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t score_rsrc(const T *col, i64 nvalid) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(col), (short)0, (int)(nvalid * (i64)sizeof(T)), BUF_WORD3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Reduction of the per-workgroup partial rows INSIDE the launch that wrote them (instead of reduce_partials_kernel behind
+// it), and -- in a row-sharded fit over the device-side exchange -- the push of the sums to the peers from the same tail:
+// a sharded component is then two launches, pass -> update, instead of pass -> reduce -> exchange -> update.
+//
+// The rows [lo, hi) of slice s are those of reduce_partials_kernel (lo = nrows s / 8); every workgroup stores its row with
+// sc1 stores, waits for them, and ONE lane adds 1 to the slice's arrival counter (agent scope).  The workgroup whose add
+// came last -- told by the value the add returned, so the order of arrival is free -- acquires (agent scope) and sums the
+// slice's rows in exactly the order of reduce_partials_kernel: four interleaved chains per column, row index ascending,
+// (c0 + c1) + (c2 + c3); the bits do not depend on which workgroup does it or when.  Rows written BEFORE the launch
+// (tail_rows_kernel's row of the last N % V rows: row nrows - 1) are complete by stream order and not counted.
+// Sharded (npush > 0): the last of the RED_SLICES slice reducers adds the slices in index order and writes the vector into
+// slot [seq & 1][rank] of every member's inbox, then publishes seq in the flags (exchange_kernels.hpp: xchg_push_kernel);
+// the gather is the prologue of the component update (small_kernels.hpp).
+// Counters: RED_SLICES + 1 words, zero before the first launch of a fit; every counter is reset by its last arriver.
+// Every wait is an atomic's return value or a barrier: no spinning, nothing that needs other workgroups to be resident.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SliceTail {
+    unsigned *cnt = nullptr;  // nullptr: no tail (reduce_partials_kernel follows the launch)
+    double *red = nullptr;    // RED_SLICES slices of K + 1 values
+    int nrows = 0;            // partial rows in all: this launch's workgroups (+ 1 written before the launch)
+    int npush = 0;            // members of the exchange to push to; 0: single rank or a reducer of the caller's
+    unsigned long long seq = 0;
+    XchgPeers peers;
+};
+
+constexpr int TAIL_MIN_WG = 32;  // fewer workgroups: a slice could be left without one (reduce_partials_kernel instead)
+
+// all NT threads of the workgroup call it after their stores of part / sspart have been waited for and a barrier;
+// role: one int of LDS, sm: >= 4 doubles of LDS
+// Hand-off: every handed-off byte is stored sc1, waited for by the storing wave, and loaded sc1 behind the returned add
+// and a barrier -- MI355X_MICROARCH.md "Valid forms", first row of its table (hipMalloc memory, ONE workgroup per CU, 8-byte
+// accesses): the launchers use the tail for launches of one workgroup per CU only.  (With two per CU -- the read-only
+// passes at 16 columns per lane -- a slice is 64 rows, its last workgroup reads 256 KB behind an agent-scope acquire, and
+// the pass + tail lost 4.7 us per component to pass + reduce_partials_kernel at config 3: profiles/r4/tail_ab.txt.)
+template <int NT>
+__device__ __forceinline__ void slice_tail(const SliceTail &st, const double *part, const double *sspart, int K, int *role,
+                                           double *sm) {
+    static_assert(NT >= WG, "the t^T t sum takes the first four waves");
+    const int tid = threadIdx.x, nb = st.nrows, nwg = gridDim.x, b = blockIdx.x;
+    const int sl = (int)(((i64)(b + 1) * RED_SLICES + nb - 1) / nb) - 1;  // lo(sl) <= b < hi(sl)
+    const int lo = (int)((i64)nb * sl / RED_SLICES), hi = (int)((i64)nb * (sl + 1) / RED_SLICES);
+    if (tid == 0) {
+        const unsigned mine = (unsigned)(min(hi, nwg) - lo);  // workgroups of this launch in the slice
+        const unsigned ticket = __hip_atomic_fetch_add(st.cnt + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (ticket + 1u == mine);
+        if (last) {
+            __hip_atomic_store(st.cnt + sl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (nobody else comes)
+        }
+        *role = last;
+    }
+    __syncthreads();
+    if (!*role) return;
+    const i64 LP = K + 1;
+    double ssl = 0.0;  // t^T t of the slice, this thread's strided share: loaded ahead of the rows
+    {
+        const __amdgpu_buffer_rsrc_t rq =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(sspart), (short)0, nb * 8, BUF_WORD3);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        if (tid < WG)
+            for (int r = lo + tid; r < hi; r += WG) {
+                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rq, (uint32_t)r * 8u, 0, AUX_SC1);
+                double d;
+                __builtin_memcpy(&d, &raw, 8);
+                ssl += d;
+            }
+    }
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(part + (i64)lo * K), (short)0,
+                                                                            (int)((i64)(hi - lo) * K * 8), BUF_WORD3);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        auto ld = [&](int row, int j) -> double {  // (rows beyond hi - lo: out of range, zero)
+            const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs, (uint32_t)(((i64)row * K + j) * 8), 0, AUX_SC1);
+            double d;
+            __builtin_memcpy(&d, &raw, 8);
+            return d;
+        };
+        const int nr = hi - lo;
+        for (int j = tid; j < K; j += NT) {
+            double c[4] = {0.0, 0.0, 0.0, 0.0};
+            int r = 0;
+            for (; r + 16 <= nr; r += 16) {  // 16 loads in flight per lane; chain q takes the rows lo + q, lo + q + 4, ...
+                double x[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) x[u] = ld(r + u, j);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) c[u & 3] += x[u];
+            }
+            for (; r < nr; r += 4) {
+                double x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = (r + u < nr) ? ld(r + u, j) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (r + u < nr) c[u] += x[u];
+            }
+            st_agent(st.red + (i64)sl * LP + j, (c[0] + c[1]) + (c[2] + c[3]));
+        }
+    }
+    {  // t^T t of the slice: reduce_partials_kernel's sum -- 256 strided sums, wave sums, waves 0..3 in order
+        double s = wave_sum(ssl);
+        __syncthreads();
+        if ((tid & 63) == 0 && tid < WG) sm[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) st_agent(st.red + (i64)sl * LP + K, ((sm[0] + sm[1]) + sm[2]) + sm[3]);
+    }
+    if (st.npush <= 0) return;
+    // ---- the sums of all slices -> every member's inbox (the last of the RED_SLICES slice reducers)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(st.cnt + RED_SLICES, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (ticket + 1u == (unsigned)RED_SLICES);
+        if (last) {
+            __hip_atomic_store(st.cnt + RED_SLICES, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *role = last;
+    }
+    __syncthreads();
+    if (!*role) return;
+    {
+        const __amdgpu_buffer_rsrc_t rr =
+            __builtin_amdgcn_make_buffer_rsrc(st.red, (short)0, (int)((i64)RED_SLICES * LP * 8), BUF_WORD3);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        for (int j = tid; j <= K; j += NT) {
+            double x[RED_SLICES];
+#pragma unroll
+            for (int i = 0; i < RED_SLICES; ++i) {
+                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rr, (uint32_t)(((i64)i * LP + j) * 8), 0, AUX_SC1);
+                __builtin_memcpy(&x[i], &raw, 8);
+            }
+            double sum = x[0];
+#pragma unroll
+            for (int i = 1; i < RED_SLICES; ++i) sum += x[i];  // (the order of xchg_push_kernel)
+            for (int d = 0; d < st.npush; ++d) __hip_atomic_store(st.peers.slot[d] + j, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        // the inboxes are fine-grained (uncached) memory: a store that has been acknowledged is visible to its device; every
+        // wave waits for its own, the flags go out behind the barrier (release: ordered behind this thread's stores too)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < st.npush) __hip_atomic_store(st.peers.flag[tid], st.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Matrix layouts: element (i, k) of a matrix with column stride ld and tile stride ts lives at
@@ -161,7 +307,7 @@ template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX_ = AUX
 __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !(DEFL && TILED)) ? 2 : 1)) void fused_pass_kernel(
     const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd, i64 N, int K,  // dst may alias X (in-place deflation)
     const double *__restrict__ v, const T *__restrict__ tprev, const double *__restrict__ pprev,
-    T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart, int rdst, i64 NV) {
+    T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart, int rdst, i64 NV, const SliceTail st) {
     // N: rows swept (a multiple of V); NV <= N: valid rows of the score columns (the rows between are zero padding of
     // the library's own copy)
     constexpr int RP = R / V;    // lanes along the rows of a tile
@@ -356,10 +502,15 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !(DEFL && TILED)) ?
     for (int j = 0; j < CPT; ++j) {
         const double s = xor_range_sum<1, RP>(pacc[j]);
         const int k = cg + CG * j;
-        if (rp == 0 && k < K) part[(i64)blockIdx.x * K + k] = s;
+        if (rp == 0 && k < K) st_agent(part + (i64)blockIdx.x * K + k, s);  // (sc1: read by the slice's last workgroup)
     }
     ss = block_sum<NW>(ss, sred);
-    if (tid == 0) sspart[blockIdx.x] = ss;
+    if (tid == 0) st_agent(sspart + blockIdx.x, ss);
+    if (st.cnt) {  // (uniform) the partial rows are summed inside this launch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        slice_tail<NT>(st, part, sspart, K, reinterpret_cast<int *>(&tred[0][0][0]), sred);
+    }
 }
 
 // Semi-fused sweep for matrices too wide for the resident tile (K > 32 column groups' worth):
@@ -1037,7 +1188,9 @@ template <typename T, int CGX = 32>
 int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd,
                       i64 N, int K, const double *v, const T *tprev, const double *pprev, T *tout,
                       double *part, int max_rows, double *sspart, int *nb, int *nss, int grid_hint, int rdst = 0,
-                      bool src_padded = false) {
+                      bool src_padded = false, const SliceTail *tail = nullptr, bool *tail_used = nullptr) {
+    // tail (cnt, red, npush, seq, peers set by the caller): sum the partial rows inside the launch (slice_tail) when the
+    // grid is large enough; *tail_used tells the caller whether reduce_partials_kernel is still to run
     // src_padded: X is the library's own copy, whose rows up to the next multiple of V exist and hold zeros -- the sweep
     // runs over them (no tail kernel); otherwise the last N % V rows go to the tail kernel
     constexpr int V = 16 / sizeof(T);
@@ -1063,6 +1216,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     }
     const i64 Nf = src_padded ? (N + V - 1) / V * V : N - N % V;  // whole row packs; the rest is the tail kernel's
     i64 grid = 0;
+    if (tail_used) *tail_used = false;
     if (Nf > 0) {
         const i64 ntiles = (Nf + R - 1) / R;
         // Workgroups per CU.  Read-only passes: two (5 % faster than one on the caller's column-major X).  Read+write
@@ -1076,9 +1230,32 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows - 1);
         if (grid < 1) return 1;
         const dim3 g((unsigned)grid), b(NT);
+        SliceTail st;
+        if (tail && tail->cnt && grid >= TAIL_MIN_WG && per_cu == 1 && grid <= (i64)num_cu) {
+            st = *tail;
+            st.nrows = (int)grid + (Nf < N ? 1 : 0);
+            if (tail_used) *tail_used = true;
+        }
+        if (Nf < N) {  // the last N % V rows FIRST: their partial row (index `grid`) is complete when the sweep's tail sums the rows
+            TailArgs<T> a;
+            a.src = X; a.lds = ldx; a.tss = tsx; a.rs = R;
+            if (defl) {
+                a.dst = dst; a.ldd = ldd; a.tsd = tsd; a.rd = rdst > 0 ? rdst : R;
+                a.tprev = tprev; a.pprev = pprev;
+            }
+            a.v = v; a.tout = tout; a.part = part + grid * K; a.sspart = sspart + grid;
+            a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K; a.zero_rows = V - a.nrows;
+            launch_tail_rows(stream, a);
+        }
         // a deflating pass IN the library's tiled copy (source and destination in this tile shape: ld = R, ts = R K): the
         // one-descriptor-per-tile form (TILED); the short tiles (CGX > 32) only ever hold that copy
-        static const int pace_env = getenv("PLS_HIP_PACE") ? atoi(getenv("PLS_HIP_PACE")) : 0;  // EXPERIMENT
+        // Pacing of the in-place deflating sweep: every wave sleeps 2 x 64 cycles per column of its lanes (32 x 64 cycles per
+        // 128 KB tile) before it issues a tile's loads.  A read+write sweep is faster with LESS in flight (one workgroup
+        // per CU beats two); throttled a little further it gains another 1.5-3 % on every shape measured -- config 3
+        // 0.752 -> 0.772 / 0.774 -> 0.787 of peak on two boxes, an eighth of it 0.723 -> 0.736, config 4 0.784 -> 0.799, a
+        // shard of config 5 0.773 -> 0.786 -- while 64 x 64 cycles already cost one box 2 % (profiles/r4/pace_sweep_*.txt).
+        // PLS_HIP_PACE overrides the 64-cycle units per tile (measurements).
+        static const int pace_env = getenv("PLS_HIP_PACE") ? atoi(getenv("PLS_HIP_PACE")) : -1;
         static const int tiled_env = getenv("PLS_HIP_TILED") ? atoi(getenv("PLS_HIP_TILED")) : 1;  // A/B measurements only (CGX <= 32)
         const bool tiled = defl && edge == 0 && rdst == 0 && ldx == R && ldd == R && tsx == (i64)R * K && tsd == (i64)R * K &&
                            (tiled_env != 0 || CGX > 32);
@@ -1087,7 +1264,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     do {                                                                                                                  \
         auto kfn = &fused_pass_kernel<T, V, R, NT, CPT_, DEFL_, AUX_NT, AUX_NT, false, EDGE_, TILED_>;                   \
         if ((dyn_) > 48 * 1024 && !raise_dynamic_lds(reinterpret_cast<const void *>(kfn), (int)(dyn_))) return 1;         \
-        hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, (TILED_) ? pace_env : 0, N); \
+        hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, (TILED_) ? (pace_env >= 0 ? pace_env : 2 * (CPT_)) : 0, N, st); \
     } while (0)
 #define FUSED_EDGE(CPT_, DEFL_, dyn_)                                                                                     \
     do {                                                                                                                  \
@@ -1111,7 +1288,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
                 auto kfn = edge == 2 ? &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 2>
                                      : (edge == 1 ? &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 1>
                                                   : &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 0>);
-                hipLaunchKernelGGL(kfn, g, b, 0, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, rdst, N);
+                hipLaunchKernelGGL(kfn, g, b, 0, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, rdst, N, st);
             } else if (K <= CG * 4) FUSED_CASE(4);
             else if (K <= CG * 8) FUSED_CASE(8);
             else if (K <= CG * 16) FUSED_CASE(16);
@@ -1138,15 +1315,17 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
 #undef FUSED_LAUNCH
     }
     if (Nf < N) {  // the last N % V rows: one more partial row
-        TailArgs<T> a;
-        a.src = X; a.lds = ldx; a.tss = tsx; a.rs = R;
-        if (defl) {
-            a.dst = dst; a.ldd = ldd; a.tsd = tsd; a.rd = rdst > 0 ? rdst : R;
-            a.tprev = tprev; a.pprev = pprev;
+        if (Nf <= 0) {  // (fewer rows than one pack: nothing but them)
+            TailArgs<T> a;
+            a.src = X; a.lds = ldx; a.tss = tsx; a.rs = R;
+            if (defl) {
+                a.dst = dst; a.ldd = ldd; a.tsd = tsd; a.rd = rdst > 0 ? rdst : R;
+                a.tprev = tprev; a.pprev = pprev;
+            }
+            a.v = v; a.tout = tout; a.part = part + grid * K; a.sspart = sspart + grid;
+            a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K; a.zero_rows = V - a.nrows;
+            launch_tail_rows(stream, a);
         }
-        a.v = v; a.tout = tout; a.part = part + grid * K; a.sspart = sspart + grid;
-        a.row0 = Nf; a.nrows = (int)(N - Nf); a.K = K; a.zero_rows = V - a.nrows;
-        launch_tail_rows(stream, a);
         ++grid;
     }
     *nb = (int)grid;

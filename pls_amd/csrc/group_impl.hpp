@@ -414,6 +414,14 @@ int pls_hip_group_create(pls_hip_group *out, int n, const int *devices) {
         return rc;
     }
     if (g->xchg && !xchg_selftest(g.get())) g->xchg = false;
+    if (g->xchg)  // the members' view of the exchange: the push of a fused component rides in the pass, the gather in the update
+        for (int r = 0; r < n; ++r) {
+            pls_hip_context::XchgEndpoint &e = g->h[r]->xep;
+            e.on = true;
+            e.n = n; e.rank = r;
+            e.inbox = g->inbox.data(); e.flags = g->xflags.data();
+            e.seq = &g->xseq[r]; e.status = g->xstatus[r]; e.host_status = g->xhost_dev + r; e.limit = &g->xlimit[r];
+        }
     *out = g.release();
     return PLS_HIP_OK;
 }

@@ -85,6 +85,19 @@ struct pls_hip_context {
     std::vector<void *> graveyard;
     // cross-process device-side exchange (pls_hip_xchg_*, exchange_kernels.hpp)
     struct XchgIpc *xchg = nullptr;
+    // This member's view of the device-side exchange it belongs to, whoever owns the inboxes (XchgIpc: one process per
+    // GPU; pls_hip_group: the members of one process).  With it the per-component collective of a fused fit is not a
+    // call of the reducer: the push rides in the tail of the pass, the gather is the prologue of the component update.
+    struct XchgEndpoint {
+        bool on = false;
+        int n = 0, rank = 0;
+        double *const *inbox = nullptr;             // [n] the members' inboxes (peer-visible addresses)
+        unsigned long long *const *flags = nullptr;  // [n] their flags
+        unsigned long long *seq = nullptr;           // this member's running collective number
+        int *status = nullptr, *host_status = nullptr;
+        const long long *limit = nullptr;
+    } xep;
+    DevBuf tailcnt;  // arrival counters of slice_tail (fused_kernels.hpp)
     // replica guard of sharded fits (small_kernels.hpp): host-mapped flag "the ranks derived different W/P/Q/R/B"
     int *diverged = nullptr, *diverged_dev = nullptr;
     DevBuf guard;
@@ -565,16 +578,35 @@ int launch_update_large(pls_hip_context *c, const double *red, double *XY, doubl
     return PLS_HIP_OK;
 }
 
+// Will launch_update run the ONE-workgroup kernel for this shape (the form that can take the gather of a sharded fit's
+// collective as its prologue)?  The conditions of the branches in launch_update, in their order.
+bool update_is_single(int K, int M, int A, int a) {
+    static const bool mid_on = !(getenv("PLS_HIP_MID_UPDATE") && atoi(getenv("PLS_HIP_MID_UPDATE")) == 0);
+    static const int wide1_min = getenv("PLS_HIP_WIDE1_MIN") ? atoi(getenv("PLS_HIP_WIDE1_MIN")) : 4097;
+    static const bool widem_on = !(getenv("PLS_HIP_WIDEM_UPDATE") && atoi(getenv("PLS_HIP_WIDEM_UPDATE")) == 0);
+    static const int widem_min = getenv("PLS_HIP_WIDEM_MIN") ? atoi(getenv("PLS_HIP_WIDEM_MIN")) : plsk::COOP_MAXG * plsk::COOP_WG + 1;
+    static const bool coop_on = !(getenv("PLS_HIP_COOP_UPDATE") && atoi(getenv("PLS_HIP_COOP_UPDATE")) == 0);
+    int g = 0, e = 0;
+    if (M > plsk::MMAX || (mid_on && M > 8 && (i64)K * M >= 16384)) return false;
+    if (M == 1 && K >= wide1_min && plsk::wide1_geometry(K, &g, &e)) return false;
+    if (widem_on && M >= 2 && M <= 8 && K >= widem_min && (i64)K * M >= 16384 && A <= 4096 && plsk::wide1_geometry(K, &g, &e)) return false;
+    if (coop_on && plsk::coop_update_covers(K, M) && A <= 4096) return false;
+    const int n = a + 1;
+    return !(n < A && n > 0 && (i64)n * K >= ROTATE_SPLIT_MIN);  // (the r recurrence on several workgroups: two more launches)
+}
+
 // nip: 0 = KERNEL algo (next pass is X r), 1 = NIPALS (next pass X_a w)
-int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, double *P,
-                  double *Q, double *R, double *v, int K, int M, int A, int a, int nip) {
+// gx (only where update_is_single says yes): the gather of the component's collective as the kernel's prologue; red is
+// then written (slice 0) instead of read
+int launch_update(pls_hip_context *c, double *red, double *XY, double *W, double *P,
+                  double *Q, double *R, double *v, int K, int M, int A, int a, int nip, const plsk::XchgGather *gx = nullptr) {
     const int n = a + 1;
     // 9 <= M <= 32 responses on many columns: the one-workgroup kernel walks K x M values several times and forms the
     // M (M + 1) / 2 Gram entries one wave per pair (208 us per component at K = 4096, M = 16; 630 us at M = 32 -- more
     // than the 0.32 ms pass); the multi-workgroup kernels of the many-response path with the LDS eigen solve: ~12 launches
     static const bool mid_on = !(getenv("PLS_HIP_MID_UPDATE") && atoi(getenv("PLS_HIP_MID_UPDATE")) == 0);
     if (M > plsk::MMAX || (mid_on && M > 8 && (i64)K * M >= 16384))
-        return launch_update_large(c, red, XY, W, P, Q, R, v, K, M, A, a, nip);
+        return launch_update_large(c, (const double *)red, XY, W, P, Q, R, v, K, M, A, a, nip);
     // One response on very many columns: element-wise work and K-long sums on up to 128 workgroups, two launches
     // (wide1_update.hpp) instead of one workgroup walking K (+ one workgroup per p_j^T w of the r recurrence)
     static const int wide1_min = getenv("PLS_HIP_WIDE1_MIN") ? atoi(getenv("PLS_HIP_WIDE1_MIN")) : 4097;  // (up to 4096 columns the one-workgroup kernel keeps XY in registers)
@@ -649,9 +681,16 @@ int launch_update(pls_hip_context *c, const double *red, double *XY, double *W, 
     // K > 4096 as well, so the multi-workgroup form below takes over from the fourth component on)
     const bool split = n < A && n > 0 && (i64)n * K >= ROTATE_SPLIT_MIN;
     Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * M * 3 + (i64)K * (2 * (a + 2)) + K) * 8);
-    hipLaunchKernelGGL(plsk::component_update_kernel, dim3(1), dim3(plsk::UPD_THREADS),
-                       (size_t)std::min(A, 4096) * sizeof(double), c->stream, red, XY, W, P, Q, R, v, K, M, A, a, nip,
-                       (int)c->opt_power_iters, (int)split);
+    if (gx) {
+        if (split) return fail(c, PLS_HIP_ERR_DEVICE, "internal: gather prologue on a split update");
+        hipLaunchKernelGGL(plsk::component_update_gather_kernel, dim3(1), dim3(plsk::UPD_THREADS),
+                           (size_t)std::min(A, 4096) * sizeof(double), c->stream, *gx, red, XY, W, P, Q, R, v, K, M, A, a, nip,
+                           (int)c->opt_power_iters, 0);
+    } else {
+        hipLaunchKernelGGL(plsk::component_update_kernel, dim3(1), dim3(plsk::UPD_THREADS),
+                           (size_t)std::min(A, 4096) * sizeof(double), c->stream, (const double *)red, XY, W, P, Q, R, v, K, M, A, a, nip,
+                           (int)c->opt_power_iters, (int)split);
+    }
     LAUNCH_CHECK(c);
     if (split) {
         double *cs = (double *)c->cs.p;
@@ -950,6 +989,18 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     double *part = (double *)c->part.p, *sspart = (double *)c->sspart.p;
     double *XY = (double *)c->xy.p, *v = (double *)c->v.p;
     T *work = (T *)c->work.p;
+    // The partial rows of a fused pass are summed in the tail of the pass itself (slice_tail: no reduce launch behind it),
+    // and with the device-side exchange attached the push of a sharded component rides there too, the gather in front of
+    // the update: pass -> update.  PLS_HIP_TAIL=0: the launches of round 3 (A/B measurements).
+    static const bool tail_on = !(getenv("PLS_HIP_TAIL") && atoi(getenv("PLS_HIP_TAIL")) == 0);
+    plsk::SliceTail tail;
+    if (tail_on && c->opt_fuse && N > 0) {
+        if (!c->tailcnt.p) CHK(ensure(c, c->tailcnt, 256));
+        HIPCHK(c, hipMemsetAsync(c->tailcnt.p, 0, 256, c->stream));  // (whatever an earlier, failed fit left behind)
+        tail.cnt = (unsigned *)c->tailcnt.p;
+        tail.red = red;
+    }
+    const bool xep_ok = c->xep.on && c->reducer && (i64)K + 1 <= plsk::XCHG_CAP;
 
     // prologue: XY = X^T Y (src/pls.cpp:396), summed over ranks
     Range r_fit("pls_hip_fit");
@@ -1062,6 +1113,21 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     int defer_b = 0;         // deferred write-back: index of the stored matrix X_b
     for (int a = 0; a < A; ++a) {
         Range r_comp("component", a);
+        bool tail_used = false;
+        // sharded over the device-side exchange, the one-workgroup update behind the pass: the pass pushes (if its tail
+        // runs), the update gathers.  The collective number is drawn only when the pass did push.
+        const bool want_push = tail.cnt && xep_ok && update_is_single(K, M, A, a);
+        tail.npush = 0;
+        if (want_push) {
+            const unsigned long long seq = *c->xep.seq + 1;
+            const int par = (int)(seq & 1);
+            tail.npush = c->xep.n;
+            tail.seq = seq;
+            for (int j = 0; j < c->xep.n; ++j) {
+                tail.peers.slot[j] = c->xep.inbox[j] + ((i64)par * c->xep.n + c->xep.rank) * plsk::XCHG_CAP;
+                tail.peers.flag[j] = c->xep.flags[j] + par * c->xep.n + c->xep.rank;
+            }
+        }
         if (N > 0) {
             bool done = false;
             if (fused_fit && defer > 1 && a > 0) {
@@ -1101,11 +1167,11 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     if (mid_cg && a >= 2)  // half-height tiles of the working copy, in place
                         rc = plsk::launch_fused_pass<T, 64>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v,
                                                             tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
-                                                            &nb, &nss, (int)c->opt_fused_grid, 0, true);
+                                                            &nb, &nss, (int)c->opt_fused_grid, 0, true, &tail, &tail_used);
                     else {  // (a == 1 with mid_cg: X in 256-byte segments -> half-height tiles)
 #define TALL_PASS(CG_) plsk::launch_fused_pass<T, CG_>(c->stream, c->num_cu, Xc, ldc, tsc, tprev ? work : nullptr, ldw, tsw, N, K, v, tprev, \
                                                        pprev, Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss,                        \
-                                                       (int)c->opt_fused_grid, (mid_cg && tprev) ? (int)WR : 0, Xc == work)
+                                                       (int)c->opt_fused_grid, (mid_cg && tprev) ? (int)WR : 0, Xc == work, &tail, &tail_used)
                         rc = tall_cg == 8 ? TALL_PASS(8) : (tall_cg == 16 ? TALL_PASS(16) : TALL_PASS(32));
 #undef TALL_PASS
                     }
@@ -1115,7 +1181,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     LAUNCH_CHECK(c);
                     done = true;
                     if (tprev) { Xc = work; ldc = ldw; tsc = tsw; cur_tiled = tiled_work; }
-                    CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
+                    if (!tail_used) CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
                 } else {
                     return fail(c, PLS_HIP_ERR_DEVICE, "fused pass launch failed");
                 }
@@ -1136,7 +1202,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     const i64 bytes = (tprev ? 2 : 1) * ((i64)N * K * sizeof(T) + (i64)N * sizeof(T)) + 3 * (i64)K * 8;
                     Scope s(c, PLS_HIP_FAM_FUSED, bytes);
 #define WIDE_PASS(CG_) plsk::launch_fused_pass<T, CG_>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v, tprev, pprev, \
-                                                        Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid, 0, true)
+                                                        Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid, 0, true, \
+                                                        &tail, &tail_used)
                     rc = wide_cg == 8 ? WIDE_PASS(8) : (wide_cg == 16 ? WIDE_PASS(16) : (wide_cg == 32 ? WIDE_PASS(32)
                          : (wide_cg == 64 ? WIDE_PASS(64) : (wide_cg == 128 ? WIDE_PASS(128) : (wide_cg == 256 ? WIDE_PASS(256) : WIDE_PASS(512))))));
 #undef WIDE_PASS
@@ -1145,7 +1212,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 if (rc != 0) return fail(c, PLS_HIP_ERR_DEVICE, "short-tile fused pass launch failed");
                 LAUNCH_CHECK(c);
                 done = true;
-                CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
+                if (!tail_used) CHK(launch_reduce(c, part, nb, K, sspart, nss, red));
             }
             if (!done) {
                 int nss = 0, nb = 0;
@@ -1195,8 +1262,19 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         } else {
             HIPCHK(c, hipMemsetAsync(red, 0, (size_t)plsk::RED_SLICES * (K + 1) * 8, c->stream));
         }
-        CHK(do_allreduce(c, red, (i64)plsk::RED_SLICES * (K + 1)));
-        CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a, nip));  // :427-433 and :403-416 of a+1
+        if (tail_used && want_push) {  // pushed from the tail of the pass: gather in the prologue of the update
+            const unsigned long long seq = ++*c->xep.seq;
+            const int par = (int)(seq & 1);
+            plsk::XchgGather gx;
+            gx.inbox = c->xep.inbox[c->xep.rank] + (i64)par * c->xep.n * plsk::XCHG_CAP;
+            gx.flags = c->xep.flags[c->xep.rank] + par * c->xep.n;
+            gx.n = c->xep.n; gx.cap = plsk::XCHG_CAP; gx.seq = seq;
+            gx.status = c->xep.status; gx.host_status = c->xep.host_status; gx.limit = *c->xep.limit;
+            CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a, nip, &gx));
+        } else {
+            CHK(do_allreduce(c, red, (i64)plsk::RED_SLICES * (K + 1)));
+            CHK(launch_update(c, red, XY, W, P, Q, R, v, K, M, A, a, nip));  // :427-433 and :403-416 of a+1
+        }
     }
     if (B) {
         Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * A + (i64)M * A + (i64)K * M) * 8);
@@ -1359,7 +1437,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->zeros, &h->part, &h->sspart, &h->xbpart, &h->wide1, &h->red, &h->red2, &h->xx, &h->xyp, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
+    DevBuf *bufs[] = {&h->tailcnt, &h->zeros, &h->part, &h->sspart, &h->xbpart, &h->wide1, &h->red, &h->red2, &h->xx, &h->xyp, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
                       &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->cvtx, &h->cvty, &h->cvtt, &h->cvm, &h->cvkeep, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)
@@ -2203,6 +2281,7 @@ int ipc_allreduce(void *user, void *buf, int64_t count, void *stream) {
 void xchg_release(pls_hip_context *c) {
     XchgIpc *x = c->xchg;
     if (!x) return;
+    c->xep = pls_hip_context::XchgEndpoint();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int j = 0; j < x->n; ++j)
@@ -2278,6 +2357,10 @@ int pls_hip_xchg_connect(pls_hip_handle h, const void *all) {
         x->opened[j] = true;
     }
     x->connected = true;
+    h->xep.on = true;
+    h->xep.n = x->n; h->xep.rank = x->rank;
+    h->xep.inbox = x->inbox; h->xep.flags = x->flags;
+    h->xep.seq = &x->seq; h->xep.status = x->status; h->xep.host_status = x->host_status_dev; h->xep.limit = &x->limit;
     return pls_hip_set_reducer(h, ipc_allreduce, h, x->rank, x->n);
 }
 

@@ -4,7 +4,9 @@
 // inputs (the all-reduced partials) and therefore derives bit-identical w, r, p, q.
 #pragma once
 #include "common.hpp"
-#include "stream_kernels.hpp"  // RED_SLICES
+#include "exchange_kernels.hpp"  // XchgGather
+#include "fused_kernels.hpp"     // raw buffer loads with cache-policy bits
+#include "stream_kernels.hpp"
 
 namespace plsk {
 
@@ -581,6 +583,61 @@ __global__ __launch_bounds__(UPD_THREADS) void component_update_kernel(
     __shared__ UpdShared sh;
     component_update_body(red, RED_SLICES, XY, W, P, Q, R, vnext, K, M, A, a, nipals, power_iters, split_rotate,
                           cs, sh);
+}
+
+// The same update with the GATHER of a sharded fit's collective as its prologue (the push rode in the tail of the pass:
+// fused_kernels.hpp, slice_tail): wait until every member's flag shows this collective, add the members' vectors in rank
+// order -- every member the same bits -- into slice 0 of `red`, and run the body on that one slice.  A wait beyond the time
+// limit raises the status words and poisons the sums with NaN, as xchg_gather_kernel does.
+constexpr int AUX_SYS = 17;  // sc0 sc1: system scope (the peers' writes into fine-grained memory)
+__global__ __launch_bounds__(UPD_THREADS) void component_update_gather_kernel(
+    const XchgGather gx, double *red, double *__restrict__ XY, double *__restrict__ W, double *__restrict__ P,
+    double *__restrict__ Q, double *__restrict__ R, double *__restrict__ vnext, int K, int M, int A, int a, int nipals,
+    int power_iters, int split_rotate) {
+    extern __shared__ double cs[];  // [A]
+    __shared__ UpdShared sh;
+    __shared__ int ok;
+    const int tid = threadIdx.x;
+    if (tid == 0) ok = (*gx.status == 0);  // an earlier wait of this member timed out: do not wait again
+    __syncthreads();
+    if (tid < gx.n && ok) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(gx.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < gx.seq) {
+            if (wall_clock64() - t0 > gx.limit) {
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the vectors behind the flags
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!ok && tid == 0) {
+        *gx.status = 1;
+        __hip_atomic_store(gx.host_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    {
+        const int L = K + 1;
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        for (int j = tid; j < L; j += UPD_THREADS) {
+            double x[XCHG_MAX];
+#pragma unroll
+            for (int m = 0; m < XCHG_MAX; ++m) {  // all members' values in flight together
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<double *>(gx.inbox + (i64)(m < gx.n ? m : 0) * gx.cap), (short)0, L * 8, BUF_WORD3);
+                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs, (uint32_t)j * 8u, 0, AUX_SYS);
+                __builtin_memcpy(&x[m], &raw, 8);
+            }
+            double sum = x[0];
+#pragma unroll
+            for (int m = 1; m < XCHG_MAX; ++m)
+                if (m < gx.n) sum += x[m];  // rank order, as xchg_gather_kernel
+            red[j] = ok ? sum : __builtin_nan("");
+        }
+    }
+    __syncthreads();  // (the workgroup's own stores: visible to all its waves behind the barrier)
+    component_update_body(red, 1, XY, W, P, Q, R, vnext, K, M, A, a, nipals, power_iters, split_rotate, cs, sh);
 }
 
 // Multi-workgroup form of the r update (src/pls.cpp:412-416) for large n*K, where one workgroup

@@ -981,8 +981,6 @@ __global__ __launch_bounds__(WG) void sse_components_kernel(const T *__restrict_
 // out_stride > 0 replaces LP as the distance between the slices of `red` (a column block of a larger sliced matrix).
 // grid = (ceil(L/64), RED_SLICES); 256 threads = 64 columns x 4 interleaved sub-slices.
 // ------------------------------------------------------------------------------------
-constexpr int RED_SLICES = 8;
-
 __global__ __launch_bounds__(WG) void reduce_partials_kernel(const double *__restrict__ part,
                                                              int nb, int L,
                                                              const double *__restrict__ sspart,
