@@ -374,7 +374,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !(DEFL && TILED)) ?
         int cgz = cg;
         asm volatile("" : "+v"(cgz));
         if constexpr (TILED && DEFL) {
-            // pacing: `rdst` x 64 cycles of s_sleep before a tile's loads go out (launcher: fused_pace)
+            // pacing: `rdst` x 64 cycles of s_sleep before a tile's loads go out (launcher)
             for (int q = 0; q < rdst; ++q) __builtin_amdgcn_s_sleep(1);
         }
         Pack<T, V> x[CPT];
@@ -882,8 +882,10 @@ int launch_retile_xty(hipStream_t stream, int num_cu, const T *src, i64 lds_, co
         // columns per lane: 8, or 4 where 8 x MT accumulators and the tiles in flight do not fit 128 registers
         const int cptb = (M > 4 || (M > 2 && sizeof(T) == 4)) ? 4 : 8;
         const int nkb = (K + CG * cptb - 1) / (CG * cptb);
-        // two resident workgroups per CU in total (consecutive tiles per workgroup), at most max_rows - 1 row chunks
-        const i64 want = std::max<i64>(1, std::min<i64>((2 * (i64)num_cu + nkb - 1) / nkb, max_rows - 1));
+        // ONE workgroup per CU in total (consecutive tiles per workgroup), at most max_rows - 1 row chunks: like every
+        // read+write sweep of this library the copy is faster with less in flight -- config 4 (8 responses) 0.797 -> 0.719 ms,
+        // 65,536 x 8,192 fp32 1.088 -> 1.020 ms, config 3 -1.5 % (three alternating pairs, profiles/r4/retile_xty_wgs.txt)
+        const i64 want = std::max<i64>(1, std::min<i64>(((i64)num_cu + nkb - 1) / nkb, max_rows - 1));
         const i64 tpw = (ntiles + want - 1) / want;
         gx = (int)((ntiles + tpw - 1) / tpw);
         const dim3 g((unsigned)gx, (unsigned)nkb), b(NT);

@@ -871,6 +871,26 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         LAUNCH_CHECK(c);
         return PLS_HIP_OK;
     }
+    // ... and the same for 2..8 responses (tiny_fit_m_kernel: the reference's own example, README.md:23, is such a fit)
+    if (method == PLS_HIP_KERNEL_TYPE1 && (c->opt_algo == PLS_HIP_ALGO_KERNEL || c->opt_algo == PLS_HIP_ALGO_AUTO) && c->opt_fuse &&
+        !c->reducer && plsk::tiny_fit_m_covers(N, K, M, A, ldx, sizeof(T)) &&
+        !(getenv("PLS_HIP_TINY") && atoi(getenv("PLS_HIP_TINY")) == 0)) {
+        const size_t lds = (size_t)(2 * K + M) * A * 8;
+        Range r_fit("pls_hip_fit (single launch)");
+        Scope s(c, PLS_HIP_FAM_SMALL, ((i64)N * K + (i64)N * M + (i64)N * A) * (i64)sizeof(T) + (3 * (i64)K + M) * A * 8);
+#define TINY_M(MM_)                                                                                                          \
+    do {                                                                                                                     \
+        if (!plsk::raise_dynamic_lds((const void *)plsk::tiny_fit_m_kernel<T, MM_>, (int)plsk::TINY_LDS_MAX))               \
+            return fail(c, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the single-launch fit could not be raised");            \
+        hipLaunchKernelGGL((plsk::tiny_fit_m_kernel<T, MM_>), dim3(1), dim3(plsk::UPD_THREADS), lds, c->stream, X, ldx, Y, ldy,  \
+                           (int)N, K, M, A, (int)c->opt_power_iters, W, P, Q, R, Tm, ldt, B, (const i64 *)nullptr, 0, (i64)0,  \
+                           (double *)nullptr);                                                                               \
+    } while (0)
+        if (M <= 2) TINY_M(2); else if (M <= 4) TINY_M(4); else TINY_M(8);
+#undef TINY_M
+        LAUNCH_CHECK(c);
+        return PLS_HIP_OK;
+    }
     i64 algo = c->opt_algo;
     const bool have_pre = c->pre_xx && c->pre_xy && K <= 32768;
     if (algo == PLS_HIP_ALGO_AUTO && have_pre) {
@@ -1085,6 +1105,14 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 hipLaunchKernelGGL(plsk::symv_kernel, dim3((K + 3) / 4), dim3(plsk::WG), 0, c->stream,
                                    (const double *)XX, (const double *)v, K, praw);  // XX symmetric: XX r
                 LAUNCH_CHECK(c);
+            }
+            if (update_is_single(K, M, A, a)) {  // tt = r^T praw and the packing: the prologue of the one-workgroup update
+                Scope s(c, PLS_HIP_FAM_SMALL, ((i64)K * M * 3 + (i64)K * (2 * (a + 2)) + 2 * K) * 8);
+                hipLaunchKernelGGL(plsk::component_update_type2_kernel, dim3(1), dim3(plsk::UPD_THREADS),
+                                   (size_t)std::min(A, 4096) * sizeof(double), c->stream, (const double *)praw, (const double *)v, red,
+                                   XY, W, P, Q, R, v, K, M, A, a, (int)c->opt_power_iters, 0);
+                LAUNCH_CHECK(c);
+                continue;
             }
             hipLaunchKernelGGL(plsk::type2_pack_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream,
                                (const double *)praw, (const double *)v, K, red);
@@ -1604,7 +1632,8 @@ int pls_hip_fit(pls_hip_handle h, const void *X, int64_t ldx, const void *Y, int
         bool pre = false;
         const bool wants_gram = h->opt_algo == PLS_HIP_ALGO_AUTO || h->opt_algo == PLS_HIP_ALGO_GRAM || method == PLS_HIP_KERNEL_TYPE2;
         const bool single_launch = method == PLS_HIP_KERNEL_TYPE1 && h->opt_algo == PLS_HIP_ALGO_AUTO && h->opt_fuse &&
-                                   plsk::tiny_fit_covers(N, Ki, Mi, Ai, ldn, es);  // (no use for X^T X there)
+                                   (plsk::tiny_fit_covers(N, Ki, Mi, Ai, ldn, es) ||
+                                    plsk::tiny_fit_m_covers(N, Ki, Mi, Ai, ldn, es));  // (no use for X^T X there)
         if (wants_gram && !single_launch && !h->reducer && N > 0 && K <= 4096 && ensure(h, h->gxx, (size_t)K * K * 8) == PLS_HIP_OK &&
             ensure(h, h->gxy, (size_t)K * M * 8) == PLS_HIP_OK) {
             if (dtype == PLS_HIP_F64)
@@ -2005,6 +2034,30 @@ int cv_folds_tiny(pls_hip_context *h, const T *dX, i64 dldx, const T *dY, i64 N,
     return PLS_HIP_OK;
 }
 
+// ... the same for 2..8 responses (tiny_fit_m_kernel in fold mode)
+template <typename T>
+int cv_folds_tiny_m(pls_hip_context *h, const T *dX, i64 dldx, const T *dY, i64 dldy, i64 N, int Ki, int Mi, int Ai,
+                    const int64_t *test_idx, int ts, i64 num_folds, double *dE) {
+    const i64 nobs = num_folds * ts;
+    CHK(ensure(h, h->cvidx, (size_t)nobs * 8));
+    HIPCHK(h, hipMemcpyAsync(h->cvidx.p, test_idx, (size_t)nobs * 8, hipMemcpyHostToDevice, h->stream));
+    const size_t lds = (size_t)(2 * Ki + Mi) * Ai * 8;
+    Scope s(h, PLS_HIP_FAM_SMALL, (i64)num_folds * N * Ki * (i64)sizeof(T));
+#define TINY_M(MM_)                                                                                                          \
+    do {                                                                                                                     \
+        if (!plsk::raise_dynamic_lds((const void *)plsk::tiny_fit_m_kernel<T, MM_>, (int)plsk::TINY_LDS_MAX))               \
+            return fail(h, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the single-launch fit could not be raised");            \
+        hipLaunchKernelGGL((plsk::tiny_fit_m_kernel<T, MM_>), dim3((unsigned)num_folds), dim3(plsk::UPD_THREADS), lds, h->stream, dX, \
+                           dldx, dY, dldy, (int)N, Ki, Mi, Ai, (int)h->opt_power_iters, (double *)nullptr, (double *)nullptr,  \
+                           (double *)nullptr, (double *)nullptr, (T *)nullptr, (i64)0, (double *)nullptr,                    \
+                           (const i64 *)h->cvidx.p, ts, nobs, dE);                                                           \
+    } while (0)
+    if (Mi <= 2) TINY_M(2); else if (Mi <= 4) TINY_M(4); else TINY_M(8);
+#undef TINY_M
+    LAUNCH_CHECK(h);
+    return PLS_HIP_OK;
+}
+
 // The general form of the same call: one refit per fold on the rows that are not in its test set -- what the reference
 // does (src/pls.cpp:478-488, :524-545), with the training rows gathered on the device and the fit running under the
 // handle's own plan.  Serves the shapes the batched kernel declines (M > 32, A > 4096, K > 16384, a workspace that does
@@ -2107,11 +2160,20 @@ int pls_hip_cv_folds(pls_hip_handle h, const void *X, int64_t ldx, const void *Y
     int rc = PLS_HIP_ERR_ALLOC;
     const bool tiny = M == 1 && plsk::tiny_fit_covers(N, (int)K, 1, (int)A, dldx, es) && !getenv("PLS_HIP_CV_REFIT") &&
                       !(getenv("PLS_HIP_TINY") && atoi(getenv("PLS_HIP_TINY")) == 0);
+    const bool tiny_m = plsk::tiny_fit_m_covers(N, (int)K, (int)M, (int)A, dldx, es) && !getenv("PLS_HIP_CV_REFIT") &&
+                        !(getenv("PLS_HIP_TINY") && atoi(getenv("PLS_HIP_TINY")) == 0);
     if (tiny) {
         if (dtype == PLS_HIP_F64)
             rc = cv_folds_tiny<double>(h, (const double *)dX, dldx, (const double *)dY, N, (int)K, (int)A, test_idx, (int)test_size, num_folds, dE);
         else
             rc = cv_folds_tiny<float>(h, (const float *)dX, dldx, (const float *)dY, N, (int)K, (int)A, test_idx, (int)test_size, num_folds, dE);
+    } else if (tiny_m) {
+        if (dtype == PLS_HIP_F64)
+            rc = cv_folds_tiny_m<double>(h, (const double *)dX, dldx, (const double *)dY, dldy, N, (int)K, (int)M, (int)A, test_idx,
+                                         (int)test_size, num_folds, dE);
+        else
+            rc = cv_folds_tiny_m<float>(h, (const float *)dX, dldx, (const float *)dY, dldy, N, (int)K, (int)M, (int)A, test_idx,
+                                        (int)test_size, num_folds, dE);
     } else if (cv_batched_covers(K, M, A)) {
         if (dtype == PLS_HIP_F64)
             rc = cv_folds_device<double>(h, (const double *)dX, dldx, (const double *)dY, dldy, N, (int)K, (int)M, (int)A,

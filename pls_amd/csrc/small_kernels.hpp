@@ -640,6 +640,27 @@ __global__ __launch_bounds__(UPD_THREADS) void component_update_gather_kernel(
     component_update_body(red, 1, XY, W, P, Q, R, vnext, K, M, A, a, nipals, power_iters, split_rotate, cs, sh);
 }
 
+// KERNEL_TYPE2 / GRAM (src/pls.cpp:422-425): the update with type2_pack_kernel as its prologue -- given praw = XX r it forms
+// tt = r^T praw (the sum of type2_pack_kernel: 1024 strided sums, wave sums, waves in order) and presents [praw, tt] as the
+// one slice the body reads.  Two launches per component (symv, this) instead of three.
+__global__ __launch_bounds__(UPD_THREADS) void component_update_type2_kernel(
+    const double *__restrict__ praw, const double *r, double *red, double *__restrict__ XY, double *__restrict__ W,
+    double *__restrict__ P, double *__restrict__ Q, double *__restrict__ R, double *vnext, int K, int M, int A, int a,
+    int power_iters, int split_rotate) {
+    extern __shared__ double cs[];  // [A]
+    __shared__ UpdShared sh;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < K; k += UPD_THREADS) {
+        const double p = praw[k];
+        s = fma(r[k], p, s);
+        red[k] = p;
+    }
+    s = block_sum<UPD_WAVES>(s, sh.sred);
+    if (threadIdx.x == 0) red[K] = s;
+    __syncthreads();  // (the workgroup's own stores: visible to all its waves behind the barrier)
+    component_update_body(red, 1, XY, W, P, Q, R, vnext, K, M, A, a, 0, power_iters, split_rotate, cs, sh);
+}
+
 // Multi-workgroup form of the r update (src/pls.cpp:412-416) for large n*K, where one workgroup
 // would be latency-bound on the 2*n*K values of P and R:
 //   rotate_dots_kernel   grid n      : cs[j] = P[:,j]^T w_n

@@ -212,4 +212,170 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same single launch for 2 <= M <= 8 responses (BASELINE config 1: toyX / toyY, 10 x 15, two responses, A = 2 --
+// README.md:23 of the reference).  X stays in registers as above; XY (K x M) lives in LDS, column-major; the direction of a
+// component is the dominant eigenvector of XY^T XY (src/pls.cpp:405-408): its M (M + 1) / 2 entries one wave per pair
+// (K <= 448: seven products per lane), the eigenvector by the one-wave solver of the component update
+// (dominant_eigvec_wave: repeated squaring, two polishing steps, largest entry positive), w = XY q / |XY q|.  Everything
+// else is the single-response loop with M values of q per component.  A kernel of its own (template MM = 2, 4, 8 =
+// M rounded up): the single-response instantiation keeps its registers (a shared kernel cost it 11 %).
+// Fold mode as above, residuals per response: E[m*(nobs*A) + (f*ts + j) + a*nobs].
+// Dynamic LDS: (2 K + M) A doubles (P, R, Q as they are produced).
+// ---------------------------------------------------------------------------------------------------------------------
+inline bool tiny_fit_m_covers(i64 N, int K, int M, int A, i64 ldx, size_t es) {
+    if (M < 2 || M > 8 || N < 1 || N > UPD_THREADS || A > K || (i64)TINY_KMAX * ldx * (i64)es >= (1 << 30)) return false;
+    const TinyShape sh((int)N);
+    return sh.S >= 1 && K <= sh.S * TINY_RC && (size_t)(2 * K + M) * A * 8 <= TINY_LDS_MAX;
+}
+
+template <typename T, int MM>
+__global__ __launch_bounds__(UPD_THREADS) void tiny_fit_m_kernel(const T *__restrict__ X, i64 ldx, const T *__restrict__ Y, i64 ldy,
+                                                                 int N, int K, int M, int A, int power_iters,
+                                                                 double *__restrict__ W, double *__restrict__ P,
+                                                                 double *__restrict__ Q, double *__restrict__ R,
+                                                                 T *__restrict__ Tm, i64 ldt, double *__restrict__ B,
+                                                                 const i64 *__restrict__ fold_idx, int ts, i64 nobs,
+                                                                 double *__restrict__ E) {
+    static_assert(MM * MM <= WAVE, "one wave solves the eigenproblem");
+    extern __shared__ double dyn[];
+    double *Pl = dyn, *Rl = dyn + (i64)K * A, *Ql = dyn + 2 * (i64)K * A;  // P[:, j], R[:, j], Q[:, j] as they are produced
+    __shared__ double tp[UPD_THREADS], colp[UPD_WAVES][TINY_RC], praw[TINY_KMAX], xy[MM][TINY_KMAX], wl[TINY_KMAX], vsl[TINY_KMAX];
+    __shared__ double cs[TINY_KMAX], sred[UPD_WAVES], Gs[MM * MM], Bs[MM * MM], Cs[MM * MM], qs[MM], qa[MM];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const TinyShape shp(N);
+    const int s = wv / shp.wps, rb = wv % shp.wps, i = rb * WAVE + lane;
+    const bool act = s < shp.S && i < N;
+    const int k = tid;
+    const bool kok = k < K;
+    const int slot = (k % shp.S) * TINY_RC + k / shp.S;
+
+    const uint32_t nrec = (uint32_t)(((i64)(K - 1) * ldx + N) * (i64)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X), (short)0, (int)nrec, BUF_WORD3);
+    const uint32_t voff = act ? (uint32_t)((i + (i64)s * ldx) * (i64)sizeof(T)) : 0x80000000u;
+    const uint32_t cstep = (uint32_t)((i64)shp.S * ldx * (i64)sizeof(T));
+    double x[TINY_RC];
+#pragma unroll
+    for (int j = 0; j < TINY_RC; ++j) x[j] = tiny_ld<T>(rs, voff, (uint32_t)j * cstep);
+    for (int c = tid; c < TINY_KMAX; c += UPD_THREADS) vsl[c] = 0.0;
+
+    const bool fold = fold_idx != nullptr;
+    int hpos = -1;
+    if (fold && act)
+        for (int j = 0; j < ts; ++j)
+            if (fold_idx[(i64)blockIdx.x * ts + j] == i) hpos = j;
+    const bool held = hpos >= 0;
+    double yv[MM], yhat[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        yv[m] = (act && m < M) ? (double)Y[i + (i64)m * ldy] : 0.0;
+        yhat[m] = 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {  // XY = X^T Y (:396), a held-out row with y = 0; the columns beyond M: zeros
+        if (m < M) {
+            tiny_column_sums(x, held ? 0.0 : yv[m], colp, K, shp, xy[m]);
+        } else if (kok) {
+            xy[m][k] = 0.0;
+        }
+    }
+    const double *vs = vsl + s * TINY_RC;
+    for (int a = 0; a < A; ++a) {
+        // ---- direction (:403-411): G = XY^T XY, one wave per pair (i <= j)
+        lds_barrier();  // XY complete
+        for (int pr = wv; pr < MM * (MM + 1) / 2; pr += UPD_WAVES) {
+            int gi = 0, rem = pr;
+            while (rem >= MM - gi) { rem -= MM - gi; ++gi; }
+            const int gj = gi + rem;
+            double g = 0.0;
+            for (int kk = lane; kk < K; kk += WAVE) g = fma(xy[gi][kk], xy[gj][kk], g);
+            g = wave_sum(g);
+            if (lane == 0) { Gs[gi + gj * MM] = g; Gs[gj + gi * MM] = g; }
+        }
+        lds_barrier();
+        if (wv == 0) dominant_eigvec_wave<MM>(Gs, Bs, Cs, qs, power_iters);
+        lds_barrier();
+        double wk = 0.0;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) wk = fma(kok ? xy[m][k] : 0.0, qs[m], wk);  // w = XY q (:408)
+        wk = wk / sqrt(tiny_block_sum(wk * wk, sred));                          // (:411)
+        if (kok) {
+            if (!fold) W[k + (i64)a * K] = wk;
+            wl[k] = wk;
+        }
+        lds_barrier();
+        for (int j = wv; j < a; j += UPD_WAVES) {  // c_j = p_j^T w, against the ORIGINAL w (:415)
+            double c = 0.0;
+            for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
+            c = wave_sum(c);
+            if (lane == 0) cs[j] = c;
+        }
+        lds_barrier();
+        double r = wk;
+        for (int j = 0; j < a; ++j) r -= cs[j] * Rl[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
+        if (kok) {
+            if (!fold) R[k + (i64)a * K] = r;
+            Rl[k + (i64)a * K] = r;
+            vsl[slot] = r;
+        }
+        lds_barrier();  // r_a complete
+        // ---- score, loading (:419-427)
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < TINY_RC; ++j) {
+            acc = fma(x[j], vs[j], acc);
+            if (j % 8 == 7) asm volatile("" ::: "memory");
+        }
+        tp[tid] = acc;
+        lds_barrier();
+        double ti = 0.0;
+        if (act)
+            for (int q = 0; q < shp.S; ++q) ti += tp[(q * shp.wps + rb) * WAVE + lane];
+        const double ui = ti;
+        if (held) ti = 0.0;
+        if (act && s == 0 && !fold) Tm[i + (i64)a * ldt] = (T)ti;
+        const double tt = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // (:420)
+        tiny_column_sums(x, ti, colp, K, shp, praw);                              // X^T t (:421)
+        lds_barrier();
+        const double p = kok ? praw[k] / tt : 0.0;  // (:427)
+        if (kok) {
+            if (!fold) P[k + (i64)a * K] = p;
+            Pl[k + (i64)a * K] = p;
+        }
+        // ---- q = XY^T r / tt (:428): one wave per response
+        if (wv < MM) {
+            double c = 0.0;
+            for (int kk = lane; kk < K; kk += WAVE) c = fma(Rl[kk + (i64)a * K], xy[wv][kk], c);
+            c = wave_sum(c) / tt;
+            if (lane == 0) {
+                qa[wv] = c;
+                if (wv < M) {
+                    Ql[wv + (i64)a * M] = c;
+                    if (!fold) Q[wv + (i64)a * M] = c;
+                }
+            }
+        }
+        lds_barrier();
+        if (held && s == 0) {  // residuals of a held-out row with a + 1 components
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+                if (m < M) {
+                    yhat[m] = fma(ui, qa[m], yhat[m]);
+                    E[(i64)m * nobs * A + ((i64)blockIdx.x * ts + hpos) + (i64)a * nobs] = yv[m] - yhat[m];
+                }
+        }
+        if (kok) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m) xy[m][k] -= (p * qa[m]) * tt;  // XY -= (p q^T) tt (:429)
+        }
+    }
+    lds_barrier();
+    if (B && kok && !fold)  // B = R Q^T (:444-447)
+        for (int m = 0; m < M; ++m) {
+            double b = 0.0;
+            for (int a = 0; a < A; ++a) b = fma(Rl[k + (i64)a * K], Ql[m + (i64)a * M], b);
+            B[k + (i64)m * K] = b;
+        }
+}
+
 }  // namespace plsk

@@ -972,6 +972,71 @@ def test_single_launch_fit(handle, oracle, po, N, K, A, dt, pad):
         assert np.abs(out[k].cpu().numpy() - plain[k].cpu().numpy()).max() < (1e-9 if dt == "f64" else 1e-4)
 
 
+@pytest.mark.parametrize("N,K,M,A,dt,pad", [(10, 15, 2, 2, "f64", 0), (60, 40, 4, 6, "f64", 3), (64, 300, 8, 5, "f64", 0), (130, 100, 3, 7, "f64", 1),
+                                            (1000, 20, 2, 6, "f32", 8), (700, 26, 8, 4, "f64", 0), (5, 7, 2, 3, "f64", 0)])
+def test_single_launch_fit_several_responses(handle, oracle, po, N, K, M, A, dt, pad):
+    """2 .. 8 responses as ONE launch (tiny_fit_m_kernel, MM = 2, 4, 8): BASELINE config 1 -- the reference's README example,
+    toyX / toyY with two responses and two components -- and synthetic shapes of every row-block layout; against the oracle at
+    1e-10 and against the general plan (PLS_HIP_TINY=0)."""
+    import pls_amd
+    torch = _torch()
+    if (N, K, M) == (10, 15, 2):
+        Xh = oracle.z_scores(po.read_csv(os.path.join(DATA, "toyX.csv"))); Yh = oracle.z_scores(po.read_csv(os.path.join(DATA, "toyY.csv")))
+    else:
+        Xh, Yh = oracle.synth_x(0, N, K), oracle.synth_y(0, N, M)
+    dtype = np.float64 if dt == "f64" else np.float32
+    if dt == "f32":
+        Xh = np.asfortranarray(Xh.astype(np.float32).astype(np.float64)); Yh = np.asfortranarray(Yh.astype(np.float32).astype(np.float64))
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    Xbig = torch.zeros((K, N + pad), dtype=torch.float64 if dt == "f64" else torch.float32, device="cuda")
+    Xbig[:, :N] = torch.from_numpy(np.ascontiguousarray(Xh.T.astype(dtype))).cuda()
+    Xd = Xbig.T[:N]
+    Yd = to_dev(Yh.astype(dtype))
+    handle.set_option(pls_amd.OPT_PROFILE, 2)
+    try:
+        handle.timing()
+        out = handle.fit_device(Xd, Yd, A)
+        torch.cuda.synchronize()
+        t = handle.timing()
+        assert sum(t["launches"].values()) == 1, t["launches"]
+        os.environ["PLS_HIP_TINY"] = "0"
+        try:
+            plain = handle.fit_device(Xd, Yd, A)
+            torch.cuda.synchronize()
+            assert sum(handle.timing()["launches"].values()) > 1
+        finally:
+            del os.environ["PLS_HIP_TINY"]
+    finally:
+        handle.set_option(pls_amd.OPT_PROFILE, 0)
+    tol = dict(tol_b=1e-10, tol_col=1e-9) if dt == "f64" else dict(tol_b=2e-5, tol_col=2e-4, tol_inv=1e-3)
+    check_against(po, out, ref, Bref, Tref=ref["T"], col_err=cerr, **tol)
+    for k in "WPQRB":
+        assert np.abs(out[k].cpu().numpy() - plain[k].cpu().numpy()).max() < (1e-9 if dt == "f64" else 1e-4)
+
+
+@pytest.mark.parametrize("case", ["toy-loo", "toy-lso", "synth-m4"])
+def test_single_launch_folds_several_responses(handle, oracle, po, monkeypatch, case):
+    """Cross-validation folds of small multi-response data on the fold form of the single-launch kernel (one workgroup per fold:
+    cv_LOO / cv_LSO of the reference's own example, src/pls.cpp:469-549), against one oracle refit per fold and against the
+    general form of the call."""
+    if case.startswith("toy"):
+        Xh = oracle.z_scores(po.read_csv(os.path.join(DATA, "toyX.csv"))); Yh = oracle.z_scores(po.read_csv(os.path.join(DATA, "toyY.csv")))
+        A = 2
+    else:
+        Xh, Yh, A = oracle.synth_x(0, 90, 30), oracle.synth_y(0, 90, 4), 5
+    N = Xh.shape[0]
+    rng = np.random.default_rng(5)
+    idx = np.arange(N)[:, None] if case == "toy-loo" else np.stack([rng.permutation(N)[:max(1, (3 * N) // 10)] for _ in range(12)])
+    Xd, Yd = to_dev(Xh), to_dev(Yh)
+    got = handle.cv_folds(Xd, Yd, A, idx).cpu().numpy()
+    ref = _fold_reference(oracle, Xh, Yh, A, idx)
+    assert np.abs(got - ref).max() < 1e-9 * max(np.abs(ref).max(), 1.0)
+    monkeypatch.setenv("PLS_HIP_TINY", "0")
+    general = handle.cv_folds(Xd, Yd, A, idx).cpu().numpy()
+    monkeypatch.delenv("PLS_HIP_TINY")
+    assert np.abs(got - general).max() < 1e-9 * max(np.abs(ref).max(), 1.0)
+
+
 def test_graph_replay_of_repeated_fits(oracle, po):
     """PLS_HIP_OPT_GRAPH: the second identical device-memory fit is captured, later ones are one hipGraphLaunch.  Results are
     the eager ones bit for bit; different inputs at the same addresses are picked up (the graph holds pointers, not data);
