@@ -153,11 +153,11 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet, fp64 matrix cores (the guide h
 def syrk_roofline(N, K, syrk_ms):
     """The X^T X launch of the GRAM / KERNEL_TYPE2 plans on the MFMA roofline: flops the kernel EXECUTES (16 x 16 tiles:
     the 128 x 128 blocks above the diagonal in full, of every diagonal block the 36 of 64 tiles on or above its diagonal
-    -- 40 with PLS_HIP_SYRK_W8=0, the 4-wave form) / launch time."""
+    ) / launch time."""
     if not syrk_ms or syrk_ms <= 0:
         return None
     nbk = (K + 127) // 128
-    diag_tiles = 40 if os.environ.get("PLS_HIP_SYRK_W8") == "0" else 36
+    diag_tiles = 36
     tiles = 64 * (nbk * (nbk - 1) // 2) + diag_tiles * nbk
     executed = 2.0 * N * 16 * 16 * tiles
     ach = executed / (syrk_ms * 1e-3) / 1e12
@@ -186,8 +186,12 @@ def cpu_baseline(N, K, M, A, rows):
             "sample": f"first {rows} of {N} rows x {K} cols, A={A}, fp64, one fit = {t1:.2f} s; "
                       f"rate scaled by {rows}/{N} (cost linear in rows); restatement of the reference "
                       f"algorithm, Eigen unavailable"}
+    import glob
+    nodes = len(glob.glob("/sys/devices/system/node/node[0-9]*")) or 1
     omp = {"value": round(A / tn * scale, 4), "unit": "components/s", "cores": gen.num_threads(), "kind": "port",
-           "sample": f"same sample, -O3 -march=x86-64-v3 -fopenmp, one fit = {tn:.2f} s"}
+           "sample": f"same sample, -O3 -march=x86-64-v3 -fopenmp, {gen.num_threads()} OpenMP threads over {nodes} NUMA node(s), "
+                     f"every sweep of X partitioned by row blocks and X generated under the same partition (first-touch: the "
+                     f"pages of a block live where their reader runs), one fit = {tn:.2f} s"}
     return base, omp
 
 

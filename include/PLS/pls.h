@@ -122,7 +122,7 @@ void print_validation(const Residual &residual, const VALIDATION_OUTPUT out_type
 // ---- where Models run (extension; the reference is a CPU library) --------------------------------
 // The GPUs the Models created FROM NOW ON use: {0, 1, 2, 3} = those HIP devices with the rows of every matrix spread
 // over them, an ordinal may repeat (virtual shards on one GPU), {} = back to the environment (PLS_HIP_DEVICES = "4" or
-// "0,2,5"; default PLS_HIP_DEVICE or device 0).  Existing Models keep the context they were built on.  There is no
+// "0,2,5"; default device 0).  Existing Models keep the context they were built on.  There is no
 // process-wide device state: every host thread gets a context of its own (streams, workspace) on first use, a Model
 // carries the context it was built on, so Models of different threads run at the same time -- as upstream, where a
 // Model shares nothing with another (include/PLS/pls.h:184-266 there).

@@ -74,10 +74,73 @@ static double dot2(const double *a, const double *b, i64 n) {
 /* Streaming products on a column-major N x K matrix                          */
 /* ------------------------------------------------------------------------- */
 
+/* The OpenMP build (liboracle_omp.so: the all-core CPU baseline, and the full-size checker of the GPU tests) partitions
+ * EVERY sweep of X by ROW BLOCKS -- thread id owns rows [N id / nt, N (id + 1) / nt), the block boundaries rounded to 512
+ * rows = one 4 KB page of a column -- the generator included: the thread that first touches a page of X (oracle_synth_x)
+ * is the one that reads it in every later product, so on a multi-socket host the pages are local to their readers
+ * (first-touch placement; the same partition as the GPU path's row shards).  Column sums then meet as per-thread partials
+ * added in thread order (compensated mode: (sum, error) pairs combined error-free).  One thread = one block = the
+ * reference's index-order sums; the single-threaded liboracle.so has none of this. */
+#ifdef _OPENMP
+static inline void row_block(i64 N, int nt, int id, i64 *a, i64 *b) {
+    const i64 pages = (N + 511) / 512;
+    *a = (pages * id / nt) * 512;
+    *b = (pages * (id + 1) / nt) * 512;
+    if (*a > N) *a = N;
+    if (*b > N) *b = N;
+}
+/* out[j] = sum over the rows of col_j(A)[i] * col_m(B)[i] for the K x M pairs (xty) -- B = Y (M columns) or a vector */
+static void omp_colsums(const double *X, i64 ldx, const double *Y, i64 ldy, i64 N, i64 K, i64 M, double *XY) {
+    const int nt = omp_get_max_threads();
+    double *ps = (double *)calloc((size_t)nt * (size_t)(K * M) * 2, sizeof(double)); /* [thread][sum K*M | err K*M] */
+#pragma omp parallel num_threads(nt)
+    {
+        const int id = omp_get_thread_num();
+        i64 a, b;
+        row_block(N, omp_get_num_threads(), id, &a, &b);
+        double *s = ps + (size_t)id * (size_t)(K * M) * 2, *c = s + K * M;
+        for (i64 k = 0; k < K; ++k) {
+            const double *xk = X + k * ldx;
+            for (i64 m = 0; m < M; ++m) {
+                const double *ym = Y + m * ldy;
+                double ss = 0.0, cc = 0.0;
+                if (g_compensated) {
+                    for (i64 i = a; i < b; ++i) acc2(xk[i], ym[i], &ss, &cc);
+                } else {
+                    for (i64 i = a; i < b; ++i) ss += xk[i] * ym[i];
+                }
+                s[k + m * K] = ss;
+                c[k + m * K] = cc;
+            }
+        }
+    }
+    for (i64 j = 0; j < K * M; ++j) { /* thread order; compensated: two-sum of the partial sums, errors added */
+        double ss = 0.0, cc = 0.0;
+        for (int t = 0; t < nt; ++t) {
+            const double v = ps[(size_t)t * (size_t)(K * M) * 2 + j], e = ps[(size_t)t * (size_t)(K * M) * 2 + K * M + j];
+            if (g_compensated) {
+                const double tt = ss + v, bb = tt - ss;
+                cc += ((ss - (tt - bb)) + (v - bb)) + e;
+                ss = tt;
+            } else {
+                ss += v;
+            }
+        }
+        XY[j] = ss + cc;
+    }
+    free(ps);
+}
+#endif
+
 /* out(K x M) = X^T Y.  Reference: `Mat2D XY = X.transpose() * Y;` src/pls.cpp:396 */
 ORACLE_API void oracle_xty(const double *X, i64 ldx, const double *Y, i64 ldy,
                            i64 N, i64 K, i64 M, double *XY /* K x M, ld K */) {
-#pragma omp parallel for schedule(static)
+#ifdef _OPENMP
+    if (omp_get_max_threads() > 1) {
+        omp_colsums(X, ldx, Y, ldy, N, K, M, XY);
+        return;
+    }
+#endif
     for (i64 k = 0; k < K; ++k) {
         const double *xk = X + k * ldx;
         for (i64 m = 0; m < M; ++m) {
@@ -101,10 +164,11 @@ ORACLE_API void oracle_xv(const double *X, i64 ldx, i64 N, i64 K, const double *
         {
 #ifdef _OPENMP
             const int nt = omp_get_num_threads(), id = omp_get_thread_num();
+            i64 a, b;
+            row_block(N, nt, id, &a, &b);
 #else
-            const int nt = 1, id = 0;
+            const i64 a = 0, b = N;
 #endif
-            const i64 a = N * id / nt, b = N * (id + 1) / nt;
             for (i64 i = a; i < b; ++i) t[i] = 0.0;
             for (i64 k = 0; k < K; ++k) {
                 const double *xk = X + k * ldx;
@@ -120,7 +184,8 @@ ORACLE_API void oracle_xv(const double *X, i64 ldx, i64 N, i64 K, const double *
 #pragma omp parallel
     {
         int nt = omp_get_num_threads(), id = omp_get_thread_num();
-        i64 lo = N * id / nt, hi = N * (id + 1) / nt;
+        i64 lo, hi;
+        row_block(N, nt, id, &lo, &hi);
         for (i64 i = lo; i < hi; ++i) t[i] = 0.0;
         for (i64 k = 0; k < K; ++k) {
             const double *xk = X + k * ldx;
@@ -140,7 +205,12 @@ ORACLE_API void oracle_xv(const double *X, i64 ldx, i64 N, i64 K, const double *
 
 /* p = X^T t.  Reference: `p.noalias() = (X.transpose()*t);` src/pls.cpp:421 */
 ORACLE_API void oracle_xtv(const double *X, i64 ldx, i64 N, i64 K, const double *t, double *p) {
-#pragma omp parallel for schedule(static)
+#ifdef _OPENMP
+    if (omp_get_max_threads() > 1) {
+        omp_colsums(X, ldx, t, N, N, K, 1, p);
+        return;
+    }
+#endif
     for (i64 k = 0; k < K; ++k) {
         const double *xk = X + k * ldx;
         if (g_compensated) {
@@ -483,16 +553,24 @@ static inline double synth_noise_amp(uint64_t sA, uint64_t k) {
 /* rows [row0, row0+nrows) of the global N x K matrix into X (ld = ldx) */
 ORACLE_API void oracle_synth_x(double *X, i64 ldx, i64 row0, i64 nrows, i64 K, uint64_t seed) {
     const uint64_t sE = mix64(seed), sZ = mix64(seed + 1), sL = mix64(seed + 2), sA = mix64(seed + 5);
-#pragma omp parallel for schedule(static)
-    for (i64 k = 0; k < K; ++k) {
-        double L[SYN_F];
-        for (int f = 0; f < SYN_F; ++f) L[f] = SYN_LTAB[mix64(sL ^ (uint64_t)(k * SYN_F + f)) % 5];
-        const double amp = synth_noise_amp(sA, (uint64_t)k);
-        for (i64 ii = 0; ii < nrows; ++ii) {
-            const uint64_t i = (uint64_t)(row0 + ii);
-            double s = amp * u24(sE, i * (uint64_t)K + (uint64_t)k);
-            for (int f = 0; f < SYN_F; ++f) s += u24(sZ, i * SYN_F + f) * L[f];
-            X[ii + k * ldx] = s;
+    /* (row blocks per thread in the OpenMP build: the pages of a block are first touched by the thread that reads them
+     * in every later product -- see omp_colsums) */
+#pragma omp parallel
+    {
+        i64 a = 0, b = nrows;
+#ifdef _OPENMP
+        row_block(nrows, omp_get_num_threads(), omp_get_thread_num(), &a, &b);
+#endif
+        for (i64 k = 0; k < K; ++k) {
+            double L[SYN_F];
+            for (int f = 0; f < SYN_F; ++f) L[f] = SYN_LTAB[mix64(sL ^ (uint64_t)(k * SYN_F + f)) % 5];
+            const double amp = synth_noise_amp(sA, (uint64_t)k);
+            for (i64 ii = a; ii < b; ++ii) {
+                const uint64_t i = (uint64_t)(row0 + ii);
+                double s = amp * u24(sE, i * (uint64_t)K + (uint64_t)k);
+                for (int f = 0; f < SYN_F; ++f) s += u24(sZ, i * SYN_F + f) * L[f];
+                X[ii + k * ldx] = s;
+            }
         }
     }
 }

@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void xchg_gather_kernel(const double *inbox, c
 // destinations in a loop), the blocks behind it gather (xchg_gather_kernel).  The gather blocks wait for the member's own
 // flag like for every other; block 0 publishes its flags only after it has read all of buf and issued every store, so a
 // gather block never overwrites an element the push still has to read.  Block 0 is dispatched first; the grid is at most
-// 5 workgroups.  One launch boundary fewer per collective (PLS_HIP_XCHG_FUSED=0: the two launches; long pieces take those
-// anyway, one push workgroup per destination).
+// 5 workgroups.  One launch boundary fewer per collective (long pieces take the two launches, one push workgroup per
+// destination).
 constexpr int XCHG_FUSED_MAX = 4096;  // doubles
 __global__ __launch_bounds__(XCHG_THREADS) void xchg_push_gather_kernel(XchgPeers peers, int do_push, const double *inbox,
                                                                         const unsigned long long *flags, int n, i64 cap, i64 Ltot,
@@ -159,8 +159,7 @@ inline int xchg_launch_piece(hipStream_t stream, int n, int rank, double *const 
         unsigned long long dq = 0;
         if (sscanf(drop, "%d:%llu", &dr, &dq) == 2 && dr == rank && dq == seq) skip = !dropped.exchange(true);
     }
-    static const bool fused = !(getenv("PLS_HIP_XCHG_FUSED") && atoi(getenv("PLS_HIP_XCHG_FUSED")) == 0);
-    if (fused && L <= XCHG_FUSED_MAX) {
+    if (L <= XCHG_FUSED_MAX) {
         const int ngb = (int)std::min<i64>(4, (L + XCHG_THREADS - 1) / XCHG_THREADS);
         hipLaunchKernelGGL(xchg_push_gather_kernel, dim3(1 + ngb), dim3(XCHG_THREADS), 0, stream, peers, skip ? 0 : 1,
                            (const double *)(inboxes[rank] + (i64)par * n * XCHG_CAP), (const unsigned long long *)(flagsv[rank] + par * n),

@@ -854,10 +854,9 @@ inline bool elem_aligned(const void *q) { return (uintptr_t)q % sizeof(T) == 0; 
 template <typename T>
 inline int edge_level(const void *q, i64 ld, int cg_all, int cg_wave) {
     if (!elem_aligned<T>(q)) return -1;
-    static const bool edge_on = !(getenv("PLS_HIP_EDGE") && atoi(getenv("PLS_HIP_EDGE")) == 0);  // A/B measurements only
     const bool fits = (i64)cg_all * ld * (i64)sizeof(T) < (1ll << 31);
     if (cols_aligned<T>(q, ld) && fits) return 0;
-    if (!edge_on || (i64)cg_wave * ld * (i64)sizeof(T) >= (1ll << 31)) return -1;
+    if ((i64)cg_wave * ld * (i64)sizeof(T) >= (1ll << 31)) return -1;
     return cols_aligned<T>(q, ld) ? 1 : 2;
 }
 
@@ -892,8 +891,7 @@ int launch_retile_xty(hipStream_t stream, int num_cu, const T *src, i64 lds_, co
         // destination tiles of ONE row pack, one or two responses: transposed through LDS (the 32-group source tile only).
         // Measured: 87,381 x 6,144 fp64 3.14 -> 2.17 ms; with 8 responses (4 columns per lane, two tiles in flight) no gain,
         // and two-pack tiles (config 4: 128-byte runs already) lose, 0.82 -> 1.10 ms -- those keep the direct stores.
-        static const bool lt_on = !(getenv("PLS_HIP_RETILE_LT") && atoi(getenv("PLS_HIP_RETILE_LT")) == 0);
-        const bool lt = lt_on && CGX == 32 && rdst == V && M <= 2;
+        const bool lt = CGX == 32 && rdst == V && M <= 2;
 #define RX_LAUNCH(CPTB_, MT_, E_) \
     hipLaunchKernelGGL((retile_xty_kernel<T, V, R, NT, CPTB_, MT_, E_>), g, b, 0, stream, src, lds_, Y, ldy, dst, ldd, tsd, rdst, Nf, K, M, part, (int)tpw)
 #define RX_LAUNCH_LT(CPTB_, MT_, E_)                                                                                      \
@@ -1167,8 +1165,7 @@ constexpr int tile_rows() { return (512 / CGX) * (16 / (int)sizeof(T)); }
 // row lanes (128 fp64 rows, 1 KB segments) up to 128 columns, 16 x 32 up to 256.  With the 32-group tile a 64-column matrix
 // has 2 loads per lane and streams at 0.64-0.68 of peak (config-3-sized: 581 / 1,097 components/s), a 32-column one at 0.38-0.46.
 inline int tall_groups(int K) {
-    static const bool on = !(getenv("PLS_HIP_TALL_TILES") && atoi(getenv("PLS_HIP_TALL_TILES")) == 0);  // A/B measurements only
-    return !on ? 32 : (K <= 128 ? 8 : (K <= 256 ? 16 : 32));
+    return K <= 128 ? 8 : (K <= 256 ? 16 : 32);
 }
 
 template <typename T>
@@ -1206,7 +1203,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     int edge = edge_level<T>(X, ldx, CG, WAVE / (R / V));
     if (edge < 0 || (edge == 0 && tsx % V != 0) || (defl && tsd % V != 0)) return 1;
     // (512 groups: 32 columns per lane only for read-only passes -- v alone is 128 KB of LDS there, p_prev would not fit)
-    if (K > CG * ((CGX == 256 || CGX < 32 || (CGX == 512 && defl)) ? 16 : 32) || N < 1 || max_rows < 2) return 1;
+    if (K > CG * ((CGX == 64 || CGX == 128 || CGX == 256 || CGX < 32 || (CGX == 512 && defl)) ? 16 : 32) || N < 1 || max_rows < 2) return 1;
     if ((N + V) * (i64)sizeof(T) >= (1ll << 31)) return 1;  // one descriptor per score column
     if (defl && (i64)CG * ldd * (i64)sizeof(T) >= (1ll << 31)) return 1;
     if (rdst > 0 && (CGX != 32 || !defl || rdst < V || R % rdst != 0 ||
@@ -1256,17 +1253,13 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         // per CU beats two); throttled a little further it gains another 1.5-3 % on every shape measured -- config 3
         // 0.752 -> 0.772 / 0.774 -> 0.787 of peak on two boxes, an eighth of it 0.723 -> 0.736, config 4 0.784 -> 0.799, a
         // shard of config 5 0.773 -> 0.786 -- while 64 x 64 cycles already cost one box 2 % (profiles/r4/pace_sweep_*.txt).
-        // PLS_HIP_PACE overrides the 64-cycle units per tile (measurements).
-        static const int pace_env = getenv("PLS_HIP_PACE") ? atoi(getenv("PLS_HIP_PACE")) : -1;
-        static const int tiled_env = getenv("PLS_HIP_TILED") ? atoi(getenv("PLS_HIP_TILED")) : 1;  // A/B measurements only (CGX <= 32)
-        const bool tiled = defl && edge == 0 && rdst == 0 && ldx == R && ldd == R && tsx == (i64)R * K && tsd == (i64)R * K &&
-                           (tiled_env != 0 || CGX > 32);
+        const bool tiled = defl && edge == 0 && rdst == 0 && ldx == R && ldd == R && tsx == (i64)R * K && tsd == (i64)R * K;
         if (CGX > 32 && defl && !tiled) return 1;
 #define FUSED_LAUNCH(CPT_, DEFL_, EDGE_, TILED_, dyn_)                                                                    \
     do {                                                                                                                  \
         auto kfn = &fused_pass_kernel<T, V, R, NT, CPT_, DEFL_, AUX_NT, AUX_NT, false, EDGE_, TILED_>;                   \
         if ((dyn_) > 48 * 1024 && !raise_dynamic_lds(reinterpret_cast<const void *>(kfn), (int)(dyn_))) return 1;         \
-        hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, (TILED_) ? (pace_env >= 0 ? pace_env : 2 * (CPT_)) : 0, N, st); \
+        hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, (TILED_) ? 2 * (CPT_) : 0, N, st); \
     } while (0)
 #define FUSED_EDGE(CPT_, DEFL_, dyn_)                                                                                     \
     do {                                                                                                                  \
@@ -1296,8 +1289,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
             else if (K <= CG * 16) FUSED_CASE(16);
             else FUSED_CASE(32);
         } else if constexpr (CGX == 64 || CGX == 128) {
-            if (K <= CG * 16) FUSED_CASE(16);
-            else FUSED_CASE(32);
+            FUSED_CASE(16);  // (32 columns per lane on these tiles was the round-1 shape: slower, deleted in round 4)
         } else if constexpr (CGX == 8) {  // narrow matrices: 128-row (fp64) tiles
             if (K <= CG * 4) FUSED_CASE(4);
             else if (K <= CG * 8) FUSED_CASE(8);

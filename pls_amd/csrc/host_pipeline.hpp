@@ -117,13 +117,16 @@ private:
     const bool caller_works_;
 };
 
-inline int default_copy_threads() {
-    if (const char *e = std::getenv("PLS_HIP_COPY_THREADS")) {
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 256) return v;
-    }
-    const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(16u, (hw ? hw : 1u) / 2));
+inline int default_copy_threads() {  // PLS_HIP_COPY_THREADS (read once per process), else min(16, cores / 2)
+    static const int cached = [] {
+        if (const char *e = std::getenv("PLS_HIP_COPY_THREADS")) {
+            const int v = std::atoi(e);
+            if (v >= 1 && v <= 256) return v;
+        }
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(16u, (hw ? hw : 1u) / 2));
+    }();
+    return cached;
 }
 
 // CPUs of the NUMA node closest to `device` (hipDeviceAttributeHostNumaId + the node's sysfs cpulist, "0-63,128-191");
@@ -132,8 +135,6 @@ inline int default_copy_threads() {
 // 47-52 GB/s staged from the device's socket, 28-34 GB/s from the other one).
 inline std::vector<int> device_numa_cpus(int device) {
     std::vector<int> cpus;
-    if (const char *e = std::getenv("PLS_HIP_COPY_BIND"))
-        if (std::atoi(e) == 0) return cpus;
     int node = -1;
     if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, device) != hipSuccess || node < 0) {
         (void)hipGetLastError();
@@ -162,9 +163,9 @@ inline size_t env_size(const char *name, size_t dflt, size_t lo, size_t hi) {
     }
     return dflt;
 }
-// per pinned buffer (two per handle), MiB: PLS_HIP_STAGE_MB; one copy job, KiB: PLS_HIP_PIECE_KB
+// per pinned buffer (two per handle), MiB: PLS_HIP_STAGE_MB (read once per process); one copy job: 512 KiB
 static const size_t STAGE_BYTES = env_size("PLS_HIP_STAGE_MB", 32, 1, 1024) << 20;
-static const size_t PIECE_BYTES = env_size("PLS_HIP_PIECE_KB", 512, 4, 65536) << 10;
+static const size_t PIECE_BYTES = (size_t)512 << 10;
 
 struct Stager {
     void *buf[2] = {nullptr, nullptr};

@@ -1,0 +1,274 @@
+// launch_products.hpp -- typed launchers of the streaming products over X: X B / X v, X^T Y / X^T t, the stand-alone deflation, the fixed-order reduction of partial rows.
+// Part of libpls_hip.so: included by pls_hip.hip (one translation unit), in the order given there.
+#pragma once
+
+namespace {
+
+template <typename T>
+bool vec_ok(const void *p, i64 ld, int vec) {
+    return ((uintptr_t)p % (sizeof(T) * vec) == 0) && (ld % vec == 0);
+}
+
+// ---- geometry -------------------------------------------------------------------------
+constexpr int XTY_KCMT = 32;  // accumulators per lane in xty_kernel
+constexpr int DEFL_KC = 32;
+
+struct XtyGeom {
+    int G;    // row groups = number of partial rows (same for every m-tile of one product)
+    int nkg;  // column groups of this m-tile
+};
+// All m-tiles of one X^T Y write the same number of partial rows G.  It is derived from the column groups of the
+// product's FIRST tile (kc_first columns each; the first tile is the widest in m, i.e. the one with the most column
+// groups): with G from the 32-column shape instead, the 8-response tile of config 4 ran 16,384 workgroups of 8 row
+// chunks each and spent half its time in their 32 butterfly sums (1.0 ms = 2.1 TB/s, fp32 and fp64 alike).
+XtyGeom xty_geom(i64 N, int K, int KC, int vec, int target_wgs, int kc_first) {
+    XtyGeom g;
+    g.nkg = (K + KC - 1) / KC;
+    const int nkg32 = (K + kc_first - 1) / kc_first;
+    const i64 nch = (N + (i64)plsk::WG * vec - 1) / ((i64)plsk::WG * vec);
+    i64 G = std::max<i64>(1, target_wgs / nkg32);
+    G = std::min<i64>(G, std::max<i64>(nch, 1));
+    g.G = (int)G;
+    return g;
+}
+// upper bound of partial rows any product of this fit can write
+i64 max_partial_rows(pls_hip_context *c, i64 N, int K) {
+    const int nkg32 = (K + XTY_KCMT - 1) / XTY_KCMT;
+    const i64 nch = (N + plsk::WG - 1) / plsk::WG;  // vec = 1 is the worst case
+    const i64 G = std::min<i64>(std::max<i64>(1, (8 * c->num_cu) / nkg32), std::max<i64>(nch, 1));
+    return std::max<i64>(G, std::max<i64>(8 * (i64)c->num_cu, c->opt_fused_grid));
+}
+
+// ---- typed launchers --------------------------------------------------------------------
+template <typename T, int VEC, int MT>
+void launch_xb_t(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const double *Bm, i64 ldb,
+                 int ncols, T *out, i64 ldo, double *sspart, int *nss) {
+    const i64 per = (i64)plsk::WG * VEC;
+    const int nblk = (int)((N + per - 1) / per);
+    if (sspart && MT == 1) {
+        hipLaunchKernelGGL((plsk::xb_kernel<T, VEC, 1, true>), dim3(nblk), dim3(plsk::WG), 0,
+                           c->stream, X, ldx, N, K, Bm, ldb, ncols, out, ldo, sspart);
+        *nss = nblk;
+    } else {
+        hipLaunchKernelGGL((plsk::xb_kernel<T, VEC, MT, false>), dim3(nblk), dim3(plsk::WG), 0,
+                           c->stream, X, ldx, N, K, Bm, ldb, ncols, out, ldo, (double *)nullptr);
+    }
+}
+
+// out(N x C) = X * Bm ; optionally sum of squares partials of column 0 (C must be 1 then)
+template <typename T>
+int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const double *Bm, i64 ldb,
+              int C, T *out, i64 ldo, double *sspart, int *nss) {
+    constexpr int FV = 16 / sizeof(T);
+    bool wide = vec_ok<T>(X, ldx, FV) && vec_ok<T>(out, ldo, FV);
+    // keep >= ~4 workgroups per CU in flight: narrow the per-lane access on short matrices
+    if (wide && N / ((i64)FV * plsk::WG) < 4 * (i64)c->num_cu) wide = false;
+    // One score column of a short, wide matrix: the rows alone give fewer workgroups than there are CUs -- split the
+    // columns as well (xb_split_kernel); ~3 workgroups per CU, at least 128 columns each.
+    if (N > 0 && K >= 1024) {
+        const bool v2 = vec_ok<T>(X, ldx, FV) && (N + (i64)FV * plsk::WG - 1) / ((i64)FV * plsk::WG) >= 8;
+        const i64 per = (i64)plsk::WG * (v2 ? FV : 1);
+        const i64 rg = (N + per - 1) / per;
+        // taken while one row per lane cannot give every CU a workgroup (fp32: two -- its 4-byte accesses stream worse);
+        // measured per shape, tools/xb_split_sweep.py: beyond that the row-parallel kernel is as fast or faster
+        const i64 rg1 = (N + plsk::WG - 1) / plsk::WG;
+        if (rg1 <= (i64)(sizeof(T) == 4 ? 2 : 1) * c->num_cu) {
+            int KS = (int)std::min<i64>(K / 128, (3 * (i64)c->num_cu + rg - 1) / rg);
+            const int kper = (K + KS - 1) / KS;
+            KS = (K + kper - 1) / kper;
+            const i64 ldp = (N + 63) / 64 * 64;
+            const int mt = C > 2 ? 4 : (C > 1 ? 2 : 1);  // columns per sweep of X
+            if (KS >= 2 && KS <= 65535 && ensure(c, c->xbpart, (size_t)KS * mt * ldp * 8) == PLS_HIP_OK) {
+                double *xp = (double *)c->xbpart.p;
+                const int fb = (int)((N + 63) / 64);
+                for (int c0 = 0; c0 < C; c0 += mt) {
+                    const int use = std::min(mt, C - c0);
+                    const double *b = Bm + (i64)c0 * ldb;
+                    Scope s(c, PLS_HIP_FAM_XB, (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8);
+                    const dim3 g((unsigned)rg, (unsigned)KS), blk(plsk::WG);
+#define XS_CASE(V_, M_) hipLaunchKernelGGL((plsk::xb_split_kernel<T, V_, M_>), g, blk, 0, c->stream, X, ldx, N, K, kper, b, ldb, use, xp, ldp)
+                    if (v2) { if (mt == 4) XS_CASE(FV, 4); else if (mt == 2) XS_CASE(FV, 2); else XS_CASE(FV, 1); }
+                    else { if (mt == 4) XS_CASE(1, 4); else if (mt == 2) XS_CASE(1, 2); else XS_CASE(1, 1); }
+#undef XS_CASE
+                    LAUNCH_CHECK(c);
+                    hipLaunchKernelGGL((plsk::xb_split_finish_kernel<T>), dim3(fb, use), blk, 0, c->stream, (const double *)xp, ldp, KS, mt,
+                                       N, out + (i64)c0 * ldo, ldo, C == 1 ? sspart : (double *)nullptr);
+                    LAUNCH_CHECK(c);
+                }
+                if (C == 1 && sspart && nss) *nss = fb;
+                return PLS_HIP_OK;
+            }
+            c->err.clear();
+        }
+    }
+    int c0 = 0;
+    while (c0 < C) {
+        const int rem = C - c0;
+        const double *b = Bm + (i64)c0 * ldb;
+        T *o = out + (i64)c0 * ldo;
+        const int cap = wide ? (FV == 2 ? 32 : 8) : 32;  // fp32 x 4 rows per lane: 8 columns = 32 fp64 accumulators
+        if (sizeof(T) == 4 && rem > 8 && vec_ok<T>(X, ldx, FV)) {
+            // fp32 storage, many columns: up to 32 per pass on the matrix cores (xb_mfma_kernel) -- the LDS-staged
+            // VALU kernel below holds only 8 columns of fp64 accumulators per pass at 4 rows per lane.  (For fp64
+            // storage, where it takes 32 columns per pass, it is the faster one: 0.86 vs 1.04 ms at 20 columns.)
+            const int use = std::min(rem, 32);
+            const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
+            Scope s(c, PLS_HIP_FAM_XB, bytes);
+            const i64 per = (i64)(plsk::WG / plsk::WAVE) * 16 * FV;  // rows per workgroup
+            const dim3 grid((unsigned)((N + per - 1) / per)), blk(plsk::WG);
+            if (use > 16)
+                hipLaunchKernelGGL((plsk::xb_mfma_kernel<T, FV, 2>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo);
+            else
+                hipLaunchKernelGGL((plsk::xb_mfma_kernel<T, FV, 1>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo);
+            LAUNCH_CHECK(c);
+            c0 += use;
+            continue;
+        }
+        if (rem > 4) {
+            // many columns: Bm through LDS, up to `cap` columns per pass over X; the tile is the column
+            // count rounded up to a multiple of 4 (every extra column costs VEC fp64 FMAs per element)
+            const int use = std::min(rem, cap);
+            const int mtc = (use + 3) & ~3;
+            const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
+            Scope s(c, PLS_HIP_FAM_XB, bytes);
+            // fp64, 13..20 columns on a large matrix: two row packs per lane (one LDS read of a B value feeds 4 FMAs)
+            const bool two = wide && FV == 2 && mtc >= 16 && mtc <= 20 && N >= (i64)c->num_cu * 4 * plsk::WG * FV * 2;
+            const i64 per = (i64)plsk::WG * (wide ? FV : 1) * (two ? 2 : 1);
+            const dim3 grid((unsigned)((N + per - 1) / per)), blk(plsk::WG);
+            if (two) {
+                if constexpr (FV == 2) {
+                    switch (mtc) {
+                        case 16: hipLaunchKernelGGL((plsk::xb_wide_kernel<T, 2, 16, 2>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo); break;
+                        default: hipLaunchKernelGGL((plsk::xb_wide_kernel<T, 2, 20, 2>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo); break;
+                    }
+                }
+                LAUNCH_CHECK(c);
+                c0 += use;
+                continue;
+            }
+#define XW_CASE(V, M_) hipLaunchKernelGGL((plsk::xb_wide_kernel<T, V, M_>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo)
+#define XW_SWITCH(V)                                   \
+    switch (mtc) {                                     \
+        case 8: XW_CASE(V, 8); break;                  \
+        case 12: XW_CASE(V, 12); break;                \
+        case 16: XW_CASE(V, 16); break;                \
+        case 20: XW_CASE(V, 20); break;                \
+        case 24: XW_CASE(V, 24); break;                \
+        case 28: XW_CASE(V, 28); break;                \
+        default: XW_CASE(V, 32); break;                \
+    }
+            if (wide) {
+                if constexpr (FV == 2) {
+                    XW_SWITCH(FV)
+                } else {
+                    XW_CASE(FV, 8);
+                }
+            } else {
+                XW_SWITCH(1)
+            }
+#undef XW_SWITCH
+#undef XW_CASE
+            LAUNCH_CHECK(c);
+            c0 += use;
+            continue;
+        }
+        const int mt = rem > 2 ? 4 : rem > 1 ? 2 : 1;
+        const int use = std::min(mt, rem);
+        const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
+        Scope s(c, PLS_HIP_FAM_XB, bytes);
+#define XB_CASE(V, M_) launch_xb_t<T, V, M_>(c, X, ldx, N, K, b, ldb, use, o, ldo, sspart, nss)
+        if (wide) {
+            if (mt == 4) XB_CASE(FV, 4); else if (mt == 2) XB_CASE(FV, 2); else XB_CASE(FV, 1);
+        } else {
+            if (mt == 4) XB_CASE(1, 4); else if (mt == 2) XB_CASE(1, 2); else XB_CASE(1, 1);
+        }
+#undef XB_CASE
+        LAUNCH_CHECK(c);
+        c0 += use;
+    }
+    return PLS_HIP_OK;
+}
+
+template <typename T, int VEC, int KC, int MT>
+void launch_xty_t(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64 N, int K, int M,
+                  int m0, double *part, const XtyGeom &g) {
+    hipLaunchKernelGGL((plsk::xty_kernel<T, VEC, KC, MT>), dim3(g.G, g.nkg), dim3(plsk::WG), 0,
+                       c->stream, X, ldx, Y, ldy, N, K, M, m0, part);
+}
+
+// part[G][K*M] = per-row-group partials of X^T Y; returns G through *nb
+template <typename T>
+int launch_xty(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64 N, int K, int M,
+               double *part, int *nb) {
+    constexpr int FV = 16 / sizeof(T);
+    const bool wide = vec_ok<T>(X, ldx, FV) && vec_ok<T>(Y, ldy, FV);
+    // workgroups per CU aimed at: 8; 4 with 8-response tiles, whose 32 butterfly sums per workgroup want longer walks
+    // (config 4, fp32: 0.55 ms at 4, 0.59 at 8, 0.77 at 32 -- tools/xty_m8.py)
+    const int target = (M >= 8 ? 4 : 8) * c->num_cu;
+    int m0 = 0;
+    const int kc_first = XTY_KCMT / ((M >= 8) ? 8 : (M >= 4 ? 4 : (M >= 2 ? 2 : 1)));
+    while (m0 < M) {
+        const int mt = (M - m0 >= 8) ? 8 : (M - m0 >= 4 ? 4 : (M - m0 >= 2 ? 2 : 1));
+        // 8 responses: 8 columns per workgroup (64 accumulators per lane) -- the Y packs of a row chunk are loaded once
+        // per column group, so 4 columns meant twice as many bytes of Y as of X through L2 (1.0 ms = 2.1 TB/s at config 4)
+        const int kc = XTY_KCMT / mt;
+        const XtyGeom g = xty_geom(N, K, kc, wide ? FV : 1, target, kc_first);
+        *nb = g.G;
+        const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * mt * sizeof(T) + (i64)K * mt * 8;
+        Scope s(c, PLS_HIP_FAM_XTY, bytes);
+#define XTY_CASE(V, KC_, M_) launch_xty_t<T, V, KC_, M_>(c, X, ldx, Y, ldy, N, K, M, m0, part, g)
+        if (wide && mt == 8 && K % 4 == 0) {
+            hipLaunchKernelGGL((plsk::xty8_kernel<T, FV>), dim3(g.G, g.nkg), dim3(plsk::WG), 0, c->stream, X, ldx, Y, ldy, N, K,
+                               M, m0, part);
+        } else if (wide) {
+            if (mt == 8) XTY_CASE(FV, 4, 8); else if (mt == 4) XTY_CASE(FV, 8, 4);
+            else if (mt == 2) XTY_CASE(FV, 16, 2); else XTY_CASE(FV, 32, 1);
+        } else {
+            if (mt == 8) XTY_CASE(1, 4, 8); else if (mt == 4) XTY_CASE(1, 8, 4);
+            else if (mt == 2) XTY_CASE(1, 16, 2); else XTY_CASE(1, 32, 1);
+        }
+#undef XTY_CASE
+        LAUNCH_CHECK(c);
+        m0 += mt;
+    }
+    return PLS_HIP_OK;
+}
+
+template <typename T>
+int launch_deflate(pls_hip_context *c, const T *src, i64 lds, T *dst, i64 ldd, i64 N, int K,
+                   const T *t, const double *p) {
+    constexpr int FV = 16 / sizeof(T);
+    const bool wide = vec_ok<T>(src, lds, FV) && vec_ok<T>(dst, ldd, FV) && vec_ok<T>(t, FV, FV);
+    const int nkg = (K + DEFL_KC - 1) / DEFL_KC;
+    const int vec = wide ? FV : 1;
+    const i64 nch = (N + (i64)plsk::WG * vec - 1) / ((i64)plsk::WG * vec);
+    const i64 G = std::min<i64>(std::max<i64>(nch, 1), std::max<i64>(1, (16 * c->num_cu) / nkg));
+    const i64 bytes = 2 * (i64)N * K * sizeof(T) + (i64)N * sizeof(T) + (i64)K * 8;
+    Scope s(c, PLS_HIP_FAM_DEFLATE, bytes);
+    const i64 nrb = (N + (i64)plsk::WG * FV - 1) / ((i64)plsk::WG * FV);
+    if (wide && K <= 65535 && nrb >= 1 && nrb < (1ll << 31)) {  // one 4 KB column piece per workgroup
+        hipLaunchKernelGGL((plsk::deflate_piece_kernel<T, FV>), dim3((unsigned)nrb, (unsigned)K), dim3(plsk::WG), 0,
+                           c->stream, src, lds, dst, ldd, N, t, p);
+        LAUNCH_CHECK(c);
+        return PLS_HIP_OK;
+    }
+    if (wide)
+        hipLaunchKernelGGL((plsk::deflate_kernel<T, FV, DEFL_KC>), dim3((unsigned)G, nkg),
+                           dim3(plsk::WG), 0, c->stream, src, lds, dst, ldd, N, K, t, p);
+    else
+        hipLaunchKernelGGL((plsk::deflate_kernel<T, 1, DEFL_KC>), dim3((unsigned)G, nkg),
+                           dim3(plsk::WG), 0, c->stream, src, lds, dst, ldd, N, K, t, p);
+    LAUNCH_CHECK(c);
+    return PLS_HIP_OK;
+}
+
+int launch_reduce(pls_hip_context *c, const double *part, int nb, int L, const double *sspart,
+                  int nss, double *red, i64 out_stride = 0) {
+    Scope s(c, PLS_HIP_FAM_SMALL, ((i64)nb * L + nss + (i64)plsk::RED_SLICES * (L + 1)) * 8);
+    hipLaunchKernelGGL(plsk::reduce_partials_kernel, dim3((L + 63) / 64, plsk::RED_SLICES),
+                       dim3(plsk::WG), 0, c->stream, part, nb, L, sspart, nss, red, out_stride);
+    LAUNCH_CHECK(c);
+    return PLS_HIP_OK;
+}
+
+}  // namespace

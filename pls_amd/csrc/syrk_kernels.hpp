@@ -149,11 +149,11 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_base) {
 #endif
 }
 
-// ---- LDS-DMA variant ----------------------------------------------------------------------------------
+// ---- LDS-DMA variant (the kernel that runs whenever N % V == 0; the register-staged one above takes ragged N) ----------
 // The register-staged kernel above exposes the global-load latency of every slab (load -> barrier -> LDS
 // store -> barrier -> 128 MFMAs; only the second workgroup of the CU covers it): 67-68 % MFMA-busy.  Here
-// the panels go global -> LDS directly (global_load_lds_dwordx4: no staging registers, so the 128
-// accumulator registers leave room), into one of two LDS buffers, one slab ahead of the MFMAs, with ONE
+// the panels go global -> LDS directly (global_load_lds_dwordx4: no staging registers),
+// into one of two LDS buffers, one slab ahead of the MFMAs, with ONE
 // barrier per slab:
 //     barrier (slab s landed, slab s-1 consumed) -> issue slab s+1 -> 16 MFMAs x RB/4 steps on slab s.
 // An LDS-DMA instruction writes 1 KB lane-linearly, so the LDS image of a panel is [column][8 positions of
@@ -163,229 +163,12 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_base) {
 // address of the DMA and to the READ address alike.
 // Columns >= K read column K-1 again (their products are never written); the launcher requires N % V == 0
 // and sends rows beyond N to a zero block.
-// Tiles (m, n) of a wave's 4 x 4 set as a 16-bit mask, bit 4 m + n.
-constexpr unsigned SYRK_ALL = 0xFFFFu;
-constexpr unsigned SYRK_UPPER = 0x8CEFu;   // m <= n: rows 0xF, 0xE, 0xC, 0x8
-
-// the MFMAs of one slab for the tiles in MASK (operands of unused rows / columns are never read)
-template <typename T, unsigned MASK, int V, int RB, int CS>
-__device__ __forceinline__ void syrk_slab_mfma(const T *As, const T *Bs, int a0, int b0, int li, int lq, int fl, f64x4 (&acc)[4][4]) {
-#pragma unroll
-    for (int kk = 0; kk < RB; kk += 4) {
-        const int r = kk + lq;
-        const int off = (((r / V) ^ fl) * V) + (r % V);
-        double a[4], b[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-            if ((MASK >> (4 * m)) & 0xFu) a[m] = (double)As[(a0 + 16 * m + li) * CS + off];
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-            if (MASK & (0x1111u << n)) b[n] = (double)Bs[(b0 + 16 * n + li) * CS + off];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-                if ((MASK >> (4 * m + n)) & 1u) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
-    }
-}
-
-// Diagonal blocks: every wave does only the tiles on or above the diagonal of ITS quadrant (10 of 16).  For the quadrants
-// (0,0) and (1,1) that is all the block needs of them; the quadrants (0,1) and (1,0) are mirror images of each other, so
-// the upper tiles of the one plus the mirrored upper tiles of the other give both in full (their four diagonal tiles are
-// computed twice -- the same products in the same order, the same bits).  Same wave-to-quadrant map and ONE tile pattern
-// for all four waves (a per-wave choice between patterns costs the register allocator 400 spills).  A diagonal workgroup
-// needs 10/16 of the time per slab and gets 16/10 of the rows (sd row splits instead of gridDim.y; the workgroups
-// beyond sd only zero their slot of the partial buffer): 8.5 instead of 10 block-times at K = 512.
-// One workgroup's share of a block for the tile set MASK: slabs s0, s0 + nsplit, ... of the panels bi (A) and bj (B).
-// Out of line: the two instantiations then get a register allocation each (inlined side by side in one kernel they spill).
-// WITH_Y (diagonal blocks only): the workgroup also forms X^T Y (src/pls.cpp:396) for the 128 columns of its panel from the
-// slabs as they lie in LDS -- thread = (column, half of the slab's rows), M <= 8 accumulators; the slab's rows of Y arrive by one
-// more LDS-DMA instruction -- so that a KERNEL_TYPE2 / GRAM fit needs no separate pass over X for it.  xy_out: this row split's partial, K x M (ld K).
-template <typename T, unsigned MASK, bool WITH_Y>
-__device__ __noinline__ void syrk_glds_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, int bj, i64 s0, int nsplit,
-                                            const T *__restrict__ zeros, double *__restrict__ out, const T *__restrict__ Y, i64 ldy,
-                                            int M, double *__restrict__ xy_out) {
-    // (declared here, not passed in: a pointer argument of an out-of-line function is a generic pointer, and LDS reads
-    // through it become flat loads)
-    extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];  // [2 buffers][A panel, B panel]
-    T *lds = reinterpret_cast<T *>(slab_raw);
-    constexpr int V = 16 / sizeof(T);   // rows per 16-byte position
-    constexpr int RB = 8 * V;           // rows per slab
-    constexpr int CS = 8 * V;           // elements per column in LDS (128 bytes)
-    constexpr int PANEL = SYRK_TB * CS; // elements per panel buffer
-    const bool diag = (bi == bj);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int li = lane & 15, lq = lane >> 4;
-    const int a0 = (wv >> 1) * 64, b0 = (wv & 1) * 64;  // this wave's quadrant of the block
-    const int fl = li >> 1;  // swizzle key of this lane's operand columns: ((a0 + 16 m + li) >> 1) & 7
-
-    // staging map of the DMA: wave-instruction i covers columns 8 i .. 8 i + 7; lane = (column, position)
-    const int scol = lane >> 3, spos = lane & 7;
-
-    f64x4 acc[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
-    double accy[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) accy[m] = 0.0;
-    // X^T Y: column of the panel, half of the slab's 8 row positions.  Neighbouring lanes = the two halves of a column and
-    // columns with different swizzle keys: the 16-byte reads of a group of 8 lanes land on 4 different bank groups (with
-    // lane = column they all collide: 8-way conflicts, 0.8 instead of 0.7 of a full block's time per slab)
-    const int yc = tid >> 1, yh = tid & 1;
-    const int ykey = (yc >> 1) & 7;
-
-    const i64 nslabs = (N + RB - 1) / RB;
-    auto issue = [&](i64 s, int buf) {
-        T *Ab = lds + (size_t)buf * 2 * PANEL, *Bb = Ab + PANEL;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = wv + 4 * j;
-            const int col = 8 * i + scol;
-            const int q = spos ^ ((col >> 1) & 7);
-            const i64 row = s * RB + (i64)q * V;
-            const bool ok = row < N;  // N % V == 0: a position is all-valid or all-invalid
-            const int ca = min(bi * SYRK_TB + col, K - 1);
-            const T *ga = ok ? X + row + (i64)ca * ldx : zeros;
-            glds16(ga, Ab + i * (8 * CS));
-            if (!diag) {
-                const int cb = min(bj * SYRK_TB + col, K - 1);
-                const T *gb = ok ? X + row + (i64)cb * ldx : zeros;
-                glds16(gb, Bb + i * (8 * CS));
-            }
-        }
-        if constexpr (WITH_Y) {  // the slab's rows of Y, [response][8 positions of 16 bytes]: one DMA instruction of wave 0
-            if (wv == 0) {
-                const int m = lane >> 3, pos = lane & 7;
-                const i64 row = s * RB + (i64)pos * V;
-                const T *gy = (row < N && m < M) ? Y + row + (i64)m * ldy : zeros;
-                glds16(gy, lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS));
-            }
-        }
-    };
-
-    i64 s = s0;
-    int buf = 0;
-    if (s < nslabs) issue(s, 0);
-    for (; s < nslabs; s += nsplit, buf ^= 1) {
-        __syncthreads();  // vmcnt(0) + barrier: slab s has landed for every wave; the other buffer is free again
-        const T *As = lds + (size_t)buf * 2 * PANEL, *Bs = diag ? As : As + PANEL;
-        // (X^T Y before the next slab's DMA is issued: the compiler puts s_waitcnt vmcnt(0) in front of these LDS reads, which
-        // behind the issue would wait for the slab that was just requested)
-        if constexpr (WITH_Y) {
-            const T *Ys = lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS);
-            Pack<T, V> xv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                xv[q] = *reinterpret_cast<const Pack<T, V> *>(As + yc * CS + (((4 * yh + q) ^ ykey) * V));
-            if (M == 1) {  // the usual case, without the per-response branches
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const Pack<T, V> yv = *reinterpret_cast<const Pack<T, V> *>(Ys + (4 * yh + q) * V);  // every lane of a wave: the same address
-#pragma unroll
-                    for (int e = 0; e < V; ++e) accy[0] = fma((double)xv[q].v[e], (double)yv.v[e], accy[0]);
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < 8; ++m)
-                    if (m < M) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const Pack<T, V> yv = *reinterpret_cast<const Pack<T, V> *>(Ys + (m * 8 + 4 * yh + q) * V);
-#pragma unroll
-                            for (int e = 0; e < V; ++e) accy[m] = fma((double)xv[q].v[e], (double)yv.v[e], accy[m]);
-                        }
-                    }
-            }
-        }
-        if (s + nsplit < nslabs) issue(s + nsplit, buf ^ 1);
-        syrk_slab_mfma<T, MASK, V, RB, CS>(As, Bs, a0, b0, li, lq, fl, acc);
-    }
-    if constexpr (WITH_Y) {  // the two row halves of a column, then one partial row of X^T Y per row split
-        __syncthreads();     // the panels have been read
-        double *ysh = reinterpret_cast<double *>(slab_raw);  // [2][128][8]
-#pragma unroll
-        for (int m = 0; m < 8; ++m) ysh[(yh * SYRK_TB + yc) * 8 + m] = accy[m];
-        __syncthreads();
-        const int col = bi * SYRK_TB + yc;
-        if (yh == 0 && col < K)
-            for (int m = 0; m < M; ++m) xy_out[col + (i64)m * K] = ysh[yc * 8 + m] + ysh[(SYRK_TB + yc) * 8 + m];
-    }
-
-    // f64 C/D layout: lane holds D[row = (lane>>4) + 4*reg][col = lane&15]; row <-> a, col <-> b.  Every computed tile is
-    // written with its mirror image.
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            if (!((MASK >> (4 * m + n)) & 1u)) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ga_ = bi * SYRK_TB + a0 + 16 * m + lq + 4 * r;
-                const int gb_ = bj * SYRK_TB + b0 + 16 * n + li;
-                if (ga_ < K && gb_ < K) {
-                    const double v = acc[m][n][r];
-                    out[ga_ + (i64)gb_ * K] = v;
-                    out[gb_ + (i64)ga_ * K] = v;
-                }
-            }
-        }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void syrk_glds_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
-                                                           const T *__restrict__ zeros, double *__restrict__ part, int so, int sd,
-                                                           const T *__restrict__ Y, i64 ldy, int M, double *__restrict__ xypart) {
-    // 1-D grid, exactly the workgroups that have rows: first so splits of every off-diagonal block, then sd of every
-    // diagonal block (workgroups that only exit still take a dispatch slot: a 2-D grid with idle members ran 7.8 ms
-    // instead of 6.1).  A diagonal block has fewer partials than the so the reduction sums: its workgroup j also zeroes
-    // the slots j + sd, j + 2 sd, ... < so.
-    const int ndiag = nbk, noff = nbk * (nbk + 1) / 2 - nbk;
-    int id = blockIdx.x, split, blk;
-    bool diag;
-    if (id < noff * so) {
-        diag = false;
-        blk = id % noff;
-        split = id / noff;
-    } else {
-        diag = true;
-        id -= noff * so;
-        blk = id % ndiag;
-        split = id / ndiag;
-    }
-    int bi, bj;
-    if (diag) {
-        bi = bj = blk;
-    } else {  // off-diagonal blocks numbered row by row: (0,1), (0,2), ..., (1,2), ...
-        bi = 0;
-        int rem = blk;
-        while (rem >= nbk - 1 - bi) { rem -= nbk - 1 - bi; ++bi; }
-        bj = bi + 1 + rem;
-    }
-    double *out = part + (i64)split * ((i64)K * K);
-    if (diag) {
-        for (int z = split + sd; z < so; z += sd) {
-            double *zo = part + (i64)z * ((i64)K * K);
-            for (int e = threadIdx.x; e < SYRK_TB * SYRK_TB; e += 256) {
-                const int ga_ = bi * SYRK_TB + (e & (SYRK_TB - 1)), gb_ = bj * SYRK_TB + e / SYRK_TB;
-                if (ga_ < K && gb_ < K) zo[ga_ + (i64)gb_ * K] = 0.0;
-            }
-        }
-        if (Y)
-            syrk_glds_body<T, SYRK_UPPER, true>(X, ldx, N, K, bi, bj, split, sd, zeros, out, Y, ldy, M, xypart + (i64)split * ((i64)K * M));
-        else
-            syrk_glds_body<T, SYRK_UPPER, false>(X, ldx, N, K, bi, bj, split, sd, zeros, out, nullptr, 0, 0, nullptr);
-    } else {
-        syrk_glds_body<T, SYRK_ALL, false>(X, ldx, N, K, bi, bj, split, so, zeros, out, nullptr, 0, 0, nullptr);
-    }
-}
-
-// ---- eight waves per workgroup (round 3) ---------------------------------------------------------------------------------
-// Same LDS image, DMA and swizzle as above; 512 threads = 8 waves, 64 accumulator registers per lane instead of 128, so that
-// two workgroups per CU are FOUR waves per SIMD instead of two: with two, the MFMA pipe idles whenever both waves of a SIMD
-// sit at their slab barriers (the four SIMDs of a workgroup drift apart by up to one 16-MFMA burst).  Full blocks, 4-wave
-// form 5.61 ms -> 8-wave form 5.13 ms on config 3 (`tools/syrk_ab.sh`).
+// ---- eight waves per workgroup ------------------------------------------------------------------------------------------
+// 512 threads = 8 waves, 64 accumulator registers per lane, so that two workgroups per CU are FOUR waves per SIMD: with two
+// (the 4-wave form of rounds 1-2, 128 accumulator registers per lane, deleted in round 4: profiles/r3/syrk_eight_vs_four_waves_ab.txt)
+// the MFMA pipe idles whenever both waves of a SIMD sit at their slab barriers.  Full blocks 5.61 ms -> 5.13 ms on config 3.
+// Diagonal blocks: only the 36 tiles on or above the diagonal (a diagonal workgroup costs 0.74 of a full one per slab with
+// X^T Y on board and gets that many more rows: sd row splits instead of so).
 //   off-diagonal blocks: waves in a 4 x 2 arrangement, wave tile 32 x 64: 8 MFMAs and 6 operand reads per 4-row step;
 //   diagonal blocks: the 36 tiles (16 x 16) on or above the diagonal of the 8 x 8 tile grid dealt out to the 8 waves in
 //   enumeration order (5 or 4 each -- 5/8 of a full block's time per slab), every tile with its own two operand reads;
@@ -598,8 +381,16 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
 template <typename T>
 __global__ __launch_bounds__(512, 4) void syrk_glds8_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
                                                             const T *__restrict__ zeros, double *__restrict__ part, int so, int sd,
-                                                            const T *__restrict__ Y, i64 ldy, int M, double *__restrict__ xypart) {
-    // grid layout as syrk_glds_kernel: first so splits of every off-diagonal block, then sd of every diagonal block
+                                                            const T *__restrict__ Y, i64 ldy, int M, double *__restrict__ xypart,
+                                                            int stagger, int stagger_mode) {
+    // EXPERIMENT: de-phase the two workgroups of a CU (one slab barrier each): half of the workgroups start late
+    {
+        const bool late = stagger_mode == 0 ? (blockIdx.x >= gridDim.x / 2) : (stagger_mode == 1 ? (blockIdx.x & 1) : ((blockIdx.x >> 3) & 1));
+        if (late) for (int q = 0; q < stagger; ++q) __builtin_amdgcn_s_sleep(1);
+    }
+    // 1-D grid, exactly the workgroups that have rows: first so splits of every off-diagonal block, then sd of every diagonal
+    // block (workgroups that only exit still take a dispatch slot: a 2-D grid with idle members ran 7.8 ms instead of 6.1).  A
+    // diagonal block has fewer partials than the so the reduction sums: its workgroup j also zeroes the slots j + sd, ... < so.
     const int ndiag = nbk, noff = nbk * (nbk + 1) / 2 - nbk;
     int id = blockIdx.x, split, blk;
     bool diag;
@@ -668,16 +459,12 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         const i64 nslabs_g = (N + RBG - 1) / RBG;
         i64 Sg = nblocks <= slots ? slots / nblocks : (8 * slots + nblocks - 1) / nblocks;
         i64 Sd = 0;  // row splits of the diagonal blocks; 0 = as the others (several residency waves balance themselves)
-        static const bool tri = !(getenv("PLS_HIP_SYRK_TRI") && atoi(getenv("PLS_HIP_SYRK_TRI")) == 0);
         // X^T Y rides along in the diagonal workgroups (one partial row per row split of a diagonal block)
         const bool fuse_y0 = Y && xypart && nb_xy && M >= 1 && M <= 8 && ((uintptr_t)Y % 16) == 0 && (ldy % V) == 0;
-        if (tri && nblocks <= slots) {  // one residency wave: a diagonal workgroup costs 10/16 per slab (more with X^T Y on board)
-            static const double wenv = getenv("PLS_HIP_SYRK_DIAGW") ? atof(getenv("PLS_HIP_SYRK_DIAGW")) : 0.0;
-            // measured optima with X^T Y on board: 0.70 for one response (branch-free step), 0.78-0.80 for several
-            // (the 8-wave form: a diagonal workgroup's tiles each read their own two operands -- 0.74 measured for one response)
-            static const bool w8w = !(getenv("PLS_HIP_SYRK_W8") && atoi(getenv("PLS_HIP_SYRK_W8")) == 0);
-            const double dw = wenv > 0.0 ? wenv
-                                         : (w8w ? (fuse_y0 ? (M == 1 ? 0.74 : 0.82) : 0.66) : (fuse_y0 ? (M == 1 ? 0.70 : 0.78) : 0.625));
+        if (nblocks <= slots) {  // one residency wave: a diagonal workgroup costs 36/64 per slab (more with X^T Y on board)
+            // measured optima of the row-split weight (profiles/r3/syrk_diagonal_weight_sweep.txt): 0.74 with X^T Y of one
+            // response on board, 0.82 for several, 0.66 without
+            const double dw = fuse_y0 ? (M == 1 ? 0.74 : 0.82) : 0.66;
             const double units = (nblocks - nbk) + dw * nbk;
             Sg = (i64)(slots / units);
             Sd = std::max<i64>(1, (i64)(dw * Sg));
@@ -687,24 +474,14 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         Sg = std::min<i64>(Sg, part_capacity_doubles / ((i64)K * K));
         if (Sg < 1) return 1;
         Sd = Sd ? std::min<i64>(Sd, Sg) : Sg;
-        if (!tri) Sd = Sg;
-        static const bool w8 = !(getenv("PLS_HIP_SYRK_W8") && atoi(getenv("PLS_HIP_SYRK_W8")) == 0);  // 0: the 4-wave form (A/B)
-        if (w8) {
-            if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_glds8_kernel<T>), (int)LDS_G)) return 1;
-            const i64 nwg8 = (i64)(nblocks - nbk) * Sg + (i64)nbk * Sd;
-            const bool fuse_y8 = fuse_y0 && Sd * (i64)K * M <= xypart_capacity_doubles;
-            hipLaunchKernelGGL(syrk_glds8_kernel<T>, dim3((unsigned)nwg8), dim3(512), LDS_G, stream, X, ldx, N, K, nbk,
-                               static_cast<const T *>(zeros), part, (int)Sg, (int)Sd, fuse_y8 ? Y : nullptr, ldy, M, xypart);
-            if (fuse_y8) *nb_xy = (int)Sd;
-            *nb = (int)Sg;
-            return 0;
-        }
-        if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_glds_kernel<T>), (int)LDS_G)) return 1;
-        const i64 nwg = (i64)(nblocks - nbk) * Sg + (i64)nbk * Sd;
-        const bool fuse_y = fuse_y0 && Sd * (i64)K * M <= xypart_capacity_doubles;
-        hipLaunchKernelGGL(syrk_glds_kernel<T>, dim3((unsigned)nwg), dim3(256), LDS_G, stream, X, ldx, N, K, nbk,
-                           static_cast<const T *>(zeros), part, (int)Sg, (int)Sd, fuse_y ? Y : nullptr, ldy, M, xypart);
-        if (fuse_y) *nb_xy = (int)Sd;
+        if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_glds8_kernel<T>), (int)LDS_G)) return 1;
+        const i64 nwg8 = (i64)(nblocks - nbk) * Sg + (i64)nbk * Sd;
+        const bool fuse_y8 = fuse_y0 && Sd * (i64)K * M <= xypart_capacity_doubles;
+        static const int stag = getenv("PLS_HIP_SYRK_STAG") ? atoi(getenv("PLS_HIP_SYRK_STAG")) : 0;        // EXPERIMENT
+        static const int stagm = getenv("PLS_HIP_SYRK_STAGM") ? atoi(getenv("PLS_HIP_SYRK_STAGM")) : 0;     // EXPERIMENT
+        hipLaunchKernelGGL(syrk_glds8_kernel<T>, dim3((unsigned)nwg8), dim3(512), LDS_G, stream, X, ldx, N, K, nbk,
+                           static_cast<const T *>(zeros), part, (int)Sg, (int)Sd, fuse_y8 ? Y : nullptr, ldy, M, xypart, stag, stagm);
+        if (fuse_y8) *nb_xy = (int)Sd;
         *nb = (int)Sg;
         return 0;
     }

@@ -378,4 +378,148 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_m_kernel(const T *__rest
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The smallest problems -- N <= 64 rows, K <= 32 columns, 1..8 responses: BASELINE config 1, the reference's README example
+// (toyX / toyY, 10 x 15, two responses, two components) and every cross-validation fold of it -- as ONE WAVE.  A workgroup
+// of 1024 threads spends such a fit in its barriers (31 us for config 1 in tiny_fit_m_kernel; one CPU core: 10.8 us); a
+// single wave has no workgroup barrier at all: lane i holds row i of X in registers, lane k owns entry k of everything
+// K-sized (in LDS, handed between the lanes behind a wave-level fence), every sum over rows or columns is a wave sum on
+// the DPP / permlane path (wave_sum, wave_multi_sum).  Same operation sequence as the kernels above (src/pls.cpp:396-434,
+// the direction by the one-wave eigen solver of the component update); fold mode = one wave per fold.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int MICRO_K = 32;
+inline bool micro_fit_covers(i64 N, int K, int M, int A, i64 ldx, size_t es) {
+    return N >= 1 && N <= WAVE && K >= 1 && K <= MICRO_K && M >= 1 && M <= 8 && A >= 1 && A <= K && (i64)MICRO_K * ldx * (i64)es < (1ll << 31);
+}
+
+template <typename T, int MM>
+__global__ __launch_bounds__(WAVE) void micro_fit_kernel(const T *__restrict__ X, i64 ldx, const T *__restrict__ Y, i64 ldy, int N,
+                                                         int K, int M, int A, int power_iters, double *__restrict__ W,
+                                                         double *__restrict__ P, double *__restrict__ Q, double *__restrict__ R,
+                                                         T *__restrict__ Tm, i64 ldt, double *__restrict__ B,
+                                                         const i64 *__restrict__ fold_idx, int ts, i64 nobs, double *__restrict__ E) {
+    static_assert(MM * MM <= WAVE && MM * (MM + 1) / 2 <= 36, "one wave solves the eigenproblem");
+    constexpr int NP = MM * (MM + 1) / 2;
+    __shared__ double xy[MM][MICRO_K], rl[MICRO_K], pl[MICRO_K], Pm[MICRO_K][MICRO_K], Rm[MICRO_K][MICRO_K], Ql[MICRO_K][MM];
+    __shared__ double Gs[MM * MM], Bs[MM * MM], Cs[MM * MM], qs[MM];
+    const int lane = threadIdx.x;  // row `lane` of X, and entry `lane` of everything K-sized
+    const bool act = lane < N, kok = lane < K;
+    double x[MICRO_K];
+#pragma unroll
+    for (int k = 0; k < MICRO_K; ++k) x[k] = (act && k < K) ? (double)X[lane + (i64)k * ldx] : 0.0;
+    const bool fold = fold_idx != nullptr;
+    int hpos = -1;
+    if (fold && act)
+        for (int j = 0; j < ts; ++j)
+            if (fold_idx[(i64)blockIdx.x * ts + j] == lane) hpos = j;
+    const bool held = hpos >= 0;
+    double yv[MM], yhat[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        yv[m] = (act && m < M) ? (double)Y[lane + (i64)m * ldy] : 0.0;
+        yhat[m] = 0.0;
+    }
+    rl[lane & (MICRO_K - 1)] = 0.0;  // (read, times x = 0, beyond K)
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {  // XY = X^T Y (:396); a held-out row takes part with y = 0
+        double vals[MICRO_K];
+        const double f = held ? 0.0 : yv[m];
+#pragma unroll
+        for (int k = 0; k < MICRO_K; ++k) vals[k] = x[k] * f;
+        bool valid = true;
+        const int idx = wave_multi_sum<MICRO_K, 32>(vals, lane, valid);
+        if (valid) xy[m][idx] = vals[0];
+    }
+    wave_lds_sync();
+    double xyk[MM];  // this lane's entry of every column of XY
+#pragma unroll
+    for (int m = 0; m < MM; ++m) xyk[m] = kok ? xy[m][lane] : 0.0;
+    for (int a = 0; a < A; ++a) {
+        {  // ---- direction (:403-411): G = XY^T XY, its dominant eigenvector, w = XY q / |XY q|
+            double g[NP];
+#pragma unroll
+            for (int i = 0, pr = 0; i < MM; ++i)
+#pragma unroll
+                for (int j = i; j < MM; ++j, ++pr) g[pr] = xyk[i] * xyk[j];
+            bool valid = true;
+            const int idx = wave_multi_sum<NP, 32>(g, lane, valid);
+            if (valid) {
+                int gi = 0, rem = idx;
+                while (rem >= MM - gi) { rem -= MM - gi; ++gi; }
+                const int gj = gi + rem;
+                Gs[gi + gj * MM] = g[0];
+                Gs[gj + gi * MM] = g[0];
+            }
+            wave_lds_sync();
+            dominant_eigvec_wave<MM>(Gs, Bs, Cs, qs, power_iters);
+        }
+        double wk = 0.0;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) wk = fma(xyk[m], qs[m], wk);
+        wk = wk / sqrt(wave_sum(wk * wk));
+        double rk = wk;
+        for (int j = 0; j < a; ++j) {  // r = w - sum_j (p_j^T w) r_j, against the ORIGINAL w, in the reference's order (:412-416)
+            const double cj = wave_sum(kok ? Pm[j][lane] * wk : 0.0);
+            rk -= cj * (kok ? Rm[j][lane] : 0.0);
+        }
+        wave_lds_sync();  // (rl of the previous component has been read)
+        if (kok) {
+            rl[lane] = rk;
+            Rm[a][lane] = rk;
+            if (!fold) {
+                W[lane + (i64)a * K] = wk;
+                R[lane + (i64)a * K] = rk;
+            }
+        }
+        wave_lds_sync();
+        double ti = 0.0;  // t = X r (:419)
+#pragma unroll
+        for (int k = 0; k < MICRO_K; ++k) ti = fma(x[k], rl[k], ti);
+        const double ui = ti;
+        if (held) ti = 0.0;
+        if (act && !fold) Tm[lane + (i64)a * ldt] = (T)ti;
+        const double tt = wave_sum(ti * ti);  // (:420)
+        {  // p = X^T t / tt (:421, :427)
+            double vals[MICRO_K];
+#pragma unroll
+            for (int k = 0; k < MICRO_K; ++k) vals[k] = x[k] * ti;
+            bool valid = true;
+            const int idx = wave_multi_sum<MICRO_K, 32>(vals, lane, valid);
+            if (valid) pl[idx] = vals[0];
+        }
+        wave_lds_sync();
+        const double pk = kok ? pl[lane] / tt : 0.0;
+        if (kok) {
+            Pm[a][lane] = pk;
+            if (!fold) P[lane + (i64)a * K] = pk;
+        }
+        double qv[MM];  // q = XY^T r / tt (:428)
+#pragma unroll
+        for (int m = 0; m < MM; ++m) qv[m] = wave_sum(rk * xyk[m]) / tt;
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+            if (lane == m && m < M) {
+                Ql[a][m] = qv[m];
+                if (!fold) Q[m + (i64)a * M] = qv[m];
+            }
+        if (held) {  // residuals of a held-out row with a + 1 components
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+                if (m < M) {
+                    yhat[m] = fma(ui, qv[m], yhat[m]);
+                    E[(i64)m * nobs * A + ((i64)blockIdx.x * ts + hpos) + (i64)a * nobs] = yv[m] - yhat[m];
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < MM; ++m) xyk[m] -= (pk * qv[m]) * tt;  // XY -= (p q^T) tt (:429)
+    }
+    wave_lds_sync();
+    if (B && kok && !fold)  // B = R Q^T (:444-447)
+        for (int m = 0; m < M; ++m) {
+            double b = 0.0;
+            for (int a = 0; a < A; ++a) b = fma(Rm[a][lane], Ql[a][m], b);
+            B[lane + (i64)m * K] = b;
+        }
+}
+
 }  // namespace plsk

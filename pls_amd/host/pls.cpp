@@ -42,10 +42,7 @@ std::vector<int> device_list() {
             }
         }
     }
-    if (devs.empty()) {
-        const char *e = std::getenv("PLS_HIP_DEVICE");
-        devs.push_back(e ? std::atoi(e) : 0);
-    }
+    if (devs.empty()) devs.push_back(0);
     return devs;
 }
 
@@ -57,7 +54,7 @@ std::atomic<unsigned long> g_cfg_gen{1};
 }  // namespace
 
 // A device context: a pls_hip_group (include/pls_hip.h) over the GPUs PLS_HIP_DEVICES names -- "4" = devices 0..3,
-// "0,2,5" = that list (an ordinal may repeat: virtual shards on one GPU); default: the single device PLS_HIP_DEVICE (or 0) --
+// "0,2,5" = that list (an ordinal may repeat: virtual shards on one GPU; "3," = device 3 alone); default: device 0 --
 // or over the list given to PLS::set_devices.  The rows of every matrix are spread over the members, one host thread per
 // member inside the library; the library keeps its workspace in the member handles, so repeated fits reuse the same device
 // buffers.  The reference has no shared state between Models (include/PLS/pls.h:184-266 upstream): here a Model carries its

@@ -37,3 +37,27 @@ def handle():
     h = pls_amd.Handle()
     yield h
     h.close()
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def handle_with_env(**env):
+    """A fresh pls_amd.Handle created under the given environment switches: the library reads its switches ONCE, when a
+    handle is created (pls_hip_create), so a test that compares two settings makes a handle for the other one."""
+    import pls_amd
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        h = pls_amd.Handle()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    try:
+        yield h
+    finally:
+        h.close()

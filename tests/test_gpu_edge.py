@@ -87,6 +87,19 @@ SHAPES = [
 ]
 
 
+@pytest.fixture(scope="module")
+def handle():
+    """(this module's handle: small single-response fits on the GENERAL plan -- PLS_HIP_TINY=0, read when the handle is
+    created -- they would otherwise run as one launch and never reach the kernels under test)"""
+    from conftest import handle_with_env
+    torch = _torch()
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    torch.cuda.set_device(0)
+    with handle_with_env(PLS_HIP_TINY=0) as h:
+        yield h
+
+
 @pytest.fixture(params=[(0, 1), (1, 1)], ids=["kernel", "nipals"])
 def plan(request, handle):
     import pls_amd
@@ -102,7 +115,6 @@ def plan(request, handle):
 def test_edge_shapes_take_the_one_sweep_plan(handle, oracle, po, plan, monkeypatch, N, K, M, A, dt, ld_extra, base_off):
     import pls_amd
     torch = _torch()
-    monkeypatch.setenv("PLS_HIP_TINY", "0")  # (small single-response fits would otherwise run as ONE launch)
     tdt = torch.float64 if dt == "f64" else torch.float32
     Xh = oracle.synth_x(0, N, K); Yh = oracle.synth_y(0, N, M)
     if dt == "f32":

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import DATA, GOLDEN
+from conftest import handle_with_env, DATA, GOLDEN
 
 pytestmark = pytest.mark.gpu
 
@@ -957,13 +957,12 @@ def test_single_launch_fit(handle, oracle, po, N, K, A, dt, pad):
         torch.cuda.synchronize()
         t = handle.timing()
         assert sum(t["launches"].values()) == 1, t["launches"]
-        os.environ["PLS_HIP_TINY"] = "0"
-        try:
-            plain = handle.fit_device(Xd, Yd, A)
+        with handle_with_env(PLS_HIP_TINY=0) as general:  # (the switches are read when a handle is created)
+            general.set_option(pls_amd.OPT_PROFILE, 2)
+            plain = general.fit_device(Xd, Yd, A)
             torch.cuda.synchronize()
-            assert sum(handle.timing()["launches"].values()) > 1
-        finally:
-            del os.environ["PLS_HIP_TINY"]
+            assert sum(general.timing()["launches"].values()) > 1
+            plain = {k: v.clone() for k, v in plain.items()}
     finally:
         handle.set_option(pls_amd.OPT_PROFILE, 0)
     tol = dict(tol_b=1e-10, tol_col=1e-9) if dt == "f64" else dict(tol_b=2e-5, tol_col=2e-4, tol_inv=1e-3)
@@ -999,13 +998,12 @@ def test_single_launch_fit_several_responses(handle, oracle, po, N, K, M, A, dt,
         torch.cuda.synchronize()
         t = handle.timing()
         assert sum(t["launches"].values()) == 1, t["launches"]
-        os.environ["PLS_HIP_TINY"] = "0"
-        try:
-            plain = handle.fit_device(Xd, Yd, A)
+        with handle_with_env(PLS_HIP_TINY=0) as general:  # (the switches are read when a handle is created)
+            general.set_option(pls_amd.OPT_PROFILE, 2)
+            plain = general.fit_device(Xd, Yd, A)
             torch.cuda.synchronize()
-            assert sum(handle.timing()["launches"].values()) > 1
-        finally:
-            del os.environ["PLS_HIP_TINY"]
+            assert sum(general.timing()["launches"].values()) > 1
+            plain = {k: v.clone() for k, v in plain.items()}
     finally:
         handle.set_option(pls_amd.OPT_PROFILE, 0)
     tol = dict(tol_b=1e-10, tol_col=1e-9) if dt == "f64" else dict(tol_b=2e-5, tol_col=2e-4, tol_inv=1e-3)
@@ -1031,9 +1029,8 @@ def test_single_launch_folds_several_responses(handle, oracle, po, monkeypatch, 
     got = handle.cv_folds(Xd, Yd, A, idx).cpu().numpy()
     ref = _fold_reference(oracle, Xh, Yh, A, idx)
     assert np.abs(got - ref).max() < 1e-9 * max(np.abs(ref).max(), 1.0)
-    monkeypatch.setenv("PLS_HIP_TINY", "0")
-    general = handle.cv_folds(Xd, Yd, A, idx).cpu().numpy()
-    monkeypatch.delenv("PLS_HIP_TINY")
+    with handle_with_env(PLS_HIP_TINY=0) as h0:
+        general = h0.cv_folds(Xd, Yd, A, idx).cpu().numpy()
     assert np.abs(got - general).max() < 1e-9 * max(np.abs(ref).max(), 1.0)
 
 
@@ -1097,10 +1094,9 @@ def test_cv_folds_refit_per_fold(handle, oracle, po, monkeypatch, N, K, M, A, ts
     idx = np.arange(N)[:, None] if ts == 1 and nf == N else np.stack([rng.permutation(N)[:ts] for _ in range(nf)])
     Xd, Yd = to_dev(Xh.astype(dtype)), to_dev(Yh.astype(dtype))
     batched = handle.cv_folds(Xd, Yd, A, idx).cpu().numpy()
-    monkeypatch.setenv("PLS_HIP_CV_REFIT", "1")
-    refit = handle.cv_folds(Xd, Yd, A, idx).cpu().numpy()
-    refit_host = handle.cv_folds(np.asfortranarray(Xh.astype(dtype)), np.asfortranarray(Yh.astype(dtype)), A, idx)
-    monkeypatch.delenv("PLS_HIP_CV_REFIT")
+    with handle_with_env(PLS_HIP_CV_REFIT=1) as hr:
+        refit = hr.cv_folds(Xd, Yd, A, idx).cpu().numpy()
+        refit_host = hr.cv_folds(np.asfortranarray(Xh.astype(dtype)), np.asfortranarray(Yh.astype(dtype)), A, idx)
     ref = _fold_reference(oracle, Xh, Yh, A, idx)
     tol = (1e-8 if dt == "f64" else 2e-4) * max(np.abs(ref).max(), 1.0)   # fp32: the refit stores its scores in fp32
     assert np.abs(refit - ref).max() < tol

@@ -72,14 +72,12 @@ PY
   stats c3odd_nipals python3 bench.py --workload C3odd- --steps 3 --warmup 1 --no-alt --no-cpu
   ./pls_amd/csrc/tune/unaligned_probe > $E/unaligned_probe.txt 2>&1 ;;
 narrow)
-  # narrow matrices (taller tiles) and 9-32 responses on many columns, with the previous forms beside them
+  # narrow matrices (taller tiles) and 9-32 responses on many columns (the previous forms, measured in round 3, are deleted)
   for wl in narrow32 tall64a narrow128 narrow256; do for algo in nipals kernel; do
     python3 bench.py --workload $wl --algo $algo --steps 8 --warmup 3 --no-cpu --no-alt > $E/narrow_bench_${wl}_${algo}.json 2> /dev/null
-    PLS_HIP_TALL_TILES=0 python3 bench.py --workload $wl --algo $algo --steps 8 --warmup 3 --no-cpu --no-alt > $E/narrow_bench_${wl}_${algo}_one_tile_shape.json 2> /dev/null
   done; done
   for wl in C4m16 C4m32; do
     python3 bench.py --workload $wl --algo kernel --steps 3 --warmup 2 --no-cpu --no-alt > $E/narrow_bench_${wl}_kernel.json 2> /dev/null
-    PLS_HIP_MID_UPDATE=0 python3 bench.py --workload $wl --algo kernel --steps 3 --warmup 2 --no-cpu --no-alt > $E/narrow_bench_${wl}_kernel_one_workgroup_update.json 2> /dev/null
   done
   python3 - <<'PY'
 import glob, json, os
@@ -99,20 +97,17 @@ wide)
   # beyond 4096 columns (row-pack tiles) and few-rows-many-columns shapes, with the previous forms beside them; z-scores
   for wl in wide8k wide6k64 wide8k64; do for algo in kernel nipals; do
     python3 bench.py --workload $wl --algo $algo --steps 6 --warmup 2 --no-cpu --no-alt > $E/wide512_bench_${wl}_${algo}.json 2> /dev/null
-    PLS_HIP_WIDE512=0 python3 bench.py --workload $wl --algo $algo --steps 6 --warmup 2 --no-cpu --no-alt > $E/wide512_bench_${wl}_${algo}_one_product_kernels.json 2> /dev/null
   done; done
   for wl in wide16k wide12k64; do
     python3 bench.py --workload $wl --algo kernel --steps 6 --warmup 2 --no-cpu --no-alt > $E/wide512_bench_${wl}_kernel.json 2> /dev/null
-    PLS_HIP_WIDE512=0 python3 bench.py --workload $wl --algo kernel --steps 6 --warmup 2 --no-cpu --no-alt > $E/wide512_bench_${wl}_kernel_one_product_kernels.json 2> /dev/null
   done
   for wl in shortwide genes genes4; do for algo in kernel nipals; do
     python3 bench.py --workload $wl --algo $algo --steps 6 --warmup 2 --no-cpu --no-alt > $E/shortwide_bench_${wl}_${algo}.json 2> /dev/null
-    PLS_HIP_XB_SPLIT=0 PLS_HIP_WIDE1_MIN=2000000000 PLS_HIP_WIDEM_UPDATE=0 python3 bench.py --workload $wl --algo $algo --steps 6 --warmup 2 --no-cpu --no-alt > $E/shortwide_bench_${wl}_${algo}_one_workgroup_kernels.json 2> /dev/null
   done; done
   rm -f $E/zscore_time_raw.txt
-  for op in 1 0; do for shape in "1048576 512" "1048576 512 f32" "4000000 64"; do
-    PLS_HIP_ZSCORE_ONE_PASS=$op PLS_HIP_ZS_PIECE=$op python3 tools/zscore_time.py $shape 2> /dev/null >> $E/zscore_time_raw.txt
-  done; done ;;
+  for shape in "1048576 512" "1048576 512 f32" "4000000 64"; do
+    python3 tools/zscore_time.py $shape 2> /dev/null >> $E/zscore_time_raw.txt
+  done ;;
 group)
   # the two in-process exchanges with virtual members (one hardware queue per member), the cross-process exchange with
   # ranks sharing the GPU, config 5 at its own size

@@ -1,6 +1,7 @@
 """Randomised parity sweep beyond the fixed cases of tests/: random shapes, response counts, storage types and plans
-against the CPU oracle on the same inputs.  Not part of the suites (minutes of oracle time); run on an MI355X:
-    python tools/fuzz_parity.py [cases] [seed]"""
+against the CPU oracle on the same inputs.  100 cases with random handle options run in the -m gpu suite
+(tests/test_gpu_fuzz.py); longer sweeps by hand on an MI355X:
+    python tools/fuzz_parity.py [cases] [seed] [options]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, pls_amd
@@ -19,7 +20,7 @@ for case in range(ncases):
     kind = rng.choice(["tiny", "small", "gram", "wide", "cv"] + (["xwide"] * 5 if os.environ.get("FUZZ_XWIDE") else ["xwide"]))
     M = int(rng.choice([1, 1, 2, 3, 4, 8]))
     if kind == "tiny":
-        N = int(rng.integers(1, 1025)); S = 16 // ((N + 63) // 64); K = int(rng.integers(1, max(2, 26 * S + 1))); M = 1
+        N = int(rng.integers(1, 1025)); S = 16 // ((N + 63) // 64); K = int(rng.integers(1, max(2, 26 * S + 1)))  # (single-launch fits: 1..8 responses)
     elif kind == "small":
         N = int(rng.integers(2, 3000)); K = int(rng.integers(1, 300))
     elif kind == "gram":

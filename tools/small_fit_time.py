@@ -18,7 +18,8 @@ for name, fx, fy, A in (("C1_toy", "toyX.csv", "toyY.csv", 2), ("C2_nir", "nir.c
     row = {"N": X.shape[0], "K": X.shape[1], "M": Y.shape[1], "A": A, "cpu_one_core_us": round(best * 1e6, 1)}
     Xd = pls_amd.as_colmajor(torch.from_numpy(X).cuda()); Yd = pls_amd.as_colmajor(torch.from_numpy(Y).cuda())
     for tag, env in (("single_launch", "1"), ("three_launches_per_component", "0")):
-        os.environ["PLS_HIP_TINY"] = env
+        os.environ["PLS_HIP_TINY"] = env  # (read when a handle is created)
+        h = pls_amd.Handle()
         o = h.fit_device(Xd, Yd, A); torch.cuda.synchronize()
         Bref = one.coefficients(ref["R"], ref["Q"])
         err = float(np.abs(o["B"].cpu().numpy() - Bref).max())

@@ -1,5 +1,5 @@
 """X^T Y at config 4's shape (131,072 x 4,096 fp32, M = 8): HIP-event time of the xty family per call.
-PLS_HIP_XTY_KC8 = 4 | 8 | 16 selects the columns per workgroup of the 8-response tile (A/B measurements)."""
+(4 columns per workgroup of the 8-response tile: the 8- and 16-column forms measured in round 2 are deleted)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pls_amd
@@ -15,5 +15,5 @@ for dt in (torch.float32, torch.float64):
     gb = tm['bytes']['xty'] / tm['launches']['xty'] / 1e9
     ref = (X.double().t() @ Y.double())
     err = float((h.xty(X, Y) - ref).norm() / ref.norm())
-    print(f"{str(dt):14s} KC8={os.environ.get('PLS_HIP_XTY_KC8','default')}: {ms:.4f} ms per launch, {gb/ms*1e3:.0f} GB/s = {gb/ms/8:.3f} of peak, rel err {err:.1e}", flush=True)
+    print(f"{str(dt):14s} KC8=4: {ms:.4f} ms per launch, {gb/ms*1e3:.0f} GB/s = {gb/ms/8:.3f} of peak, rel err {err:.1e}", flush=True)
     del X, Y

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time of pls_hip_colwise_z_scores on a resident matrix, out of place:
-   python tools/zscore_time.py [N K [f32]]     (PLS_HIP_ZSCORE_ONE_PASS=0 for the two-pass statistics)
+   python tools/zscore_time.py [N K [f32]]
 Traffic: statistics read X once (one sweep) or twice (two passes); the scale pass reads X and writes Z."""
 import os
 import sys
@@ -40,4 +40,4 @@ for what, z in (("statistics only", None), ("statistics + scale", Z), ("... in p
     ms = (time.perf_counter() - t0) / reps * 1e3
     gb = N * K * X.element_size() / 1e9
     print(f"{what:20s} N={N} K={K} {str(dt)[6:]}: {ms:.3f} ms  ({gb:.2f} GB per sweep of X; "
-          f"one_pass={os.environ.get('PLS_HIP_ZSCORE_ONE_PASS', '1')})")
+          f"one-sweep statistics)")
