@@ -381,13 +381,10 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
 template <typename T>
 __global__ __launch_bounds__(512, 4) void syrk_glds8_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
                                                             const T *__restrict__ zeros, double *__restrict__ part, int so, int sd,
-                                                            const T *__restrict__ Y, i64 ldy, int M, double *__restrict__ xypart,
-                                                            int stagger, int stagger_mode) {
-    // EXPERIMENT: de-phase the two workgroups of a CU (one slab barrier each): half of the workgroups start late
-    {
-        const bool late = stagger_mode == 0 ? (blockIdx.x >= gridDim.x / 2) : (stagger_mode == 1 ? (blockIdx.x & 1) : ((blockIdx.x >> 3) & 1));
-        if (late) for (int q = 0; q < stagger; ++q) __builtin_amdgcn_s_sleep(1);
-    }
+                                                            const T *__restrict__ Y, i64 ldy, int M, double *__restrict__ xypart) {
+    // (Round 4: starting half of the workgroups late -- the second half of the grid, odd ids, or every second group of 8, by
+    // 16 ... 96 x 64 cycles -- so that the two workgroups of a CU do not sit at their slab barriers together: no effect,
+    // 4.91-4.96 ms in all 18 combinations, profiles/r4/syrk_stagger.txt.)
     // 1-D grid, exactly the workgroups that have rows: first so splits of every off-diagonal block, then sd of every diagonal
     // block (workgroups that only exit still take a dispatch slot: a 2-D grid with idle members ran 7.8 ms instead of 6.1).  A
     // diagonal block has fewer partials than the so the reduction sums: its workgroup j also zeroes the slots j + sd, ... < so.
@@ -477,10 +474,8 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_glds8_kernel<T>), (int)LDS_G)) return 1;
         const i64 nwg8 = (i64)(nblocks - nbk) * Sg + (i64)nbk * Sd;
         const bool fuse_y8 = fuse_y0 && Sd * (i64)K * M <= xypart_capacity_doubles;
-        static const int stag = getenv("PLS_HIP_SYRK_STAG") ? atoi(getenv("PLS_HIP_SYRK_STAG")) : 0;        // EXPERIMENT
-        static const int stagm = getenv("PLS_HIP_SYRK_STAGM") ? atoi(getenv("PLS_HIP_SYRK_STAGM")) : 0;     // EXPERIMENT
         hipLaunchKernelGGL(syrk_glds8_kernel<T>, dim3((unsigned)nwg8), dim3(512), LDS_G, stream, X, ldx, N, K, nbk,
-                           static_cast<const T *>(zeros), part, (int)Sg, (int)Sd, fuse_y8 ? Y : nullptr, ldy, M, xypart, stag, stagm);
+                           static_cast<const T *>(zeros), part, (int)Sg, (int)Sd, fuse_y8 ? Y : nullptr, ldy, M, xypart);
         if (fuse_y8) *nb_xy = (int)Sd;
         *nb = (int)Sg;
         return 0;
