@@ -358,6 +358,9 @@ def main():
 
     if line["roofline"] is not None:
         line["roofline"]["measured_over"] = roofline_where
+        if world == 1:  # (the contract: the launch durations come from the timed steps themselves)
+            line["roofline"]["note"] = ("HIP-event brackets around every streaming launch sit INSIDE the timed region at N = 1 "
+                                        "(about 8 us per component): `value` is ~0.5 % below the un-bracketed rate")
     if line["roofline"] is not None and world == 1:  # the PMC summary was taken on the single-GPU shape
         tr, src = pmc_traffic(a.workload, a.algo, a.fuse, line["roofline"]["kernel"])
         line["roofline"]["traffic"] = tr

@@ -142,6 +142,8 @@ __global__ __launch_bounds__(256, 2) void syrk_kernel(const T *__restrict__ X, i
 // (lds_base wave-uniform).  The builtin exists in the device pass only.
 __device__ __forceinline__ void glds16(const void *gsrc, void *lds_base) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // (cache policy of the DMA: default.  nt / sc0 / sc1 measured in round 4: 4.98 / 4.92 / 4.94 ms against 4.92 for the SYRK
+    // launch at config 3 -- no effect, profiles/r4/syrk_sixteen_waves_32_row_slabs.txt)
     __builtin_amdgcn_global_load_lds(gsrc, lds_base, 16, 0, 0);
 #else
     (void)gsrc;

@@ -335,6 +335,7 @@ class Group:
         L.check(self._lib.pls_hip_group_create(ctypes.byref(g), len(devices), devs))
         self.g = g
         self.n = len(devices)
+        self.devices = [int(d) for d in devices]  # member r lives on device self.devices[r]
 
     def _check(self, rc):
         if rc != L.OK:
@@ -420,7 +421,7 @@ class Group:
             pb, ldb, _, _ = self.block(Bm, r)
             if nr == 0:
                 continue
-            out = torch.empty((kb, ka), dtype=torch.float64, device="cuda")  # column-major ka x kb
+            out = torch.empty((kb, ka), dtype=torch.float64, device=f"cuda:{self.devices[r]}")  # column-major ka x kb, on the member's GPU
             L.check(self._lib.pls_hip_xty(h, pa, lda, pb, ldb, nr, ka, kb, L.F64 if self.shape(Am)[2] == np.float64 else L.F32,
                                           out.data_ptr()), h)
             L.check(self._lib.pls_hip_synchronize(h), h)
