@@ -167,11 +167,36 @@ def syrk_roofline(N, K, syrk_ms):
             "nominal_tflops_2NK2_symmetry_counted": round(2.0 * N * K * K / (syrk_ms * 1e-3) / 1e12, 2)}
 
 
+def cpu_share():
+    """host cores this process may really use: the affinity mask, cut by a cgroup CPU quota (the GPU boxes of this pool give a
+    job the share of one GPU -- 16 of 256 hardware threads -- which omp_get_max_threads does not see)"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(N, K, M, A, rows):
     """oracle C restatement (reference operation sequence: 1 + 2A passes over X), 1 core, -O3."""
     from oracle import pls_oracle as po
     rows = min(rows, N)
+    os.environ.setdefault("OMP_PROC_BIND", "close")  # (threads stay where they first touched their row blocks)
+    os.environ.setdefault("OMP_PLACES", "cores")
     gen = po.OracleLib(omp=True)
+    share = cpu_share()
+    gen.set_num_threads(share)
     Xh = gen.synth_x(0, rows, K)
     Yh = gen.synth_y(0, rows, M)
     one = po.OracleLib(omp=False)
@@ -189,7 +214,8 @@ def cpu_baseline(N, K, M, A, rows):
     import glob
     nodes = len(glob.glob("/sys/devices/system/node/node[0-9]*")) or 1
     omp = {"value": round(A / tn * scale, 4), "unit": "components/s", "cores": gen.num_threads(), "kind": "port",
-           "sample": f"same sample, -O3 -march=x86-64-v3 -fopenmp, {gen.num_threads()} OpenMP threads over {nodes} NUMA node(s), "
+           "sample": f"same sample, -O3 -march=x86-64-v3 -fopenmp, {gen.num_threads()} OpenMP threads (the CPU share of this job: "
+                     f"affinity {len(os.sched_getaffinity(0))}, cgroup quota -> {share}) on a host with {nodes} NUMA node(s), "
                      f"every sweep of X partitioned by row blocks and X generated under the same partition (first-touch: the "
                      f"pages of a block live where their reader runs), one fit = {tn:.2f} s"}
     return base, omp

@@ -590,6 +590,15 @@ ORACLE_API void oracle_synth_y(double *Y, i64 ldy, i64 row0, i64 nrows, i64 M, u
     }
 }
 
+/* (the all-core baseline sizes its team to the CPU share of the box: a cgroup quota is invisible to omp_get_max_threads) */
+ORACLE_API void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORACLE_API int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

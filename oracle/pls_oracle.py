@@ -350,6 +350,9 @@ class OracleLib:
     def num_threads(self):
         return self.lib.oracle_num_threads()
 
+    def set_num_threads(self, n):
+        self.lib.oracle_set_num_threads(int(n))
+
 
 def read_csv(path: str) -> np.ndarray:
     """read_matrix_file, src/pls.cpp:37-67: comma separated, no header, one row per line."""

@@ -715,8 +715,10 @@ void launch_tail_rows(hipStream_t stream, const TailArgs<T> &a) {
 // belongs to a destination tile of its own, and stored directly a wave writes 64- or 128-byte runs (2.7 TB/s for the copy
 // into row-pack tiles).  Instead the tile block is transposed through LDS -- [row pack][column] with the column index XORed
 // by the row pack: conflict-free both ways -- and written out in the destination's order, 1 KB per wave-store.
+// (register bounds of ONE workgroup per CU, which is what the launcher starts: config 4 0.80 -> 0.77 ms against the bounds of
+// two; two tiles in flight at 8 columns per lane as well: no difference -- profiles/r4/retile_xty_wgs.txt)
 template <typename T, int V, int R, int NT, int CPTB, int MT, int EDGE = 0, bool LT = false>
-__global__ __launch_bounds__(NT, (NT / 256) * 2) void retile_xty_kernel(const T *src, i64 lds_, const T *__restrict__ Y,
+__global__ __launch_bounds__(NT, NT / 256) void retile_xty_kernel(const T *src, i64 lds_, const T *__restrict__ Y,
                                                                         i64 ldy, T *dst, i64 ldd, i64 tsd, int rdst, i64 N,
                                                                         int K, int M, double *__restrict__ part, int tpw) {
     constexpr int RP = R / V, CG = NT / RP;
