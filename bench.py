@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--defer", type=int, default=1, choices=[1, 2, 3, 4],
                     help="NIPALS plan: write the deflated matrix back every D-th component only (default 1 = explicit "
                          "deflation every component, the headline)")
+    ap.add_argument("--rccl-leg-at-one-rank", action="store_true",
+                    help="rehearsal: run the RCCL leg (alt.rccl) with ONE rank as well -- a 1-rank nccl process group and "
+                         "communicator -- so that its code path can be exercised on a single GPU")
     ap.add_argument("--alt-timeout", type=float, default=90.0, help="N > 1: seconds the RCCL leg (alt.rccl) may take before the "
                     "line is printed without it")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -237,7 +240,7 @@ def rccl_leg(h, a, torch, dist, world, X, Y, A, out, reducer_used):
         if not already:
             if reducer_used.startswith("torch"):
                 h.clear_reducer()
-            attach_rccl_reducer(h)
+            attach_rccl_reducer(h)  # (with one rank: a 1-rank communicator)
         ok, why = 1, ""
     except Exception as e:  # noqa: BLE001
         ok, why = 0, repr(e)
@@ -291,7 +294,10 @@ def main():
     ndev = torch.cuda.device_count()
     local = local if a.backend == "nccl" else local % max(ndev, 1)
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or a.rccl_leg_at_one_rank:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -465,7 +471,7 @@ def main():
             del W
         line["alt"] = alt
 
-    if world > 1 and not a.no_alt:
+    if (world > 1 or a.rccl_leg_at_one_rank) and not a.no_alt:
         # The RCCL leg must never cost the run its line: if it does not finish in time (a communicator that hangs in its
         # set-up on one rank) rank 0 prints the headline as measured and every rank leaves.
         import threading
@@ -476,10 +482,15 @@ def main():
                 print(json.dumps(line), flush=True)
             os._exit(0)
 
-        dog = threading.Timer(a.alt_timeout, give_up)
+        finished = threading.Event()
+        dog = threading.Timer(a.alt_timeout, lambda: None if finished.is_set() else give_up())
         dog.daemon = True
         dog.start()
-        res = rccl_leg(h, a, torch, dist, world, X, Y, A, out, reducer_used)
+        try:
+            res = rccl_leg(h, a, torch, dist, world, X, Y, A, out, reducer_used or "none")
+        except Exception as e:  # noqa: BLE001  (a rank that fails alone leaves the others to the watchdog)
+            res = {"unavailable": "RCCL leg raised " + repr(e)}
+        finished.set()
         dog.cancel()
         line.setdefault("alt", {})["rccl"] = res
 
@@ -493,7 +504,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "components/s", "cores": 1, "kind": "port",
                                         "sample": f"failed: {e!r}"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or a.rccl_leg_at_one_rank:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -432,7 +432,9 @@ __global__ __launch_bounds__(512, 4) void syrk_glds8_kernel(const T *__restrict_
 
 // (Round 4: a 16-wave form with 32-row slabs -- 256-byte DMA pieces, half the barriers, one workgroup per CU -- was built after
 // the PMC reading of this kernel and measured EQUAL, 4.93-4.96 vs 4.94-4.97 ms at config 3: profiles/r4/syrk_sixteen_waves_32_row_slabs.txt.
-// What holds the matrix pipe at 75 % is the 17.2 GB per launch that leave L2, not the barrier count or the piece length.  Deleted.)
+// Nor is it the 17.2 GB per launch that leave L2 (an XCD-grouped grid cut them to 10.5 GB at the same launch time): on the CUs that
+// set the launch time the MFMA / ds_read loop alone runs at 0.857 of the pipe, DMA issue + slab barrier cost another 12 % --
+// profiles/r4/syrk_where_the_time_goes.txt.  Deleted.)
 
 // rc: 0 launched (part holds *nb partial K x K matrices), 1 shape not covered
 // zeros: >= 16 bytes of device zeros (source of the rows beyond N in the LDS-DMA variant); nullptr = register-staged kernel

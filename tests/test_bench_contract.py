@@ -104,3 +104,19 @@ def test_bench_two_ranks_over_the_device_side_exchange():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["reducer"] == "ipc" and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_rccl_leg_code_path_at_one_rank():
+    """The RCCL leg of an N > 1 line (alt.rccl) can not run with two ranks on one GPU; its code path -- nccl process group,
+    the library's own communicator attached behind the headline, ncclCommCount, three timed fits -- is exercised here with ONE
+    rank: the leg must report RCCL's rank count and a rate."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "tiny",
+                        "--no-cpu", "--rccl-leg-at-one-rank"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rl = json.loads(lines[0])["alt"]["rccl"]
+    assert rl.get("nranks_reported_by_rccl") == 1 and rl["components_per_s"] > 0, rl
