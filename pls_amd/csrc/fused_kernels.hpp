@@ -304,7 +304,7 @@ struct TileWalk<true, R> {
 // in the headline kernel, 0.29 GB of scratch stores per launch at config 3 (profiles/r3/pmc_traffic_C3_nipals_fused.txt).
 template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX_ = AUX_NT, int STAUX = AUX_NT, bool RDST = false,
           int EDGE = 0, bool TILED = false>
-__global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !(DEFL && TILED)) ? 2 : 1)) void fused_pass_kernel(
+__global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) void fused_pass_kernel(
     const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd, i64 N, int K,  // dst may alias X (in-place deflation)
     const double *__restrict__ v, const T *__restrict__ tprev, const double *__restrict__ pprev,
     T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart, int rdst, i64 NV, const SliceTail st) {
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !(DEFL && TILED)) ?
         }
         // the deflated tile goes out BEFORE the score arithmetic (left to itself the compiler sinks the stores behind the
         // score FMAs and the first butterfly level: 1.387 instead of 1.354 ms per launch at config 3)
-        if constexpr (TILED && DEFL) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DEFL) __builtin_amdgcn_sched_barrier(0);
         // score: partial over this lane's columns, then over the lanes / waves sharing the rows
         double tp2[V];
 #pragma unroll
