@@ -72,6 +72,10 @@ def parse():
                     help="nipals: north-star sequence with the rank-1 deflation of X (headline); "
                          "kernel: the reference's own sequence, X read-only")
     ap.add_argument("--fuse", type=int, default=1)
+    ap.add_argument("--profile-after", action="store_true",
+                    help="N = 1: time the steps WITHOUT the HIP-event brackets around every streaming launch (as every N > 1 "
+                         "run does) and take the roofline from extra profiled steps afterwards; default: brackets in the "
+                         "timed region itself")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (gloo: rehearsal with ranks sharing one GPU)")
     ap.add_argument("--reducer", default=None, choices=["torch", "rccl", "ipc"],
@@ -355,7 +359,8 @@ def main():
     # timed steps themselves; the brackets cost ~8 us per component (0.5 % of a single-GPU component, but 4 % of a
     # 1/8-size one), so at N > 1 the timed steps run without them and the roofline comes from extra profiled steps
     # after the timed region.
-    h.set_option(pls_amd.OPT_PROFILE, 1 if world == 1 else 0)
+    after = world > 1 or a.profile_after
+    h.set_option(pls_amd.OPT_PROFILE, 0 if after else 1)
     out = None
     if a.workload in TIGHT_LD:  # the scores in the reference's layout as well (T is N x A with ld = N)
         f64 = torch.float64
@@ -368,10 +373,10 @@ def main():
 
     el, tm = timed_fits(h, torch, dist, world, X, Y, A, a.steps, a.warmup, out)
     roofline_where = "timed steps"
-    if world > 1:
+    if after:
         h.set_option(pls_amd.OPT_PROFILE, 1)
         _, tm = timed_fits(h, torch, dist, world, X, Y, A, min(a.steps, 3), 1, out)
-        roofline_where = "separate profiled steps after the timed region (N > 1)"
+        roofline_where = "separate profiled steps after the timed region (N > 1, or --profile-after)"
     h.synchronize()  # (raises if the ranks of a sharded fit diverged or the exchange timed out: include/pls_hip.h)
     value = A * a.steps / el
     es = 8 if dt == "f64" else 4
