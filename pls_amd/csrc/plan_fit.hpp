@@ -118,8 +118,12 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // (retile_xty) and every component runs fused on it -- instead of 4 N K s (NIPALS) / 2 N K s (KERNEL) per component
     // through the one-product kernels.
     // (read-only passes take 32 columns per lane there: the KERNEL plan up to 16384 columns)
+    // (every precondition of launch_retile_xty for this shape is decided HERE, so that a fit which counts on the copy --
+    // wide_only -- cannot find it refused later: the source layout (wide_source_ok), element-aligned responses, M <= 8
+    // (wide_only below); the launcher's span limits hold for every row-pack tile -- 16 V K s + 512 bytes < 2^31 at K <= 16384
+    // -- and the partial-row capacity is never below 2)
     const bool wide_src = c->opt_fuse && !fused_fit && N > 0 && K <= 512 * (nipals ? 16 : 32) &&
-                          plsk::wide_source_ok<T>(X, ldx, N, Tm);
+                          plsk::wide_source_ok<T>(X, ldx, N, Tm) && plsk::elem_aligned<T>(Y);
     const bool wide_only = nipals && wide_src && K > 256 * 16 && K <= 512 * 16 && M <= 8 && A >= 3 && c->opt_work_layout != 0;
     const bool tiled_work = nipals && (fused_fit || semi_fit || wide_only) && c->opt_work_layout != 0;
     // Row-tile-major tiles are contiguous whatever their height, so for 1024 < K <= 4096 the working copy uses
