@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256, 2) void syrk_kernel(const T *__restrict__ X, i
     // No software prefetch: the 64 staging registers would not fit beside the 128 accumulator
     // registers without spilling (measured: 6.8 ms with prefetch + spills, 6.5 ms without); the
     // second workgroup on the CU covers the load phase instead.
-    for (i64 s = blockIdx.y; s < nslabs; s += gridDim.y) {
+    // (a contiguous range of slabs per row split, as in the LDS-DMA kernel below: syrk8_slab_range)
+    const i64 per_split = (nslabs + gridDim.y - 1) / gridDim.y;
+    const i64 s_end = min(nslabs, (i64)(blockIdx.y + 1) * per_split);
+    for (i64 s = (i64)blockIdx.y * per_split; s < s_end; ++s) {
         load_slab(s);
         __syncthreads();  // everyone is done reading the previous slab
         store_slab();
@@ -175,6 +178,19 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_base) {
 //   diagonal blocks: the 36 tiles (16 x 16) on or above the diagonal of the 8 x 8 tile grid dealt out to the 8 waves in
 //   enumeration order (5 or 4 each -- 5/8 of a full block's time per slab), every tile with its own two operand reads;
 //   X^T Y rides along as before (thread = (column, quarter of the slab's rows)).
+// The slabs of row split `split` of `nsplit`: a CONTIGUOUS range [first, end).  With every nsplit-th slab instead, all workgroups
+// in flight read within nsplit consecutive slabs of each other -- at config 3 a 10 KB window of each of the 512 columns, the
+// columns 8 MiB apart: the same few HBM channels for the whole chip.  Contiguous ranges put the row splits N / nsplit rows
+// apart: 3.6 -> 4.06 TB/s of panel reads, 0.734 -> 0.826 of the matrix pipe in the stand-alone form of this kernel
+// (pls_amd/csrc/tune/syrk_stream_probe.hip, profiles/r4/syrk_stream_probe.txt) -- the same as padding the columns' stride
+// away from a power of two does.
+__device__ __forceinline__ void syrk8_slab_range(i64 N, int RB, i64 split, int nsplit, i64 &first, i64 &end) {
+    const i64 nall = (N + RB - 1) / RB;
+    const i64 per = (nall + nsplit - 1) / nsplit;
+    first = split * per;
+    end = min(nall, first + per);
+}
+
 template <typename T>
 __device__ __forceinline__ void syrk8_dma(T *lds, int buf, const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, int bj, bool diag,
                                           i64 s, const T *__restrict__ zeros, int wv, int scol, int spos) {
@@ -212,14 +228,14 @@ __device__ __forceinline__ void syrk8_full_body(const T *__restrict__ X, i64 ldx
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const i64 nslabs = (N + RB - 1) / RB;
-    i64 s = s0;
+    i64 s, nslabs;
+    syrk8_slab_range(N, RB, s0, nsplit, s, nslabs);
     int buf = 0;
     if (s < nslabs) syrk8_dma<T>(lds, 0, X, ldx, N, K, bi, bj, false, s, zeros, wv, scol, spos);
-    for (; s < nslabs; s += nsplit, buf ^= 1) {
+    for (; s < nslabs; ++s, buf ^= 1) {
         __syncthreads();
         const T *As = lds + (size_t)buf * 2 * PANEL, *Bs = As + PANEL;
-        if (s + nsplit < nslabs) syrk8_dma<T>(lds, buf ^ 1, X, ldx, N, K, bi, bj, false, s + nsplit, zeros, wv, scol, spos);
+        if (s + 1 < nslabs) syrk8_dma<T>(lds, buf ^ 1, X, ldx, N, K, bi, bj, false, s + 1, zeros, wv, scol, spos);
 #pragma unroll
         for (int kk = 0; kk < RB; kk += 4) {
             const int r = kk + lq;
@@ -299,7 +315,8 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
     for (int m = 0; m < 8; ++m) accy[m] = 0.0;
     const int yc = tid >> 2, yh = tid & 3;  // X^T Y: column of the panel, quarter of the slab's 8 row positions
     const int ykey = (yc >> 1) & 7;
-    const i64 nslabs = (N + RB - 1) / RB;
+    i64 s, nslabs;
+    syrk8_slab_range(N, RB, s0, nsplit, s, nslabs);
     auto issue = [&](i64 s, int buf) {
         syrk8_dma<T>(lds, buf, X, ldx, N, K, bi, bi, true, s, zeros, wv, scol, spos);
         if constexpr (WITH_Y) {
@@ -311,13 +328,12 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
             }
         }
     };
-    i64 s = s0;
     int buf = 0;
     if (s < nslabs) issue(s, 0);
-    for (; s < nslabs; s += nsplit, buf ^= 1) {
+    for (; s < nslabs; ++s, buf ^= 1) {
         __syncthreads();
         const T *As = lds + (size_t)buf * 2 * PANEL;
-        if (s + nsplit < nslabs) issue(s + nsplit, buf ^ 1);
+        if (s + 1 < nslabs) issue(s + 1, buf ^ 1);
 #pragma unroll
         for (int kk = 0; kk < RB; kk += 4) {
             const int r = kk + lq;
