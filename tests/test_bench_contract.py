@@ -120,3 +120,22 @@ def test_bench_rccl_leg_code_path_at_one_rank():
     assert len(lines) == 1, r.stdout[-2000:]
     rl = json.loads(lines[0])["alt"]["rccl"]
     assert rl.get("nranks_reported_by_rccl") == 1 and rl["components_per_s"] > 0, rl
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_when_the_exchange_fails_in_the_fits():
+    """A reducer that passed its set-up can still fail in the fits (the device-side exchange has never crossed a real xGMI
+    link in this pipeline).  Fault injection: rank 1 never delivers its first partial sums, every rank's wait ends at the
+    time limit and the fits come back poisoned -- the ranks must agree on that, drop the exchange, take the torch reducer,
+    measure again and still print the one line, which names what happened."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", PLS_HIP_XCHG_TIMEOUT_S="1.5", PLS_HIP_TEST_DROP_PUSH="1:2")  # (collective 1 is the self-test)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "tiny", "--backend", "gloo", "--reducer", "ipc", "--no-alt"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["reducer"].startswith("torch (the ipc reducer failed in the fits"), d["config"]["reducer"]
