@@ -59,7 +59,13 @@ WORKLOADS.update({
     "wide8k1": (65536, 8192, 1, 20, "f32"), "wide8k2": (65536, 8192, 2, 20, "f32"),
     "wide8k": (65536, 8192, 8, 30, "f32"), "wide6k64": (87381, 6144, 1, 20, "f64"), "wide8k64": (65536, 8192, 2, 20, "f64"),
 })
+WORKLOADS.update({
+    # config 3 with 8 components (fewer than the copy into tiles pays for: the KERNEL plan reads the caller's matrix every
+    # component), and the same with the columns NOT a power of two apart (ld = N + 64: 8 MiB + 512 bytes)
+    "C3a8": (1 << 20, 512, 1, 8, "f64"), "C3a8pad": (1 << 20, 512, 1, 8, "f64"), "C3pad": (1 << 20, 512, 1, 20, "f64"),
+})
 TIGHT_LD = {"C3odd-", "C3odd+", "C4odd"}  # leading dimension = N (no padding to 16 bytes)
+PAD_LD = {"C3a8pad": 64, "C3pad": 64}      # leading dimension = N + this many elements
 
 
 def parse():
@@ -316,6 +322,8 @@ def main():
     if a.workload in TIGHT_LD:  # the reference's own layout: Eigen matrices have ld = rows
         Xt = pls_amd.colmajor_empty(nrows, K, tdt, X.device, ld=nrows); Xt.copy_(X); X = Xt
         Yt = pls_amd.colmajor_empty(nrows, M, tdt, Y.device, ld=nrows); Yt.copy_(Y); Y = Yt
+    if a.workload in PAD_LD:
+        Xt = pls_amd.colmajor_empty(nrows, K, tdt, X.device, ld=nrows + PAD_LD[a.workload]); Xt.copy_(X); X = Xt
     reducer_used = None
     if world > 1:
         reducer_used = a.reducer
