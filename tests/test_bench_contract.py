@@ -51,6 +51,18 @@ def test_bench_prints_one_contract_line():
 
 
 @pytest.mark.gpu
+def test_bench_profile_after_times_the_fits_without_event_brackets():
+    """--profile-after: the timed steps carry no HIP-event brackets (as every N > 1 run), the roofline comes from extra
+    profiled steps; the line says where it was measured."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--workload", "tiny",
+                        "--no-cpu", "--no-alt", "--profile-after"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert d["value"] > 0 and d["roofline"]["measured_over"].startswith("separate profiled steps")
+    assert d["roofline"]["avg_launch_ms"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_as_the_driver_launches_it():
     """The driver's N > 1 launch line (torch.distributed.run, one process per rank) with the gloo rehearsal backend
     and both ranks on the one GPU of the test box: rank 0 prints exactly one line with n_gpus = 2."""
