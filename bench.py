@@ -55,6 +55,7 @@ WORKLOADS.update({
     "wide16k": (32768, 16384, 8, 30, "f32"), "wide12k64": (43690, 12288, 1, 20, "f64"),  # (KERNEL plan: 32 columns per lane)
     "C3m4": (1 << 20, 512, 4, 20, "f64"),  # config 3 with four responses (SYRK with X^T Y of several responses on board)
     "mid1": (1000, 4000, 1, 10, "f64"), "mid2": (2000, 2000, 1, 10, "f64"), "mid3": (500, 10000, 1, 10, "f64"),  # 32-40 MB: launch-bound
+    "mid4": (500, 6000, 1, 10, "f64"), "mid5": (1500, 10000, 1, 10, "f64"), "mid6": (3000, 12000, 1, 10, "f64"), "mid7": (6000, 10000, 1, 10, "f64"),
     "abc": (100000, 40, 12, 40, "f64"),  # few predictors, a dozen responses, every component (the reference author's own use)
     "wide8k1": (65536, 8192, 1, 20, "f32"), "wide8k2": (65536, 8192, 2, 20, "f32"),
     "wide8k": (65536, 8192, 8, 30, "f32"), "wide6k64": (87381, 6144, 1, 20, "f64"), "wide8k64": (65536, 8192, 2, 20, "f64"),

@@ -122,7 +122,10 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // wide_only -- cannot find it refused later: the source layout (wide_source_ok), element-aligned responses, M <= 8
     // (wide_only below); the launcher's span limits hold for every row-pack tile -- 16 V K s + 512 bytes < 2^31 at K <= 16384
     // -- and the partial-row capacity is never below 2)
-    const bool wide_src = c->opt_fuse && !fused_fit && N > 0 && K <= 512 * (nipals ? 16 : 32) &&
+    // (beyond 8192 columns -- 32 columns per lane, a partial row of K doubles per workgroup -- only from 4096 rows on: on a shorter
+    // matrix the partial rows weigh as much as the matrix and the one-product kernels win, 500 x 10,000: 0.47 against 0.83 ms per
+    // fit, 1,500 x 10,000: 0.70 / 0.89, 3,000 x 12,000: 1.22 / 1.30; 6,000 x 10,000: 1.91 / 1.59 -- profiles/r4/short_wide_plan_choice.txt)
+    const bool wide_src = c->opt_fuse && !fused_fit && N > 0 && K <= 512 * (nipals ? 16 : 32) && (K <= 512 * 16 || N >= 4096) &&
                           plsk::wide_source_ok<T>(X, ldx, N, Tm) && plsk::elem_aligned<T>(Y);
     const bool wide_only = nipals && wide_src && K > 256 * 16 && K <= 512 * 16 && M <= 8 && A >= 3 && c->opt_work_layout != 0;
     const bool tiled_work = nipals && (fused_fit || semi_fit || wide_only) && c->opt_work_layout != 0;

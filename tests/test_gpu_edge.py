@@ -53,7 +53,8 @@ SHAPES = [
     (131, 8192, 2, 5, "f64", 0, 1),     # ... the widest they take, unaligned source
     (263, 6000, 8, 4, "f32", 0, 0),
     (130, 4100, 3, 3, "f32", 1, 2),
-    (75, 9000, 1, 4, "f64", 0, 0),      # 8192 < K <= 16384: the KERNEL plan still fuses (32 columns per lane, read-only)
+    (75, 9000, 1, 4, "f64", 0, 0),      # 8192 < K <= 16384 on a short matrix: the one-product kernels
+    (4099, 8200, 1, 3, "f64", 0, 0),    # ... and from 4096 rows on the KERNEL plan still fuses (32 columns per lane, read-only)
     (67, 16384, 2, 3, "f32", 0, 1),
     (41, 17000, 1, 3, "f64", 0, 0),     # beyond every resident tile: the one-product kernels
     (512, 20000, 1, 3, "f64", 0, 0),    # ... short and wide: the score kernel splits the columns as well as the rows
@@ -161,7 +162,9 @@ def test_edge_shapes_take_the_one_sweep_plan(handle, oracle, po, plan, monkeypat
     elif K <= 8192:
         # row-pack tiles: the same plan (one copy in the X^T Y sweep + A fused passes)
         assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
-    elif K <= 16384 and not nipals:
+    elif K <= 16384 and not nipals and N >= 4096:
+        # 32 columns per lane, read-only: from 4096 rows on (on a shorter matrix the partial rows of K doubles per workgroup
+        # weigh as much as the matrix, and the one-product kernels are the faster plan)
         assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
     else:
         assert tm["launches"]["fused"] == 0, tm["launches"]

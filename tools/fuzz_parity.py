@@ -29,6 +29,7 @@ for case in range(ncases):
         N = int(rng.integers(64, 4000)); K = int(rng.integers(1025, 5000))
     elif kind == "xwide":  # row-pack tiles (K <= 8192 / 16384), the split score kernel and the many-workgroup update beyond
         N = int(rng.integers(8, 1500)); K = int(rng.choice([rng.integers(4097, 8193), rng.integers(8193, 16385), rng.integers(16385, 40000)]))
+        if 8192 < K <= 16384 and rng.integers(0, 2) == 0: N = int(rng.integers(4096, 5000))  # (the KERNEL plan fuses there from 4096 rows on)
     else:
         N = int(rng.integers(5, 400)); K = int(rng.integers(1, 120))
     A = int(rng.integers(1, min(K, 12) + 1))
