@@ -89,6 +89,66 @@ __global__ __launch_bounds__(UPD_THREADS) void lm_eig_lds_kernel(const double *_
     if ((int)threadIdx.x < M) qe[threadIdx.x] = qs[threadIdx.x];
 }
 
+// 33 .. LM_LDS_MAX (48) responses: the same solve in ONE launch with B and C in (dynamic) LDS and G read from global memory -- every
+// thread owns the entries e = tid, tid + 1024, ... of the M x M matrices; repeated squaring to the fixed point (uniform early
+// exit), two polishing steps, sign convention: dominant_eigvec_lds with loops.  Replaces 2 + 3 x power_iters + 1 launches
+// (~150 at the default 48 squarings, none of which can stop early: the host does not see the fixed point) -- 40 responses:
+// 0.46 -> 0.1 ms per component (profiles/r4/many_responses_scan.txt).
+constexpr int LM_LDS_MAX = 48;  // (one CU squares M x M matrices: 33 -> 1.4, 40 -> 1.5, 64 -> 3.5-5.0, 88 -> 11 ms per 8-component fit against ~4.5-6 for the launches)
+__global__ __launch_bounds__(UPD_THREADS) void lm_eig_lds_big_kernel(const double *__restrict__ G, int M, int iters,
+                                                                     double *__restrict__ qe) {
+    extern __shared__ double lm_dyn[];  // Bm [M*M], Cm [M*M], qv [M]
+    double *Bm = lm_dyn, *Cm = lm_dyn + M * M, *qv = Cm + M * M;
+    const int tid = threadIdx.x, MM = M * M;
+    double tr = 0.0;
+    for (int c = 0; c < M; ++c) tr += G[c + c * M];
+    for (int e = tid; e < MM; e += UPD_THREADS) Bm[e] = G[e] / tr;
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        for (int e = tid; e < MM; e += UPD_THREADS) {
+            const int a = e % M, b = e / M;
+            double s = 0.0;
+            for (int c = 0; c < M; ++c) s = fma(Bm[a + c * M], Bm[c + b * M], s);
+            Cm[e] = s;
+        }
+        __syncthreads();
+        double t2 = 0.0;
+        for (int c = 0; c < M; ++c) t2 += Cm[c + c * M];
+        int same = 1;
+        for (int e = tid; e < MM; e += UPD_THREADS) {
+            const double nb = Cm[e] / t2, ob = Bm[e];
+            same &= fabs(nb - ob) <= 4.0e-16 * fabs(nb) + 1.0e-18;  // (see dominant_eigvec_lds)
+            Bm[e] = nb;
+        }
+        if (__syncthreads_and(same)) break;  // uniform exit; also the barrier that publishes Bm
+    }
+    int best = 0;
+    double bd = Bm[0];
+    for (int c = 1; c < M; ++c)
+        if (Bm[c + c * M] > bd) { bd = Bm[c + c * M]; best = c; }
+    if (tid < M) qv[tid] = Bm[tid + best * M];
+    __syncthreads();
+    for (int pol = 0; pol < 2; ++pol) {
+        double s = 0.0;
+        if (tid < M)
+            for (int c = 0; c < M; ++c) s = fma(G[tid + c * M], qv[c], s);
+        __syncthreads();
+        if (tid < M) qv[tid] = s;
+        __syncthreads();
+        double n2 = 0.0;
+        for (int c = 0; c < M; ++c) n2 = fma(qv[c], qv[c], n2);
+        const double inv = 1.0 / sqrt(n2);
+        __syncthreads();
+        if (tid < M) qv[tid] = s * inv;
+        __syncthreads();
+    }
+    int big = 0;
+    for (int c = 1; c < M; ++c)
+        if (fabs(qv[c]) > fabs(qv[big])) big = c;
+    const double sgn = (qv[big] < 0.0) ? -1.0 : 1.0;
+    if (tid < M) qe[tid] = qv[tid] * sgn;
+}
+
 // From Bm ~ v1 v1^T: the column with the largest diagonal entry, two power steps on G, unit norm, largest-|.| entry
 // positive (lowest index on ties) -> qe.   One workgroup of UPD_THREADS; M <= LM_MAX (qe staged in LDS).
 __global__ __launch_bounds__(UPD_THREADS) void lm_eig_finish_kernel(const double *__restrict__ G, const double *__restrict__ Bm,

@@ -47,6 +47,12 @@ int launch_update_large(pls_hip_context *c, const double *red, double *XY, doubl
         hipLaunchKernelGGL(plsk::lm_eig_lds_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream, (const double *)G, M,
                            (int)c->opt_power_iters, qe);
         LAUNCH_CHECK(c);
+    } else if (M <= plsk::LM_LDS_MAX &&
+               plsk::raise_dynamic_lds(reinterpret_cast<const void *>(&plsk::lm_eig_lds_big_kernel), (2 * M * M + M) * 8)) {
+        // up to 48 responses: still one launch, B and C in LDS (the fixed point ends the squarings; beyond, one CU is too slow)
+        hipLaunchKernelGGL(plsk::lm_eig_lds_big_kernel, dim3(1), dim3(plsk::UPD_THREADS), (size_t)(2 * M * M + M) * 8, c->stream,
+                           (const double *)G, M, (int)c->opt_power_iters, qe);
+        LAUNCH_CHECK(c);
     } else {
         // dominant eigenvector: B_0 = G / tr G, B_{j+1} = B_j^2 / tr(B_j^2)
         const dim3 sq((M + 15) / 16, (M + 15) / 16), sqb(16, 16);
