@@ -44,10 +44,20 @@ __global__ __launch_bounds__(WG) void lm_deflate_kernel(const double *__restrict
     XY[idx] -= (P[k + (i64)a * K] * qv[m]) * tt;
 }
 
-// C = A * A for a symmetric M x M matrix, 16 x 16 tiles through LDS.   grid = (ceil(M/16), ceil(M/16)), block = (16, 16)
-__global__ __launch_bounds__(256) void lm_square_kernel(const double *__restrict__ Am, int M, double *__restrict__ Cm) {
-    __shared__ double ta[16][17], tb[16][17];
-    const int tx = threadIdx.x, ty = threadIdx.y;
+// (16 x 16 tiles through LDS; grid = (ceil(M/16), ceil(M/16)), block = (16, 16))
+// C = (A / tr A)^2 in ONE launch: every workgroup forms the trace itself (fixed order: 256 strided sums, wave sums, waves in
+// order -- the same bits in every workgroup), then its 16 x 16 tile of A * A, scaled by 1 / tr^2.  One launch per squaring of the
+// direction solve instead of three (square, trace, scale): beyond LM_LDS_MAX responses the solve is launch-bound.
+__global__ __launch_bounds__(256) void lm_square_normalised_kernel(const double *__restrict__ Am, int M, double *__restrict__ Cm) {
+    __shared__ double ta[16][17], tb[16][17], sm[4];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 16 + tx;
+    double t = 0.0;
+    for (int i = tid; i < M; i += 256) t += Am[i + (i64)i * M];
+    t = wave_sum(t);
+    if ((tid & 63) == 0) sm[tid >> 6] = t;
+    __syncthreads();
+    const double tr = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+    const double sc = 1.0 / (tr * tr);
     const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
     double s = 0.0;
     for (int k0 = 0; k0 < M; k0 += 16) {
@@ -58,23 +68,7 @@ __global__ __launch_bounds__(256) void lm_square_kernel(const double *__restrict
         for (int kk = 0; kk < 16; ++kk) s = fma(ta[ty][kk], tb[kk][tx], s);
         __syncthreads();
     }
-    if (row < M && col < M) Cm[row + (i64)col * M] = s;
-}
-
-// tr[0] = trace(Am)   (one workgroup, fixed order)
-__global__ __launch_bounds__(WG) void lm_trace_kernel(const double *__restrict__ Am, int M, double *__restrict__ tr) {
-    __shared__ double sm[WG / WAVE];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < M; i += WG) s += Am[i + (i64)i * M];
-    s = block_sum<WG / WAVE>(s, sm);
-    if (threadIdx.x == 0) tr[0] = s;
-}
-
-// out = in / tr[0]
-__global__ __launch_bounds__(WG) void lm_scale_kernel(const double *__restrict__ in, const double *__restrict__ tr, i64 n,
-                                                      double *__restrict__ out) {
-    const i64 i = (i64)blockIdx.x * WG + threadIdx.x;
-    if (i < n) out[i] = in[i] / tr[0];
+    if (row < M && col < M) Cm[row + (i64)col * M] = s * sc;
 }
 
 // The dominant eigenvector of G (M x M, M <= MMAX = 32) in ONE launch, in LDS: the solver of component_update_body

@@ -54,19 +54,21 @@ int launch_update_large(pls_hip_context *c, const double *red, double *XY, doubl
                            (const double *)G, M, (int)c->opt_power_iters, qe);
         LAUNCH_CHECK(c);
     } else {
-        // dominant eigenvector: B_0 = G / tr G, B_{j+1} = B_j^2 / tr(B_j^2)
+        // dominant eigenvector by repeated squaring, X_0 = G, X_{j+1} = (X_j / tr X_j)^2 -> a multiple of v1 v1^T: one launch
+        // per squaring (the trace is formed inside; the finish kernel takes any scale).  The host cannot see the fixed point,
+        // so all power_iters squarings run.
         const dim3 sq((M + 15) / 16, (M + 15) / 16), sqb(16, 16);
-        const unsigned nmm = (unsigned)((MM + plsk::WG - 1) / plsk::WG);
-        hipLaunchKernelGGL(plsk::lm_trace_kernel, dim3(1), blk, 0, c->stream, (const double *)G, M, tr);
-        hipLaunchKernelGGL(plsk::lm_scale_kernel, dim3(nmm), blk, 0, c->stream, (const double *)G, (const double *)tr, MM, Bm);
-        for (int it = 0; it < (int)c->opt_power_iters; ++it) {
-            hipLaunchKernelGGL(plsk::lm_square_kernel, sq, sqb, 0, c->stream, (const double *)Bm, M, Cm);
-            hipLaunchKernelGGL(plsk::lm_trace_kernel, dim3(1), blk, 0, c->stream, (const double *)Cm, M, tr);
-            hipLaunchKernelGGL(plsk::lm_scale_kernel, dim3(nmm), blk, 0, c->stream, (const double *)Cm, (const double *)tr, MM, Bm);
+        const double *src = G;
+        double *dst = Bm;
+        for (int it = 0; it < std::max(1, (int)c->opt_power_iters); ++it) {
+            hipLaunchKernelGGL(plsk::lm_square_normalised_kernel, sq, sqb, 0, c->stream, src, M, dst);
+            src = dst;
+            dst = (dst == Bm) ? Cm : Bm;
         }
         LAUNCH_CHECK(c);
+        const double *Bfin = src;
         hipLaunchKernelGGL(plsk::lm_eig_finish_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream, (const double *)G,
-                           (const double *)Bm, M, qe);
+                           Bfin, M, qe);
         LAUNCH_CHECK(c);
     }
     hipLaunchKernelGGL(plsk::lm_w_kernel, dim3(nparts), blk, 0, c->stream, (const double *)XY, (const double *)qe, K, M, wraw, ssp);

@@ -8,7 +8,7 @@ one = po.OracleLib(omp=True)
 h = pls_amd.Handle()
 lines = []
 for (N, K) in ((20000, 256), (2000, 2000), (200000, 64), (500, 6000)):
-    for M in (2, 8, 16, 40, 100, 300):
+    for M in (16, 40, 49, 64, 100, 300, 600):
         A = 8
         X = one.synth_x(3, N, K); Y = one.synth_y(3, N, M)
         Xd = pls_amd.as_colmajor(torch.from_numpy(X).cuda()); Yd = pls_amd.as_colmajor(torch.from_numpy(Y).cuda())
