@@ -65,7 +65,13 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
     if (wide && N / ((i64)FV * plsk::WG) < 4 * (i64)c->num_cu) wide = false;
     // One score column of a short, wide matrix: the rows alone give fewer workgroups than there are CUs -- split the
     // columns as well (xb_split_kernel); ~3 workgroups per CU, at least 128 columns each.
-    if (N > 0 && K >= 1024) {
+    // (not when the matrix-core kernel below takes the columns in one pass -- more than 8 with fp32 storage, more than 32 with
+    // fp64 -- and has a workgroup for at least half the CUs: 32 columns on 131,072 x 4,096 fp32 were eight sweeps of this path,
+    // 2.6 instead of 0.75 ms -- profiles/r4/products_scan.txt)
+    const i64 rows_per_wg_many = (i64)(plsk::WG / plsk::WAVE) * 16 * FV;
+    const bool many = C > (sizeof(T) == 4 ? 8 : 32) && vec_ok<T>(X, ldx, FV) &&
+                      (N + rows_per_wg_many - 1) / rows_per_wg_many >= c->num_cu / 2;
+    if (N > 0 && K >= 1024 && !many) {
         const bool v2 = vec_ok<T>(X, ldx, FV) && (N + (i64)FV * plsk::WG - 1) / ((i64)FV * plsk::WG) >= 8;
         const i64 per = (i64)plsk::WG * (v2 ? FV : 1);
         const i64 rg = (N + per - 1) / per;
@@ -107,6 +113,24 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
         const double *b = Bm + (i64)c0 * ldb;
         T *o = out + (i64)c0 * ldo;
         const int cap = wide ? (FV == 2 ? 32 : 8) : 32;  // fp32 x 4 rows per lane: 8 columns = 32 fp64 accumulators
+        if (sizeof(T) == 8 && rem > 32 && vec_ok<T>(X, ldx, FV)) {
+            // fp64 storage beyond the 32 columns a pass of the LDS-staged VALU kernel holds: up to 64 per pass on the matrix
+            // cores with Bm in LDS (1,048,576 x 512, 64 columns: one pass instead of two of 1.27 ms)
+            if constexpr (sizeof(T) == 8) {
+                const int use = std::min(rem, 64);
+                const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
+                Scope s(c, PLS_HIP_FAM_XB, bytes);
+                const i64 per = (i64)(plsk::WG / plsk::WAVE) * 16 * FV;  // rows per workgroup
+                const dim3 grid((unsigned)((N + per - 1) / per)), blk(plsk::WG);
+                if (use > 48)
+                    hipLaunchKernelGGL((plsk::xb_mfma_lds_kernel<T, FV, 4>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo);
+                else
+                    hipLaunchKernelGGL((plsk::xb_mfma_lds_kernel<T, FV, 3>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo);
+                LAUNCH_CHECK(c);
+                c0 += use;
+                continue;
+            }
+        }
         if (sizeof(T) == 4 && rem > 8 && vec_ok<T>(X, ldx, FV)) {
             // fp32 storage, many columns: up to 32 per pass on the matrix cores (xb_mfma_kernel) -- the LDS-staged
             // VALU kernel below holds only 8 columns of fp64 accumulators per pass at 4 rows per lane.  (For fp64
@@ -117,9 +141,9 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
             const i64 per = (i64)(plsk::WG / plsk::WAVE) * 16 * FV;  // rows per workgroup
             const dim3 grid((unsigned)((N + per - 1) / per)), blk(plsk::WG);
             if (use > 16)
-                hipLaunchKernelGGL((plsk::xb_mfma_kernel<T, FV, 2>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo);
+                hipLaunchKernelGGL((plsk::xb_mfma_lds_kernel<T, FV, 2>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo);
             else
-                hipLaunchKernelGGL((plsk::xb_mfma_kernel<T, FV, 1>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo);
+                hipLaunchKernelGGL((plsk::xb_mfma_lds_kernel<T, FV, 1>), grid, blk, 0, c->stream, X, ldx, N, K, b, ldb, use, o, ldo);
             LAUNCH_CHECK(c);
             c0 += use;
             continue;

@@ -215,80 +215,84 @@ __global__ __launch_bounds__(WG) void xb_split_finish_kernel(const double *__res
 // the A operand comes straight from global memory in 16-byte accesses (lane = (row group li, column lq of the
 // 4-column step): a wave-load is 4 column segments of 256 bytes, the tile pattern of the fused pass) and the
 // V rows of a lane's pack feed V separate MFMAs (row set e = rows row0 + V i + e).  At 4 flop per byte the
-// kernel stays HBM-bound (the MFMA pipe could take 19 TB/s).  Bm fragments (4 x 16 doubles per step and
-// column block) come from global memory through L1/L2; accumulation is fp64 for both storage types.
-// Used for fp32 storage (where the VALU kernel below holds only 8 columns per pass); with fp64 storage and
-// 20 columns the VALU kernel is faster (0.86 vs 1.04 ms on config 3).
+// kernel stays HBM-bound (the MFMA pipe could take 19 TB/s).  Accumulation is fp64 for both storage types.
+// Used for fp32 storage beyond 8 columns (where the VALU kernel below holds only 8 per pass) and for fp64 storage beyond 32;
+// with fp64 storage and 20 columns the VALU kernel is the faster one.
 // A wave owns 16 V rows and walks all K; 4 waves per workgroup, one-shot workgroups.
 // ------------------------------------------------------------------------------------
 typedef double xb_f64x4 __attribute__((ext_vector_type(4)));
 
+// ------------------------------------------------------------------------------------
+// out(N x ncols) = X * Bm on the matrix cores with Bm staged through LDS: up to 16 NB columns per pass over X (NB <= 4 for
+// fp64 storage: 64 columns; NB <= 2 for fp32: 32), a wave per 16 V rows.  Its predecessor (rounds 2-3) fetched every B operand from
+// global memory (one 8-byte load per lane and MFMA: 2.6 ms per pass over 131,072 x 4,096 fp32, 0.8 TB/s, neither bandwidth
+// nor matrix pipe); here a chunk of KB rows of Bm sits in LDS -- [k][ST] doubles with a row stride of 16 mod 32 doubles, which
+// puts the two k-rows a half-wave reads on disjoint bank halves -- and one ds_read_b64 feeds V MFMAs.
 template <typename T, int V, int NB>
-__global__ __launch_bounds__(WG) void xb_mfma_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K,
-                                                     const double *__restrict__ Bm, i64 ldb, int ncols,
-                                                     T *__restrict__ out, i64 ldo) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+__global__ __launch_bounds__(WG) void xb_mfma_lds_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K,
+                                                         const double *__restrict__ Bm, i64 ldb, int ncols,
+                                                         T *__restrict__ out, i64 ldo) {
+    constexpr int NC = 16 * NB, KB = 32, ST = (NB % 2) ? NC : NC + 16, U = KB / 4;  // (row stride = 16 mod 32 doubles)
+    __shared__ __attribute__((aligned(16))) double bs[2][KB * ST];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     constexpr int RW = 16 * V;  // rows per wave
     const i64 row0 = ((i64)blockIdx.x * (WG / WAVE) + wv) * RW;
-    if (row0 >= N) return;  // wave-uniform
+    const bool wave_on = row0 < N;  // (wave-uniform; idle waves still stage B and keep the barriers)
     const i64 r = row0 + (i64)V * li;
     const bool rfull = (r + V <= N);
-
     xb_f64x4 acc[V][NB];
 #pragma unroll
     for (int e = 0; e < V; ++e)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[e][b] = xb_f64x4{0.0, 0.0, 0.0, 0.0};
-    // columns >= ncols of a partially used block read column ncols-1 again (never stored)
-    const double *bp[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) bp[b] = Bm + (i64)min(16 * b + li, ncols - 1) * ldb;
-
-    auto load_x = [&](int k) -> Pack<T, V> {
-        Pack<T, V> x;
-        if (rfull) {
-            x = ld_pack_nt<T, V>(X + r + (i64)k * ldx);
-        } else {
-#pragma unroll
-            for (int e = 0; e < V; ++e) x.v[e] = (r + e < N) ? X[r + e + (i64)k * ldx] : (T)0;
+    auto stage = [&](int buf, int k0) {  // Bm[k0 .. k0+KB) x ncols -> bs[buf][k][col], zero padded (consecutive threads: consecutive k)
+        for (int j = tid; j < KB * NC; j += WG) {
+            const int kk = j % KB, m = j / KB;
+            bs[buf][kk * ST + m] = (k0 + kk < K && m < ncols) ? Bm[(k0 + kk) + (i64)m * ldb] : 0.0;
         }
-        return x;
     };
-
-    constexpr int U = 8;  // k-steps in flight
-    int k0 = 0;
-    for (; k0 + 4 * U <= K; k0 += 4 * U) {
-        Pack<T, V> x[U];
-        double bv[U][NB];
+    auto load_x = [&](Pack<T, V> (&x)[U], int k0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            x[u] = load_x(k0 + 4 * u + lq);
+            const int k = k0 + 4 * u + lq;
+            if (k < K && rfull) {
+                x[u] = ld_pack_nt<T, V>(X + r + (i64)k * ldx);
+            } else {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) bv[u][b] = bp[b][k0 + 4 * u + lq];
+                for (int e = 0; e < V; ++e) x[u].v[e] = (k < K && r + e < N) ? X[r + e + (i64)k * ldx] : (T)0;
+            }
         }
+    };
+    stage(0, 0);
+    Pack<T, V> xc[U], xn[U];
+    if (wave_on) load_x(xc, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += KB, buf ^= 1) {
+        // the next chunk -- B into the other LDS buffer, X into the second register set -- goes out ahead of this chunk's MFMAs
+        if (k0 + KB < K) {
+            stage(buf ^ 1, k0 + KB);
+            if (wave_on) load_x(xn, k0 + KB);
+        }
+        if (wave_on) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u) {
+                const double *brow = &bs[buf][(4 * u + lq) * ST + li];
 #pragma unroll
-            for (int e = 0; e < V; ++e)
+                for (int b = 0; b < NB; ++b) {
+                    const double bv = brow[16 * b];
 #pragma unroll
-                for (int b = 0; b < NB; ++b)
-                    acc[e][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].v[e], bv[u][b], acc[e][b], 0, 0, 0);
+                    for (int e = 0; e < V; ++e)
+                        acc[e][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xc[u].v[e], bv, acc[e][b], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) xc[u] = xn[u];
+        }
+        __syncthreads();
     }
-    for (; k0 < K; k0 += 4) {  // last steps, columns >= K contribute zeros
-        const int k = k0 + lq;
-        const bool kok = k < K;
-        const int kc = kok ? k : K - 1;
-        Pack<T, V> x = load_x(kc);
-        double bv[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) bv[b] = kok ? bp[b][kc] : 0.0;
-#pragma unroll
-        for (int e = 0; e < V; ++e)
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-                acc[e][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(kok ? (double)x.v[e] : 0.0, bv[b], acc[e][b], 0, 0, 0);
-    }
+    if (!wave_on) return;
     // D layout: lane holds D[i = lq + 4 q][j = li]; row of X = row0 + V i + e, column of out = 16 b + j
 #pragma unroll
     for (int b = 0; b < NB; ++b) {

@@ -510,10 +510,11 @@ def test_many_responses(handle, oracle, po, mode, N, K, M, A):
     check_against(po, out, ref, Bref, ref["T"], col_err=cerr, tol_inv=1e-7)
 
 
-@pytest.mark.parametrize("N,K,C", [(64, 4, 9), (1000, 33, 16), (4099, 130, 17), (777, 63, 32), (2048, 257, 33), (300, 1025, 50)])
+@pytest.mark.parametrize("N,K,C", [(64, 4, 9), (1000, 33, 16), (4099, 130, 17), (777, 63, 32), (2048, 257, 33), (300, 1025, 50),
+                                   (5001, 100, 64), (1030, 37, 49), (2049, 515, 200), (130, 70, 65)])
 @pytest.mark.parametrize("dt", ["f32", "f64"])
 def test_xb_many_columns(handle, N, K, C, dt):
-    """X * B with more than 8 columns: fp32 storage runs on the matrix cores (xb_mfma_kernel: 16-row MFMA tiles x
+    """X * B with more than 8 columns: fp32 storage -- and fp64 beyond 32 columns -- runs on the matrix cores (xb_mfma_lds_kernel: 16-row MFMA tiles x
     V row sets, ragged last rows, K not a multiple of the 4-column step, column blocks of 16), fp64 storage on the
     LDS-staged kernel.  Against torch in fp64."""
     torch = _torch()
