@@ -478,14 +478,19 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         constexpr int RBG = 8 * V;
         constexpr size_t LDS_G = 2 * 2 * (size_t)SYRK_TB * 128 + 2 * 1024;  // two buffers of two panels + two slabs of Y
         const i64 nslabs_g = (N + RBG - 1) / RBG;
-        i64 Sg = nblocks <= slots ? slots / nblocks : (8 * slots + nblocks - 1) / nblocks;
+        i64 Sg = (8 * slots + nblocks - 1) / nblocks;  // (several waves of workgroups; overwritten for one residency wave)
         i64 Sd = 0;  // row splits of the diagonal blocks; 0 = as the others (several residency waves balance themselves)
         // X^T Y rides along in the diagonal workgroups (one partial row per row split of a diagonal block)
         const bool fuse_y0 = Y && xypart && nb_xy && M >= 1 && M <= 8 && ((uintptr_t)Y % 16) == 0 && (ldy % V) == 0;
-        if (nblocks <= slots) {  // one residency wave: a diagonal workgroup costs 36/64 per slab (more with X^T Y on board)
+        // one residency wave: a diagonal workgroup costs 36/64 per slab (more with X^T Y on board).  Only while the blocks leave
+        // at least sixteen row splits each (up to 7 column blocks, K <= 896): with fewer the slots do not fill and the two kinds of
+        // workgroup balance coarsely -- K = 2048: 136 blocks, 3 + 2 splits, 392 of 512 slots, 0.58 of the matrix pipe -- while eight
+        // waves of workgroups balance themselves and have few diagonal blocks among many: K = 1024 0.77 -> 0.80, 1280 0.68 -> 0.80,
+        // 1536 0.65 -> 0.81, 2048 0.58 -> 0.82 (profiles/r4/syrk_scan.txt)
+        const double dw = fuse_y0 ? (M == 1 ? 0.74 : 0.82) : 0.66;
+        if (nblocks <= slots && (i64)(slots / ((nblocks - nbk) + dw * nbk)) >= 16) {
             // measured optima of the row-split weight (profiles/r3/syrk_diagonal_weight_sweep.txt): 0.74 with X^T Y of one
             // response on board, 0.82 for several, 0.66 without
-            const double dw = fuse_y0 ? (M == 1 ? 0.74 : 0.82) : 0.66;
             const double units = (nblocks - nbk) + dw * nbk;
             Sg = (i64)(slots / units);
             Sd = std::max<i64>(1, (i64)(dw * Sg));
