@@ -47,7 +47,9 @@ int compute_xx_local(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, cons
                     CHK(ensure(c, c->zeros, 256));
                     HIPCHK(c, hipMemsetAsync(c->zeros.p, 0, 256, c->stream));
                 }
-                const i64 xycap = 128 * (i64)K * std::max(M, 1);  // (row splits of a diagonal block: up to 8 x 512 / 45 = 92; launch_syrk checks)
+                // partial rows of X^T Y = row splits of a diagonal block: up to 512 when the blocks are few (K <= 128: every workgroup
+                // of the launch is a diagonal one), up to 8 x 512 / 45 = 92 with eight waves of workgroups; launch_syrk checks
+                const i64 xycap = (K <= 512 ? 512 : 128) * (i64)K * std::max(M, 1);
                 const bool want_xy = Y && xy_red && M >= 1 && M <= 8 &&
                                      ensure(c, c->xyp, (size_t)xycap * 8) == PLS_HIP_OK;
                 if (!want_xy) c->err.clear();
