@@ -812,7 +812,7 @@ def test_auto_plan_choice(handle):
         X = handle.synth_x(0, 1 << 18, 256, 5); Y = handle.synth_y(0, 1 << 18, 1, 5)
         handle.timing()
         handle.fit_device(X, Y, 20); tm = handle.timing()
-        assert tm["launches"]["fused"] == 0 and tm["launches"]["xty"] >= 2     # SYRK + X^T Y, no per-component pass
+        assert tm["launches"]["fused"] == 0 and tm["launches"]["xty"] >= 1     # the SYRK (X^T Y on board), no per-component pass
         handle.fit_device(X, Y, 2); tm = handle.timing()
         assert tm["launches"]["fused"] == 2                                      # two components: passes are cheaper
         Xs = handle.synth_x(0, 500, 64, 5); Ys = handle.synth_y(0, 500, 1, 5)
