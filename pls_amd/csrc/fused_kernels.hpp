@@ -1288,10 +1288,13 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
                 hipLaunchKernelGGL(kfn, g, b, 0, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, rdst, N, st);
             } else if (K <= CG * 4) FUSED_CASE(4);
             else if (K <= CG * 8) FUSED_CASE(8);
-            else if (K <= CG * 16) FUSED_CASE(16);
+            else if (K <= CG * 12) FUSED_CASE(12);  // (the in-between shapes: a matrix just above a power-of-two boundary would
+            else if (K <= CG * 16) FUSED_CASE(16);  //  run the next shape half empty -- profiles/r4/width_scan.txt)
+            else if (K <= CG * 24) FUSED_CASE(24);
             else FUSED_CASE(32);
         } else if constexpr (CGX == 64 || CGX == 128) {
-            FUSED_CASE(16);  // (32 columns per lane on these tiles was the round-1 shape: slower, deleted in round 4)
+            if (K <= CG * 12) FUSED_CASE(12);
+            else FUSED_CASE(16);  // (32 columns per lane on these tiles was the round-1 shape: slower, deleted in round 4)
         } else if constexpr (CGX == 8) {  // narrow matrices: 128-row (fp64) tiles
             if (K <= CG * 4) FUSED_CASE(4);
             else if (K <= CG * 8) FUSED_CASE(8);
@@ -1301,10 +1304,12 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         } else if constexpr (CGX == 512) {
             // 512 x 1: a tile = ONE row pack of every column, 16 bytes per column (the copy is row-pack-major): K <= 8192
             // at 16 columns per lane; read-only passes up to K = 16384 at 32 (256 VGPRs, one workgroup per CU)
-            if (K <= CG * 16) FUSED_CASE(16);
+            if (K <= CG * 12) FUSED_CASE(12);
+            else if (K <= CG * 16) FUSED_CASE(16);
             else FUSED_EDGE(32, false, (size_t)CG * 32 * sizeof(double));
         } else {
-            FUSED_CASE(16);  // 256 column groups x 2 row lanes: K <= 4096 at 16 columns per lane
+            if (K <= CG * 12) FUSED_CASE(12);
+            else FUSED_CASE(16);  // 256 column groups x 2 row lanes: K <= 4096 at 16 columns per lane
         }
 #undef FUSED_CASE
 #undef FUSED_EDGE

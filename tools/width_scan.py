@@ -7,7 +7,7 @@ import torch, pls_amd
 h = pls_amd.Handle()
 lines = []
 for dt, es in ((torch.float64, 8), (torch.float32, 4)):
-    for K in (96, 128, 130, 250, 256, 258, 500, 512, 514, 600, 1000, 1024, 1026, 1100, 2048, 2050, 3000, 4096, 4098, 5000, 8192, 8194, 9000, 16384, 16386):
+    for K in (130, 190, 258, 300, 380, 514, 600, 760, 1026, 1100, 1500, 2050, 3000, 4098, 5000, 6100):
         N = int(3e9 / (K * es)) // 64 * 64
         A = 20
         X = h.synth_x(0, N, K, 5, dtype=dt); Y = h.synth_y(0, N, 1, 5, dtype=dt)
