@@ -1298,9 +1298,11 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         } else if constexpr (CGX == 8) {  // narrow matrices: 128-row (fp64) tiles
             if (K <= CG * 4) FUSED_CASE(4);
             else if (K <= CG * 8) FUSED_CASE(8);
+            else if (K <= CG * 12) FUSED_CASE(12);
             else FUSED_CASE(16);
         } else if constexpr (CGX == 16) {
-            FUSED_CASE(16);
+            if (K <= CG * 12) FUSED_CASE(12);
+            else FUSED_CASE(16);
         } else if constexpr (CGX == 512) {
             // 512 x 1: a tile = ONE row pack of every column, 16 bytes per column (the copy is row-pack-major): K <= 8192
             // at 16 columns per lane; read-only passes up to K = 16384 at 32 (256 VGPRs, one workgroup per CU)
