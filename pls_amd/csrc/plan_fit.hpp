@@ -18,7 +18,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // KERNEL plan and AUTO (also when X^T X came with the upload: one launch beats the K x K loop's sixty);
     // an explicit NIPALS or GRAM request keeps its own kernels.
     if (method == PLS_HIP_KERNEL_TYPE1 && (c->opt_algo == PLS_HIP_ALGO_KERNEL || c->opt_algo == PLS_HIP_ALGO_AUTO) && c->opt_fuse &&
-        !c->reducer && c->env.tiny && plsk::tiny_fit_covers(N, K, M, A, ldx, sizeof(T))) {
+        !c->reducer && c->env.tiny && plsk::tiny_fit_covers(N, K, M, A, ldx, sizeof(T)) &&
+        !plsk::micro_fit_covers(N, K, M, A, ldx, sizeof(T))) {  // (the smallest data: one wave is faster than 1024 threads' barriers, below)
         const size_t lds = (size_t)2 * K * A * 8;
         if (!plsk::raise_dynamic_lds((const void *)plsk::tiny_fit_kernel<T>, (int)plsk::TINY_LDS_MAX)  /* raised once per device: to the most any fit asks for */)
             return fail(c, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the single-launch fit could not be raised");
