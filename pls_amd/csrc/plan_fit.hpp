@@ -128,7 +128,9 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // fit, 1,500 x 10,000: 0.70 / 0.89, 3,000 x 12,000: 1.22 / 1.30; 6,000 x 10,000: 1.91 / 1.59 -- profiles/r4/short_wide_plan_choice.txt)
     const bool wide_src = c->opt_fuse && !fused_fit && N > 0 && K <= 512 * (nipals ? 16 : 32) && (K <= 512 * 16 || N >= 4096) &&
                           plsk::wide_source_ok<T>(X, ldx, N, Tm) && plsk::elem_aligned<T>(Y);
-    const bool wide_only = nipals && wide_src && K > 256 * 16 && K <= 512 * 16 && M <= 8 && A >= 3 && c->opt_work_layout != 0;
+    // (more than 8 responses: X^T Y does not ride in the copy's sweep -- a plain copy before the first component and the X^T Y pass
+    // of its own, as the KERNEL plan does; 25,000 x 8,192 with 12 responses: 12.3 -> 7.5 ms per 10-component fit)
+    const bool wide_only = nipals && wide_src && K > 256 * 16 && K <= 512 * 16 && A >= 3 && c->opt_work_layout != 0;
     const bool tiled_work = nipals && (fused_fit || semi_fit || wide_only) && c->opt_work_layout != 0;
     // Row-tile-major tiles are contiguous whatever their height, so for 1024 < K <= 4096 the working copy uses
     // SHORTER tiles (8-32 rows) that do fit the registers of a CU: from the third component on the fully fused
@@ -220,7 +222,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             retiled = true;
         }
     }
-    if (wide_only && !retiled && N > 0) return fail(c, PLS_HIP_ERR_DEVICE, "copy into row-pack tiles failed");
+    if (wide_only && !retiled && N > 0 && M <= 8) return fail(c, PLS_HIP_ERR_DEVICE, "copy into row-pack tiles failed");
     if (retiled) {
     } else if (use_pre) {
         hipLaunchKernelGGL(plsk::fill_slices_kernel, dim3((unsigned)((L0 + plsk::WG - 1) / plsk::WG)), dim3(plsk::WG), 0,
@@ -384,12 +386,12 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 } else {
                     return fail(c, PLS_HIP_ERR_DEVICE, "fused pass launch failed");
                 }
-            } else if (wide_cg && (nipals ? (a >= 2 || retiled) : true)) {
+            } else if (wide_cg && (nipals ? (a >= 2 || retiled || wide_only) : true)) {
                 // short-tile fused pass on the working copy: NIPALS deflates it in place, KERNEL only reads it
                 int nb = 0, nss = 0, rc;
                 const T *tprev = (nipals && a > 0) ? Tm + (i64)(a - 1) * ldt : nullptr;
                 const double *pprev = (nipals && a > 0) ? P + (i64)(a - 1) * K : nullptr;
-                if (!nipals && a == 0 && !retiled) {  // the one-time copy into short tiles (before the first component: it runs fused, too)
+                if ((!nipals || wide_only) && a == 0 && !retiled) {  // the one-time copy into short tiles (before the first component: it runs fused, too)
                     Scope s(c, PLS_HIP_FAM_DEFLATE, 2 * (i64)N * K * sizeof(T));
                     if (plsk::launch_retile<T>(c->stream, c->num_cu, X, ldx, work, ldw, tsw, (int)WR, N, K) != 0) {
                         s.on = false;

@@ -52,6 +52,7 @@ SHAPES = [
     (261, 5000, 1, 4, "f64", 0, 0),     # beyond 4096 columns: row-pack tiles of the copy (512 column groups)
     (131, 8192, 2, 5, "f64", 0, 1),     # ... the widest they take, unaligned source
     (263, 6000, 8, 4, "f32", 0, 0),
+    (265, 5000, 12, 4, "f64", 0, 0),    # ... with more than 8 responses: both plans still run fused on the copy
     (130, 4100, 3, 3, "f32", 1, 2),
     (75, 9000, 1, 4, "f64", 0, 0),      # 8192 < K <= 16384 on a short matrix: the one-product kernels
     (4099, 8200, 1, 3, "f64", 0, 0),    # ... and from 4096 rows on the KERNEL plan still fuses (32 columns per lane, read-only)
@@ -160,8 +161,10 @@ def test_edge_shapes_take_the_one_sweep_plan(handle, oracle, po, plan, monkeypat
         # short tiles: one copy into them (in the same sweep as X^T Y) + A fused passes, read-only (KERNEL) or in place (NIPALS)
         assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
     elif K <= 8192:
-        # row-pack tiles: the same plan (one copy in the X^T Y sweep + A fused passes)
-        assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1 and tm["launches"]["xty"] == 0, tm["launches"]
+        # row-pack tiles: the same plan (one copy in the X^T Y sweep + A fused passes; more than 8 responses: a plain copy and
+        # the X^T Y pass of its own)
+        assert tm["launches"]["fused"] == A and tm["launches"]["deflate"] == 1, tm["launches"]
+        assert (tm["launches"]["xty"] == 0) if M <= 8 else (tm["launches"]["xty"] >= 1), tm["launches"]
     elif K <= 16384 and not nipals and N >= 4096:
         # 32 columns per lane, read-only: from 4096 rows on (on a shorter matrix the partial rows of K doubles per workgroup
         # weigh as much as the matrix, and the one-product kernels are the faster plan)
