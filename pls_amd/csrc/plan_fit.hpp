@@ -67,15 +67,20 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     if (algo == PLS_HIP_ALGO_AUTO && have_pre) {
         algo = PLS_HIP_ALGO_GRAM;  // X^T X is already there: the component loop needs no pass over X at all
     } else if (algo == PLS_HIP_ALGO_AUTO) {
+        // Both plans priced with what they launch (profiles/r4/auto_scan.txt): a pass over X per component + ~14 us of launches for
+        // KERNEL; for GRAM the SYRK on the blocks it EXECUTES (whole 128-column blocks: a 32-column matrix costs what a 128-column
+        // one does), the pass that forms T = X R, and per component the symv + update on K x K data, ~9 us + 18 ns per column.
         const double pass_s = (double)N * K * sizeof(T) / 6.0e12;
         const int nbk = (K + plsk::SYRK_TB - 1) / plsk::SYRK_TB;
+        const double kp = (double)nbk * plsk::SYRK_TB;
         // tiles of 16 x 16 the SYRK executes: the blocks above the diagonal in full, 36 of 64 in a diagonal block (syrk_kernels.hpp)
         const double tile_frac = (32.0 * nbk * (nbk - 1) + 36.0 * nbk) / (64.0 * nbk * nbk);
-        const double syrk_s = 2.0 * N * (double)K * K * tile_frac / 59.0e12;
+        const double syrk_s = 2.0 * N * kp * kp * tile_frac / 60.0e12;
+        const double kernel_s = (1 + A) * pass_s + A * 14e-6;
+        const double gram_s = syrk_s + 1.3 * pass_s + A * (9e-6 + K * 1.8e-8) + 40e-6;
         // ranks of a sharded fit see different N: they must not disagree on the plan -> KERNEL there
         const bool gram_ok = K <= 2048 && N >= 4096 && !c->reducer;
-        algo = (gram_ok && (1 + A) * pass_s > syrk_s + 2.5 * pass_s + A * 25e-6) ? PLS_HIP_ALGO_GRAM
-                                                                               : PLS_HIP_ALGO_KERNEL;
+        algo = (gram_ok && kernel_s > gram_s) ? PLS_HIP_ALGO_GRAM : PLS_HIP_ALGO_KERNEL;
     }
     const bool gram = (method == PLS_HIP_KERNEL_TYPE1) && (algo == PLS_HIP_ALGO_GRAM);
     const bool type2 = (method == PLS_HIP_KERNEL_TYPE2) || gram;
