@@ -8,7 +8,7 @@ one = po.OracleLib(omp=False)
 h = pls_amd.Handle()
 lines = []
 for M in (1, 3):
-    for (N, K) in ((10, 15), (20, 10), (40, 20), (64, 32), (65, 32), (64, 33), (200, 50), (512, 50), (1024, 26), (1025, 26), (1024, 40), (2000, 30), (5000, 20), (300, 400), (300, 500),
+    for (N, K) in ((10, 15), (20, 10), (40, 20), (64, 32), (65, 32), (64, 33), (200, 50), (512, 50), (1024, 26), (1025, 26), (1024, 40), (2000, 30), (5000, 20), (8000, 100), (4000, 500), (300, 400), (300, 500),
                    (60, 401), (60, 2000), (100, 5000), (3000, 100), (10000, 64), (20000, 16)):
         A = 5
         X = one.synth_x(3, N, K); Y = one.synth_y(3, N, M)
