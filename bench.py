@@ -307,7 +307,13 @@ def main():
     torch.cuda.set_device(local)
     if world > 1 or a.rccl_leg_at_one_rank:
         if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:  # a free port: two bench / test processes on one box must not collide
+                import socket
+
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -534,6 +540,7 @@ def main():
             if rank == 0:
                 line.setdefault("alt", {})["rccl"] = {"unavailable": f"RCCL leg did not finish within {a.alt_timeout} s"}
                 print(json.dumps(line), flush=True)
+            print(f"bench.py: rank {rank}: the RCCL leg hung (> {a.alt_timeout} s); leaving with the headline only", file=sys.stderr, flush=True)
             os._exit(0)
 
         finished = threading.Event()

@@ -93,6 +93,19 @@ static inline void row_block(i64 N, int nt, int id, i64 *a, i64 *b) {
 static void omp_colsums(const double *X, i64 ldx, const double *Y, i64 ldy, i64 N, i64 K, i64 M, double *XY) {
     const int nt = omp_get_max_threads();
     double *ps = (double *)calloc((size_t)nt * (size_t)(K * M) * 2, sizeof(double)); /* [thread][sum K*M | err K*M] */
+    if (!ps) { /* no room for the per-thread partials (~1 GB at K = 6000, M = 600, 16 threads): the serial loop */
+        for (i64 k = 0; k < K; ++k)
+            for (i64 m = 0; m < M; ++m) {
+                double ss = 0.0, cc = 0.0;
+                if (g_compensated) {
+                    for (i64 i = 0; i < N; ++i) acc2(X[k * ldx + i], Y[m * ldy + i], &ss, &cc);
+                } else {
+                    for (i64 i = 0; i < N; ++i) ss += X[k * ldx + i] * Y[m * ldy + i];
+                }
+                XY[k + m * K] = ss + cc;
+            }
+        return;
+    }
 #pragma omp parallel num_threads(nt)
     {
         const int id = omp_get_thread_num();

@@ -10,7 +10,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpls_hip.so")
+# PLS_AMD_LIBRARY: another build of the same library -- the test suite's csrc/testing/libpls_hip.so, which carries the
+# fault-injection hook of the exchange that the production library does not have
+LIB_PATH = os.environ.get("PLS_AMD_LIBRARY") or os.path.join(_HERE, "csrc", "libpls_hip.so")
 
 # enums of include/pls_hip.h
 OK, ERR_INVALID, ERR_DEVICE, ERR_ALLOC, ERR_UNSUPPORTED, ERR_REDUCER = range(6)

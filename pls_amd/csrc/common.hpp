@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #include <mutex>
-#include <set>
+#include <map>
 #include <utility>
 
 namespace plsk {
@@ -160,22 +160,25 @@ __device__ __forceinline__ void st_agent(double *p, double v) {
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): a process that drives several
 // GPUs (pls_hip_group) must raise it once on each of them.  true = the kernel may be launched with `bytes` of
-// dynamic LDS on the current device.
+// dynamic LDS on the current device.  The size raised to is remembered: a later call that asks for MORE raises again
+// (callers whose size depends on the problem -- lm_eig_lds_big_kernel: (2 M^2 + M) 8 bytes -- must not be pinned to the
+// first problem's), one that asks for less is a look-up.
 inline bool raise_dynamic_lds(const void *fn, int bytes) {
     static std::mutex mu;
-    static std::set<std::pair<const void *, int>> done;
+    static std::map<std::pair<const void *, int>, int> done;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
     std::lock_guard<std::mutex> lock(mu);
-    if (done.count({fn, dev})) return true;
+    const auto it = done.find({fn, dev});
+    if (it != done.end() && it->second >= bytes) return true;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
-    done.insert({fn, dev});
+    done[{fn, dev}] = bytes;
     return true;
 }
 

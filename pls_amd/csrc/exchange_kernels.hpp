@@ -147,18 +147,20 @@ inline int xchg_launch_piece(hipStream_t stream, int n, int rank, double *const 
         peers.slot[j] = inboxes[j] + ((i64)par * n + rank) * XCHG_CAP;
         peers.flag[j] = flagsv[j] + par * n + rank;
     }
-    // fault injection for the tests of the time-out path: PLS_HIP_TEST_DROP_PUSH="rank:collective" makes that rank skip
-    // that one push, once per process (its peers -- and itself -- then wait for a flag that never comes)
-    // (UNSUPPORTED outside the test-suite: a stray value ends a production fit in a time-out.  The flag is atomic: the
-    // members of a group call this from concurrent host threads.)
+    bool skip = false;
+#ifdef PLS_HIP_TESTING
+    // fault injection for the tests of the time-out path -- compiled into testing/libpls_hip.so ONLY (make testing; the
+    // production library has no such branch): PLS_HIP_TEST_DROP_PUSH="rank:collective" makes that rank skip that one push,
+    // once per process (its peers -- and itself -- then wait for a flag that never comes).  The flag is atomic: the members
+    // of a group call this from concurrent host threads.
     static const char *drop = getenv("PLS_HIP_TEST_DROP_PUSH");
     static std::atomic<bool> dropped{false};  // (once per process)
-    bool skip = false;
     if (drop && !dropped.load(std::memory_order_relaxed)) {
         int dr = -1;
         unsigned long long dq = 0;
         if (sscanf(drop, "%d:%llu", &dr, &dq) == 2 && dr == rank && dq == seq) skip = !dropped.exchange(true);
     }
+#endif
     if (L <= XCHG_FUSED_MAX) {
         const int ngb = (int)std::min<i64>(4, (L + XCHG_THREADS - 1) / XCHG_THREADS);
         hipLaunchKernelGGL(xchg_push_gather_kernel, dim3(1 + ngb), dim3(XCHG_THREADS), 0, stream, peers, skip ? 0 : 1,

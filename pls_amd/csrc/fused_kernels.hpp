@@ -24,8 +24,27 @@
 #pragma once
 #include "common.hpp"
 #include "exchange_kernels.hpp"  // XchgPeers: the push of a sharded fit's sums rides in the tail of the pass
+#include "update_m1.hpp"         // the one-response component update: the last act of the tail
 
 namespace plsk {
+
+#ifdef PLS_HIP_TESTING
+// testing/libpls_hip.so only: wall-clock stamps of every workgroup of a fused pass (start, tile loop done, exit) for
+// tools/pass_stamps.py -- where a short pass spends its time (dispatch skew, imbalance at the end of the tile loop, the tail)
+__device__ unsigned long long *g_pass_stamps = nullptr;
+#define PLS_STAMP(slot)                                                                                 \
+    do {                                                                                                \
+        if (g_pass_stamps && threadIdx.x == 0) {                                                        \
+            g_pass_stamps[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64();                            \
+            if ((slot) == 0) {  /* where the workgroup runs: XCC_ID (hwreg 20), HW_ID (hwreg 4) */       \
+                g_pass_stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  \
+                g_pass_stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   \
+            }                                                                                           \
+        }                                                                                               \
+    } while (0)
+#else
+#define PLS_STAMP(slot) do { } while (0)
+#endif
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -108,6 +127,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t score_rsrc(const T *col, i64 n
 // Counters: RED_SLICES + 1 words, zero before the first launch of a fit; every counter is reset by its last arriver.
 // Every wait is an atomic's return value or a barrier: no spinning, nothing that needs other workgroups to be resident.
 // ---------------------------------------------------------------------------------------------------------------------
+// The one-response component update (update_m1.hpp) as the LAST act of the tail: the workgroup that summed the last slice
+// holds [X^T t, t^T t] and runs p, q, the XY deflation, w and the r recurrence right there -- a component is ONE launch.
+struct TailUpdate {
+    double *XY = nullptr;  // nullptr: no update in the tail (the component update is a launch of its own)
+    double *W = nullptr, *P = nullptr, *Q = nullptr, *R = nullptr, *vnext = nullptr;
+    int A = 0, a = 0, nipals = 0;
+};
+
+// Unequal shares of the tiles for the workgroups of the fast / slow XCD classes (fused_pass_kernel, "weighted walk")
+struct WalkWeights {
+    int nfull = -1;     // rounds dealt to all workgroups; -1: plain cyclic walk
+    unsigned mask = 0;  // bit c: the workgroups with blockIdx % 8 == c also share the tiles behind those rounds
+};
+
 struct SliceTail {
     unsigned *cnt = nullptr;  // nullptr: no tail (reduce_partials_kernel follows the launch)
     double *red = nullptr;    // RED_SLICES slices of K + 1 values
@@ -115,20 +148,59 @@ struct SliceTail {
     int npush = 0;            // members of the exchange to push to; 0: single rank or a reducer of the caller's
     unsigned long long seq = 0;
     XchgPeers peers;
+    TailUpdate upd;
+    XchgGather gx;            // sharded, with upd: the gather of this collective behind the push (n = 0: none)
 };
 
 constexpr int TAIL_MIN_WG = 32;  // fewer workgroups: a slice could be left without one (reduce_partials_kernel instead)
+constexpr int TAIL_AUX_SYS = 17;  // sc0 sc1: system scope (the peers' writes into fine-grained memory)
 
 // all NT threads of the workgroup call it after their stores of part / sspart have been waited for and a barrier;
-// role: one int of LDS, sm: >= 4 doubles of LDS
+// role: one int of LDS; sm: >= 4 doubles of LDS; scratch: >= 16 + A doubles of LDS and wl: >= K doubles of LDS (the update)
 // Hand-off: every handed-off byte is stored sc1, waited for by the storing wave, and loaded sc1 behind the returned add
 // and a barrier -- MI355X_MICROARCH.md "Valid forms", first row of its table (hipMalloc memory, ONE workgroup per CU, 8-byte
 // accesses): the launchers use the tail for launches of one workgroup per CU only.  (With two per CU -- the read-only
 // passes at 16 columns per lane -- a slice is 64 rows, its last workgroup reads 256 KB behind an agent-scope acquire, and
 // the pass + tail lost 4.7 us per component to pass + reduce_partials_kernel at config 3: profiles/r4/tail_ab.txt.)
+// The update itself, out of line (ONE copy for all instantiations of the pass; its arguments travel in registers): the reduced
+// value j is 0.0 + src[j] + src[stride + j] + ... over n vectors -- the RED_SLICES slices this launch's slice reducers stored
+// (sc1 loads), or, sharded, the members' vectors in this member's inbox in rank order (sys: sc0 sc1 loads; !ok: a wait that
+// timed out -- NaN).  The same bits as red_sum over the sliced form the other routes present (0.0 + x0 = x0, and a sum that
+// is -0.0 either way ends as +0.0).
+__device__ __noinline__ void tail_update_m1(const double *src, i64 stride, int n, int sys, int ok, double *XY, double *W, double *P,
+                                            double *Q, double *R, double *vnext, int K, int A, int a, int nipals, double *scratch,
+                                            double *wl) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    static_assert(XCHG_MAX == 2 * RED_SLICES, "two batches of RED_SLICES loads");
+    const int L = K + 1;
+    update_m1<512, 1>(  // (K <= 1024: the launcher)
+        [&](int j) -> double {
+            double sum = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h * RED_SLICES >= n) break;  // (uniform)
+                double x[RED_SLICES];
+#pragma unroll
+                for (int m = 0; m < RED_SLICES; ++m) {  // the vectors' values in flight together
+                    const int mm = h * RED_SLICES + m;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<double *>(src + (i64)(mm < n ? mm : 0) * stride), (short)0, L * 8, BUF_WORD3);
+                    const u32x2 raw = sys ? __builtin_amdgcn_raw_buffer_load_b64(rs, (uint32_t)j * 8u, 0, TAIL_AUX_SYS)
+                                          : __builtin_amdgcn_raw_buffer_load_b64(rs, (uint32_t)j * 8u, 0, AUX_SC1);
+                    __builtin_memcpy(&x[m], &raw, 8);
+                }
+#pragma unroll
+                for (int m = 0; m < RED_SLICES; ++m)
+                    if (h * RED_SLICES + m < n) sum += x[m];
+            }
+            return ok ? sum : __builtin_nan("");
+        },
+        XY, W, P, Q, R, vnext, K, A, a, nipals, 0, scratch + UPD1_VWAVES, scratch, wl);
+}
+
 template <int NT>
 __device__ __forceinline__ void slice_tail(const SliceTail &st, const double *part, const double *sspart, int K, int *role,
-                                           double *sm) {
+                                        double *sm, double *scratch, double *wl) {
     static_assert(NT >= WG, "the t^T t sum takes the first four waves");
     const int tid = threadIdx.x, nb = st.nrows, nwg = gridDim.x, b = blockIdx.x;
     const int sl = (int)(((i64)(b + 1) * RED_SLICES + nb - 1) / nb) - 1;  // lo(sl) <= b < hi(sl)
@@ -145,11 +217,11 @@ __device__ __forceinline__ void slice_tail(const SliceTail &st, const double *pa
     __syncthreads();
     if (!*role) return;
     const i64 LP = K + 1;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     double ssl = 0.0;  // t^T t of the slice, this thread's strided share: loaded ahead of the rows
     {
         const __amdgpu_buffer_rsrc_t rq =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(sspart), (short)0, nb * 8, BUF_WORD3);
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         if (tid < WG)
             for (int r = lo + tid; r < hi; r += WG) {
                 const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rq, (uint32_t)r * 8u, 0, AUX_SC1);
@@ -161,7 +233,6 @@ __device__ __forceinline__ void slice_tail(const SliceTail &st, const double *pa
     {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(part + (i64)lo * K), (short)0,
                                                                             (int)((i64)(hi - lo) * K * 8), BUF_WORD3);
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         auto ld = [&](int row, int j) -> double {  // (rows beyond hi - lo: out of range, zero)
             const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs, (uint32_t)(((i64)row * K + j) * 8), 0, AUX_SC1);
             double d;
@@ -197,8 +268,9 @@ __device__ __forceinline__ void slice_tail(const SliceTail &st, const double *pa
         __syncthreads();
         if (tid == 0) st_agent(st.red + (i64)sl * LP + K, ((sm[0] + sm[1]) + sm[2]) + sm[3]);
     }
-    if (st.npush <= 0) return;
-    // ---- the sums of all slices -> every member's inbox (the last of the RED_SLICES slice reducers)
+    if (st.npush <= 0 && !st.upd.XY) return;
+    // ---- the last of the RED_SLICES slice reducers: the sums of all slices -> every member's inbox (sharded), the component
+    // update (one response)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -211,10 +283,9 @@ __device__ __forceinline__ void slice_tail(const SliceTail &st, const double *pa
     }
     __syncthreads();
     if (!*role) return;
-    {
-        const __amdgpu_buffer_rsrc_t rr =
-            __builtin_amdgcn_make_buffer_rsrc(st.red, (short)0, (int)((i64)RED_SLICES * LP * 8), BUF_WORD3);
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rr =
+        __builtin_amdgcn_make_buffer_rsrc(st.red, (short)0, (int)((i64)RED_SLICES * LP * 8), BUF_WORD3);
+    if (st.npush > 0) {
         for (int j = tid; j <= K; j += NT) {
             double x[RED_SLICES];
 #pragma unroll
@@ -233,6 +304,38 @@ __device__ __forceinline__ void slice_tail(const SliceTail &st, const double *pa
         __syncthreads();
         if (tid < st.npush) __hip_atomic_store(st.peers.flag[tid], st.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (!st.upd.XY) return;
+    const TailUpdate &u = st.upd;
+    if (st.gx.n > 0) {
+        // sharded: the GATHER of the collective just pushed (component_update_gather_kernel's prologue) -- wait until every
+        // member's flag shows it, then the members' vectors in rank order.  Only this one workgroup is left of the launch:
+        // a peer that shares the GPU (the rehearsal on one device) finds the other CUs free, so the wait needs no
+        // co-residency; a wait beyond the time limit raises the status words and poisons the sums, as xchg_gather_kernel does.
+        const XchgGather &gx = st.gx;
+        if (tid == 0) *role = (*gx.status == 0);  // an earlier wait of this member timed out: do not wait again
+        __syncthreads();
+        if (tid < gx.n && *role) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(gx.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < gx.seq) {
+                if (wall_clock64() - t0 > gx.limit) {
+                    *role = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the vectors behind the flags
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        const int ok = *role;
+        if (!ok && tid == 0) {
+            *gx.status = 1;
+            __hip_atomic_store(gx.host_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        tail_update_m1(gx.inbox, gx.cap, gx.n, 1, ok, u.XY, u.W, u.P, u.Q, u.R, u.vnext, K, u.A, u.a, u.nipals, scratch, wl);
+        return;
+    }
+    tail_update_m1(st.red, LP, RED_SLICES, 0, 1, u.XY, u.W, u.P, u.Q, u.R, u.vnext, K, u.A, u.a, u.nipals, scratch, wl);
 }
 
 // Matrix layouts: element (i, k) of a matrix with column stride ld and tile stride ts lives at
@@ -307,7 +410,8 @@ template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX_ = AUX
 __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) void fused_pass_kernel(
     const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd, i64 N, int K,  // dst may alias X (in-place deflation)
     const double *__restrict__ v, const T *__restrict__ tprev, const double *__restrict__ pprev,
-    T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart, int rdst, i64 NV, const SliceTail st) {
+    T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart, int rdst, i64 NV, const SliceTail st,
+    const WalkWeights wk) {
     // N: rows swept (a multiple of V); NV <= N: valid rows of the score columns (the rows between are zero padding of
     // the library's own copy)
     constexpr int RP = R / V;    // lanes along the rows of a tile
@@ -336,11 +440,25 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) vo
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int rp = tid % RP, cg = tid / RP;
-    for (int k = tid; k < CG * CPT; k += NT) {
-        vs[k] = (k < K) ? v[k] : 0.0;
-        if (DEFL) ps[k] = (k < K) ? pprev[k] : 0.0;
+    PLS_STAMP(0);
+    // TILED deflating pass: the operand vectors are fetched here but go to LDS behind the FIRST tile's loads (below) -- those
+    // need neither, and a short pass (a shard) should not wait a memory round trip before its first byte of X is asked for
+    constexpr bool LATE_OK = TILED && DEFL && CG * CPT <= NT;
+    const bool LATE_FILL = LATE_OK && (rdst & 0x10000);
+    double v_late = 0.0, p_late = 0.0;
+    if (LATE_FILL) {
+        if (tid < CG * CPT) {
+            v_late = (tid < K) ? v[tid] : 0.0;
+            p_late = (tid < K) ? pprev[tid] : 0.0;
+        }
+    } else {
+        for (int k = tid; k < CG * CPT; k += NT) {
+            vs[k] = (k < K) ? v[k] : 0.0;
+            if (DEFL) ps[k] = (k < K) ? pprev[k] : 0.0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    bool first_tile = true;
 
     double pacc[CPT];
 #pragma unroll
@@ -365,7 +483,17 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) vo
     // EDGE = 2: XCD-contiguous tiles (grids that are a multiple of 8; cyclic otherwise).  The other instantiations fold
     // the three values below to blockIdx.x, gridDim.x and N at compile time.
     TileWalk<EDGE == 2, R> walk(N);
-    for (i64 tile = walk.first(); tile * R < walk.nlim(N); tile += walk.step(), buf ^= 1) {
+    const int pace = rdst & 0xffff;
+    // Weighted walk (wk.nfull >= 0; grids that are a multiple of 8): the rounds [0, nfull) are dealt out cyclically to all
+    // workgroups, the tiles behind them to the workgroups of the FAST classes only -- workgroup b runs on XCD b % 8, and on
+    // MI355X the XCDs do not stream alike: in a read+write sweep the odd ones need 5-10 % longer per tile whatever the tile
+    // (profiles/r5/pass_stamps_shapes.txt), so with equal shares half the chip idles for the last 8 % of the launch.
+    // Static, so the tile set of a workgroup -- and with it every sum -- is the same in every run.
+    const int wfast = (wk.nfull >= 0 && EDGE != 2) ? ((wk.mask >> (blockIdx.x & 7)) & 1) : 0;
+    const i64 wswitch = (wk.nfull >= 0 && EDGE != 2) ? (i64)wk.nfull * gridDim.x : (i64)1 << 62;
+    i64 wstep = walk.step();
+    bool wshared = true;
+    for (i64 tile = walk.first(); tile * R < walk.nlim(N); buf ^= 1) {
         const i64 i0 = tile * R + (i64)rp * V;
         const bool rowok = (i0 < N);  // N % V == 0 (launcher): a pack is all-valid or all-invalid
         const uint32_t xo = rowok ? xoff : OOR, dof = rowok ? doff : OOR;
@@ -375,7 +503,8 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) vo
         asm volatile("" : "+v"(cgz));
         if constexpr (TILED && DEFL) {
             // pacing: `rdst` x 64 cycles of s_sleep before a tile's loads go out (launcher)
-            for (int q = 0; q < rdst; ++q) __builtin_amdgcn_s_sleep(1);
+            if (!LATE_FILL || !first_tile)  // (nothing is in flight before the first tile)
+                for (int q = 0; q < pace; ++q) __builtin_amdgcn_s_sleep(1);
         }
         Pack<T, V> x[CPT];
         constexpr int GSTEP = CG * R * (int)sizeof(T);  // TILED: bytes between the column groups of a tile
@@ -386,6 +515,16 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) vo
 #pragma unroll
             for (int j = 0; j < CPT; ++j) x[j] = buf_ld_so<T, V, LDAUX>(rs, xo, j * GSTEP);
             __builtin_amdgcn_sched_barrier(0);  // all CPT loads in flight before anything consumes the first
+            if constexpr (LATE_OK) {
+                if (LATE_FILL && first_tile) {  // (uniform)
+                    first_tile = false;
+                    if (tid < CG * CPT) {
+                        vs[tid] = v_late;
+                        ps[tid] = p_late;
+                    }
+                    __syncthreads();
+                }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < CPT; ++j) {
@@ -494,10 +633,19 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) vo
         for (int j = 0; j < CPT; ++j)
 #pragma unroll
             for (int e = 0; e < V; ++e) pacc[j] = fma((double)x[j].v[e], t[e], pacc[j]);
+        tile += wstep;
+        if (wshared && tile >= wswitch) {  // (uniform) the shared rounds are over
+            if (!wfast) break;
+            wshared = false;
+            const int nfc = __builtin_popcount(wk.mask), below = __builtin_popcount(wk.mask & ((1u << (blockIdx.x & 7)) - 1u));
+            tile = wswitch + (i64)(blockIdx.x >> 3) * nfc + below;
+            wstep = (i64)(gridDim.x >> 3) * nfc;
+        }
     }
 
     // epilogue: sum over the RP lanes that share a column group (low lane bits), then one lane
     // per column group writes this workgroup's partial row
+    PLS_STAMP(1);
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const double s = xor_range_sum<1, RP>(pacc[j]);
@@ -506,11 +654,19 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) vo
     }
     ss = block_sum<NW>(ss, sred);
     if (tid == 0) st_agent(sspart + blockIdx.x, ss);
-    if (st.cnt) {  // (uniform) the partial rows are summed inside this launch
+    // (the tail exists in the instantiations launched with ONE workgroup per CU only -- see slice_tail; the two-per-CU read-only
+    // shapes carry neither its code nor the registers of the out-of-line update)
+    constexpr bool ONE_PER_CU = !(CPT <= 16 && !DEFL);
+    if (ONE_PER_CU && st.cnt) {  // (uniform) the partial rows are summed inside this launch
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        slice_tail<NT>(st, part, sspart, K, reinterpret_cast<int *>(&tred[0][0][0]), sred);
+        // LDS of the tail: role word and the t^T t sums in sred; the update's block sums + p_j^T w products in the score
+        // exchange buffer (2 NW R doubles: the launcher checks 16 + A against it), its w in the operand vector's place
+        static_assert(NT == 512, "tail_update_m1 plays the update's 1024 virtual threads with 512");
+        PLS_STAMP(2);
+        slice_tail<NT>(st, part, sspart, K, reinterpret_cast<int *>(sred + NW - 1), sred, &tred[0][0][0], vs);
     }
+    PLS_STAMP(3);
 }
 
 // Semi-fused sweep for matrices too wide for the resident tile (K > 32 column groups' worth):
@@ -1189,7 +1345,9 @@ template <typename T, int CGX = 32>
 int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd,
                       i64 N, int K, const double *v, const T *tprev, const double *pprev, T *tout,
                       double *part, int max_rows, double *sspart, int *nb, int *nss, int grid_hint, int rdst = 0,
-                      bool src_padded = false, const SliceTail *tail = nullptr, bool *tail_used = nullptr) {
+                      bool src_padded = false, const SliceTail *tail = nullptr, bool *tail_used = nullptr,
+                      bool *upd_done = nullptr) {
+    // *upd_done: the tail ran the component update as well (tail->upd set by the caller and the shape has room for it)
     // tail (cnt, red, npush, seq, peers set by the caller): sum the partial rows inside the launch (slice_tail) when the
     // grid is large enough; *tail_used tells the caller whether reduce_partials_kernel is still to run
     // src_padded: X is the library's own copy, whose rows up to the next multiple of V exist and hold zeros -- the sweep
@@ -1218,6 +1376,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
     const i64 Nf = src_padded ? (N + V - 1) / V * V : N - N % V;  // whole row packs; the rest is the tail kernel's
     i64 grid = 0;
     if (tail_used) *tail_used = false;
+    if (upd_done) *upd_done = false;
     if (Nf > 0) {
         const i64 ntiles = (Nf + R - 1) / R;
         // Workgroups per CU.  Read-only passes: two (5 % faster than one on the caller's column-major X).  Read+write
@@ -1236,6 +1395,13 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
             st = *tail;
             st.nrows = (int)grid + (Nf < N ? 1 : 0);
             if (tail_used) *tail_used = true;
+            // the update in the tail: its block sums and p_j^T w products take the score exchange buffer (2 NW R doubles)
+            if (st.upd.XY && upd_done && K <= UPD1_VTHREADS && 2 * (NT / WAVE) * R >= UPD1_VWAVES + st.upd.A) {
+                *upd_done = true;
+            } else {
+                st.upd.XY = nullptr;
+                st.gx.n = 0;
+            }
         }
         if (Nf < N) {  // the last N % V rows FIRST: their partial row (index `grid`) is complete when the sweep's tail sums the rows
             TailArgs<T> a;
@@ -1256,12 +1422,32 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         // 0.752 -> 0.772 / 0.774 -> 0.787 of peak on two boxes, an eighth of it 0.723 -> 0.736, config 4 0.784 -> 0.799, a
         // shard of config 5 0.773 -> 0.786 -- while 64 x 64 cycles already cost one box 2 % (profiles/r4/pace_sweep_*.txt).
         const bool tiled = defl && edge == 0 && rdst == 0 && ldx == R && ldd == R && tsx == (i64)R * K && tsd == (i64)R * K;
+        // Shares of the tiles by XCD class (kernel comment, "weighted walk"): read+write sweeps at one workgroup per CU -- the
+        // odd XCDs take rho times as long per tile (measured 1.05-1.10 over configs 3, 4, 5: profiles/r5/pass_stamps_shapes.txt)
+        // (bit 16 of the pacing word: the operand vectors go to LDS behind the first tile's loads -- 191.5 -> 190.0 us per component
+        // on an eighth of config 3, nothing at full size; pacing stays at 32 x 64 cycles per 128 KB tile on a shard too: 16 / 8 / 0
+        // cost it 1.6 / 2.6 / 3.5 us per component -- profiles/r5/small_pass.txt)
+        WalkWeights wk;
+        {
+            // rho 1.0 / 1.05 / 1.08 / 1.11 on one box: config 3 707.4 / 711.5 / 713.7 / 713.2 components/s, an eighth of it 193.3 /
+            // 193.7 / 191.0 / 191.7 us per component, config 4 1,385 / 1,400 / 1,401 / 1,400, a shard of config 5 176.9 / 177.6 /
+            // 178.6 / 178.4 (profiles/r5/weights_ab.txt): +1 % -- the slow XCDs catch up once the fast ones are done, the
+            // sweep is bound by what the memory takes in all
+            constexpr double rho = 1.08;
+            constexpr unsigned fast_mask = 0x55u;  // XCDs 0, 2, 4, 6
+            const int nfc = __builtin_popcount(fast_mask);
+            if (defl && per_cu == 1 && grid == (i64)num_cu && grid % 8 == 0 && edge != 2 && ntiles >= 2 * grid) {
+                const double share = (double)ntiles / ((double)grid * (1.0 + (rho - 1.0) * nfc / 8.0));
+                wk.nfull = (int)std::max<i64>(1, std::min<i64>((i64)(share + 0.5), ntiles / grid));
+                wk.mask = fast_mask;
+            }
+        }
         if (CGX > 32 && defl && !tiled) return 1;
 #define FUSED_LAUNCH(CPT_, DEFL_, EDGE_, TILED_, dyn_)                                                                    \
     do {                                                                                                                  \
         auto kfn = &fused_pass_kernel<T, V, R, NT, CPT_, DEFL_, AUX_NT, AUX_NT, false, EDGE_, TILED_>;                   \
         if ((dyn_) > 48 * 1024 && !raise_dynamic_lds(reinterpret_cast<const void *>(kfn), (int)(dyn_))) return 1;         \
-        hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, (TILED_) ? 2 * (CPT_) : 0, N, st); \
+        hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, (TILED_) ? (2 * (CPT_)) | 0x10000 : 0, N, st, wk); \
     } while (0)
 #define FUSED_EDGE(CPT_, DEFL_, dyn_)                                                                                     \
     do {                                                                                                                  \
@@ -1285,7 +1471,7 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
                 auto kfn = edge == 2 ? &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 2>
                                      : (edge == 1 ? &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 1>
                                                   : &fused_pass_kernel<T, V, R, NT, 32, true, AUX_NT, AUX_NT, true, 0>);
-                hipLaunchKernelGGL(kfn, g, b, 0, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, rdst, N, st);
+                hipLaunchKernelGGL(kfn, g, b, 0, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, rdst, N, st, wk);
             } else if (K <= CG * 4) FUSED_CASE(4);
             else if (K <= CG * 8) FUSED_CASE(8);
             else if (K <= CG * 12) FUSED_CASE(12);  // (the in-between shapes: a matrix just above a power-of-two boundary would

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WG) void lm_deflate_kernel(const double *__restrict
 
 // (16 x 16 tiles through LDS; grid = (ceil(M/16), ceil(M/16)), block = (16, 16))
 // C = (A / tr A)^2 in ONE launch: every workgroup forms the trace itself (fixed order: 256 strided sums, wave sums, waves in
-// order -- the same bits in every workgroup), then its 16 x 16 tile of A * A, scaled by 1 / tr^2.  One launch per squaring of the
+// order -- the same bits in every workgroup), then its 16 x 16 tile of (A / tr) * (A / tr).  One launch per squaring of the
 // direction solve instead of three (square, trace, scale): beyond LM_LDS_MAX responses the solve is launch-bound.
 __global__ __launch_bounds__(256) void lm_square_normalised_kernel(const double *__restrict__ Am, int M, double *__restrict__ Cm) {
     __shared__ double ta[16][17], tb[16][17], sm[4];
@@ -57,18 +57,18 @@ __global__ __launch_bounds__(256) void lm_square_normalised_kernel(const double 
     if ((tid & 63) == 0) sm[tid >> 6] = t;
     __syncthreads();
     const double tr = ((sm[0] + sm[1]) + sm[2]) + sm[3];
-    const double sc = 1.0 / (tr * tr);
+    const double sc = 1.0 / tr;  // the OPERANDS are scaled as they are staged: tr^2 or the entries of A * A of an unscaled Gram matrix may leave the fp64 range
     const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
     double s = 0.0;
     for (int k0 = 0; k0 < M; k0 += 16) {
-        ta[ty][tx] = (row < M && k0 + tx < M) ? Am[row + (i64)(k0 + tx) * M] : 0.0;
-        tb[ty][tx] = (k0 + ty < M && col < M) ? Am[(k0 + ty) + (i64)col * M] : 0.0;
+        ta[ty][tx] = (row < M && k0 + tx < M) ? Am[row + (i64)(k0 + tx) * M] * sc : 0.0;
+        tb[ty][tx] = (k0 + ty < M && col < M) ? Am[(k0 + ty) + (i64)col * M] * sc : 0.0;
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) s = fma(ta[ty][kk], tb[kk][tx], s);
         __syncthreads();
     }
-    if (row < M && col < M) Cm[row + (i64)col * M] = s * sc;
+    if (row < M && col < M) Cm[row + (i64)col * M] = s;
 }
 
 // The dominant eigenvector of G (M x M, M <= MMAX = 32) in ONE launch, in LDS: the solver of component_update_body

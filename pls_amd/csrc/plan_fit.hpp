@@ -146,12 +146,12 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // ... and on a matrix whose columns are not 16-byte aligned (ld odd, a base pointer at 8 mod 16): the one-sweep pass can
     // read it (EDGE level 2) but every 256-byte segment then shares a line with its neighbours and the pass runs at 0.52
     // instead of 0.73 of peak; with the copy (formed in the same sweep as X^T Y: retile_xty_kernel) every component reads
-    // aligned tiles.  Costs one write of X; pays from the fourth component on (PLS_HIP_COPY_MIN).
+    // aligned tiles.  Costs one write of X; pays from the fourth component on (copy_min below).
     constexpr int FVX = 16 / (int)sizeof(T);
     // The same copy pays for ALIGNED matrices once there are enough components: a read-only pass over the tiled copy, one
     // contiguous 128 KB block per tile, runs at 0.85 of peak (0.63 ms at config 3) against 0.72 (0.74 ms) over the caller's
     // column-major matrix in 256-byte segments; the copy costs 0.86 ms more than the X^T Y pass it replaces
-    // (PLS_HIP_COPY_MIN_ALIGNED, default 10 components).
+    // (copy_min_al below: 10 components).
     // Beyond 512 columns the direct pass (32 columns per lane, one workgroup per CU) already reads at 0.81 of peak and the
     // copy only pays from ~30 components on (one shard of config 5: 2.65 -> 2.52 ms per pass against 4.1 ms for the copy).
     constexpr int copy_min = 4, copy_min_al = 10;
@@ -162,7 +162,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // column groups of the short tiles of a wide matrix (1024 < K <= 4096): 16 columns per lane in 128 / 256 groups
     // (8-row fp32 / 4-row fp64 tiles at K <= 4096) -- the register shape of the headline kernel, two workgroups per CU
     // on read-only passes.  Config 4: read+write pass 0.766 -> 0.710 ms (0.70 -> 0.76 of peak), read-only pass
-    // 0.364 -> 0.324 ms (0.74 -> 0.83) against 32 columns per lane in 64 / 128 groups (PLS_HIP_WIDE16=0, the round-1 shape).
+    // 0.364 -> 0.324 ms (0.74 -> 0.83) against 32 columns per lane in 64 / 128 groups (the round-1 shape, deleted in round 4).
     const int wide_groups = fused_fit ? (K <= 32 * 16 ? tall_cg : 64)  // (the copy of a matrix the resident tile covers)
                             : (K <= 128 * 16 ? 128 : (K <= 256 * 16 ? 256 : ((wide_src && (!nipals || wide_only)) ? 512 : 0)));
     if (retile_fit) {  // the copy is optional: without room for it the one-product kernels do the job
@@ -319,11 +319,18 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     int defer_b = 0;         // deferred write-back: index of the stored matrix X_b
     for (int a = 0; a < A; ++a) {
         Range r_comp("component", a);
-        bool tail_used = false;
+        bool tail_used = false, upd_done = false;
         // sharded over the device-side exchange, the one-workgroup update behind the pass: the pass pushes (if its tail
         // runs), the update gathers.  The collective number is drawn only when the pass did push.
         const bool want_push = tail.cnt && xep_ok && update_is_single(K, M, A, a);
+        // one response: the update is the last act of the pass's tail (update_m1.hpp) -- ONE launch per component; sharded
+        // over the device-side exchange the tail pushes, waits for the peers' pushes and updates (other reducers: a call
+        // between the pass and the update, so the update stays a launch of its own)
+        const bool want_upd = tail.cnt && c->env.tail_update && M == 1 && K <= plsk::UPD1_KMAX && update_is_single(K, M, A, a) &&
+                              (!c->reducer || want_push);
         tail.npush = 0;
+        tail.upd = plsk::TailUpdate();
+        tail.gx = plsk::XchgGather();
         if (want_push) {
             const unsigned long long seq = *c->xep.seq + 1;
             const int par = (int)(seq & 1);
@@ -333,6 +340,17 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 tail.peers.slot[j] = c->xep.inbox[j] + ((i64)par * c->xep.n + c->xep.rank) * plsk::XCHG_CAP;
                 tail.peers.flag[j] = c->xep.flags[j] + par * c->xep.n + c->xep.rank;
             }
+            if (want_upd) {
+                plsk::XchgGather &gx = tail.gx;
+                gx.inbox = c->xep.inbox[c->xep.rank] + (i64)par * c->xep.n * plsk::XCHG_CAP;
+                gx.flags = c->xep.flags[c->xep.rank] + par * c->xep.n;
+                gx.n = c->xep.n; gx.cap = plsk::XCHG_CAP; gx.seq = seq;
+                gx.status = c->xep.status; gx.host_status = c->xep.host_status; gx.limit = *c->xep.limit;
+            }
+        }
+        if (want_upd) {
+            tail.upd.XY = XY; tail.upd.W = W; tail.upd.P = P; tail.upd.Q = Q; tail.upd.R = R; tail.upd.vnext = v;
+            tail.upd.A = A; tail.upd.a = a; tail.upd.nipals = nip;
         }
         if (N > 0) {
             bool done = false;
@@ -373,11 +391,11 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     if (mid_cg && a >= 2)  // half-height tiles of the working copy, in place
                         rc = plsk::launch_fused_pass<T, 64>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v,
                                                             tprev, pprev, Tm + (i64)a * ldt, part, (int)prow, sspart,
-                                                            &nb, &nss, (int)c->opt_fused_grid, 0, true, &tail, &tail_used);
+                                                            &nb, &nss, (int)c->opt_fused_grid, 0, true, &tail, &tail_used, &upd_done);
                     else {  // (a == 1 with mid_cg: X in 256-byte segments -> half-height tiles)
 #define TALL_PASS(CG_) plsk::launch_fused_pass<T, CG_>(c->stream, c->num_cu, Xc, ldc, tsc, tprev ? work : nullptr, ldw, tsw, N, K, v, tprev, \
                                                        pprev, Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss,                        \
-                                                       (int)c->opt_fused_grid, (mid_cg && tprev) ? (int)WR : 0, Xc == work, &tail, &tail_used)
+                                                       (int)c->opt_fused_grid, (mid_cg && tprev) ? (int)WR : 0, Xc == work, &tail, &tail_used, &upd_done)
                         rc = tall_cg == 8 ? TALL_PASS(8) : (tall_cg == 16 ? TALL_PASS(16) : TALL_PASS(32));
 #undef TALL_PASS
                     }
@@ -409,7 +427,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                     Scope s(c, PLS_HIP_FAM_FUSED, bytes);
 #define WIDE_PASS(CG_) plsk::launch_fused_pass<T, CG_>(c->stream, c->num_cu, work, ldw, tsw, work, ldw, tsw, N, K, v, tprev, pprev, \
                                                         Tm + (i64)a * ldt, part, (int)prow, sspart, &nb, &nss, (int)c->opt_fused_grid, 0, true, \
-                                                        &tail, &tail_used)
+                                                        &tail, &tail_used, &upd_done)
                     rc = wide_cg == 8 ? WIDE_PASS(8) : (wide_cg == 16 ? WIDE_PASS(16) : (wide_cg == 32 ? WIDE_PASS(32)
                          : (wide_cg == 64 ? WIDE_PASS(64) : (wide_cg == 128 ? WIDE_PASS(128) : (wide_cg == 256 ? WIDE_PASS(256) : WIDE_PASS(512))))));
 #undef WIDE_PASS
@@ -468,7 +486,9 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         } else {
             HIPCHK(c, hipMemsetAsync(red, 0, (size_t)plsk::RED_SLICES * (K + 1) * 8, c->stream));
         }
-        if (tail_used && want_push) {  // pushed from the tail of the pass: gather in the prologue of the update
+        if (upd_done) {  // the tail of the pass was the update as well (sharded: its push and gather too)
+            if (want_push) ++*c->xep.seq;
+        } else if (tail_used && want_push) {  // pushed from the tail of the pass: gather in the prologue of the update
             const unsigned long long seq = ++*c->xep.seq;
             const int par = (int)(seq & 1);
             plsk::XchgGather gx;

@@ -47,6 +47,15 @@ extern "C" {
 
 int pls_hip_abi_version(void) { return PLS_HIP_ABI_VERSION; }
 
+#ifdef PLS_HIP_TESTING
+// testing/libpls_hip.so only (not in include/pls_hip.h): 4 wall-clock stamps per workgroup of the fused passes that follow go
+// to `buf` (device memory, 64 bytes per workgroup (4 stamps, XCC_ID, HW_ID); nullptr: off)
+__attribute__((visibility("default"))) int pls_hip_test_set_pass_stamps(void *buf) {
+    unsigned long long *p = (unsigned long long *)buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(plsk::g_pass_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int pls_hip_create(pls_hip_handle *out, int device, void *stream) {
     if (!out) return PLS_HIP_ERR_INVALID;
     *out = nullptr;
@@ -66,6 +75,10 @@ int pls_hip_create(pls_hip_handle *out, int device, void *stream) {
         c->env.tiny = !off("PLS_HIP_TINY");
         c->env.cv_refit = on("PLS_HIP_CV_REFIT");
         c->env.tail = !off("PLS_HIP_TAIL");
+        {
+            const char *e = getenv("PLS_HIP_TAIL");
+            c->env.tail_update = e && atoi(e) >= 2;
+        }
         c->env.replica_guard = !off("PLS_HIP_REPLICA_GUARD");
     }
     c->device = device;

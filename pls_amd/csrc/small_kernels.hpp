@@ -6,6 +6,7 @@
 #include "common.hpp"
 #include "exchange_kernels.hpp"  // XchgGather
 #include "fused_kernels.hpp"     // raw buffer loads with cache-policy bits
+#include "update_m1.hpp"
 #include "stream_kernels.hpp"
 
 namespace plsk {
@@ -419,38 +420,14 @@ __device__ __forceinline__ void component_update_body(const double *__restrict__
         else
             narrow_update<8>(red, nsl, XY, P, Q, Rq, W, K, M, A, a, power_iters, sh);
     } else if (fast) {
-        const double tt = red_sum_n(red, nsl, K + 1, K);
-        const double *ra = Rq + (i64)a * K;
-        double xv[4], pv[4];
-        double part = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = tid + i * UPD_THREADS;
-            xv[i] = (k < K) ? XY[k] : 0.0;
-            pv[i] = (k < K) ? red_sum_n(red, nsl, K + 1, k) / tt : 0.0;
-            part = fma((k < K) ? ra[k] : 0.0, xv[i], part);
-        }
-        const double q = block_sum<UPD_WAVES>(part, sred) / tt;  // q = (r^T XY)/tt  (:428)
-        if (tid == 0) Q[(i64)a] = q;
-        double ssn = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = tid + i * UPD_THREADS;
-            if (k < K) {
-                P[k + (i64)a * K] = pv[i];
-                xv[i] -= (pv[i] * q) * tt;  // XY -= (p q^T) tt  (:429)
-                XY[k] = xv[i];
-                ssn = fma(xv[i], xv[i], ssn);
-            }
-        }
-        if (a + 1 >= A) return;
-        const double nrm = sqrt(block_sum<UPD_WAVES>(ssn, sred));  // w = XY / |XY|  (:404, :411)
-        double *w1 = W + (i64)(a + 1) * K;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = tid + i * UPD_THREADS;
-            if (k < K) w1[k] = xv[i] / nrm;
-        }
+        // one response: the arithmetic shared with the tail of the fused pass (update_m1.hpp) -- q, p, the XY deflation, w, r
+        if (K <= UPD1_VTHREADS)
+            update_m1<UPD_THREADS, 1>([&](int j) { return red_sum_n(red, nsl, K + 1, j); }, XY, W, P, Q, R, vnext, K, A, a, nipals,
+                                      split_rotate, cs, sred, (double *)nullptr);
+        else
+            update_m1<UPD_THREADS, 4>([&](int j) { return red_sum_n(red, nsl, K + 1, j); }, XY, W, P, Q, R, vnext, K, A, a, nipals,
+                                      split_rotate, cs, sred, (double *)nullptr);
+        return;
     } else if (a < 0) {
         if (red)
             for (int j = tid; j < K * M; j += UPD_THREADS) XY[j] = red_sum_n(red, nsl, K * M, j);
@@ -486,7 +463,7 @@ __device__ __forceinline__ void component_update_body(const double *__restrict__
     __syncthreads();  // XY complete (same workgroup: its own global stores are visible)
 
     double *wn = W + (i64)n * K;
-    if (fast || narrow) {
+    if (narrow) {
         // w_n already written above
     } else if (M == 1) {
         double ss = 0.0;

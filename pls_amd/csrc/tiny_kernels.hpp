@@ -109,7 +109,7 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
     const TinyShape shp(N);
     const int s = wv / shp.wps, rb = wv % shp.wps, i = rb * WAVE + lane;
     const bool act = s < shp.S && i < N;
-    const int k = tid;  // the column this thread owns in everything K-sized (K <= 448)
+    const int k = tid;  // the column this thread owns in everything K-sized (K <= TINY_KMAX = 416)
     const bool kok = k < K;
     // r in slice-major order, vsl[s*TINY_RC + j] = r[s + j*S]: one LDS base address per thread and immediate
     // offsets (indexed as r[s + j*S] the compiler keeps 28 addresses per lane -- and spills them)

@@ -219,7 +219,7 @@ struct PLS::Model::Resident {
 namespace PLS {
 
 // Extension (no upstream counterpart): which GPUs the Models created from now on use -- {0, 1, 2, 3} = those devices, an
-// ordinal may repeat (virtual shards), {} = back to the PLS_HIP_DEVICES / PLS_HIP_DEVICE environment.  Existing Models keep
+// ordinal may repeat (virtual shards), {} = back to the PLS_HIP_DEVICES environment.  Existing Models keep
 // the context they were built on.
 void set_devices(const std::vector<int> &devices) {
     {

@@ -141,7 +141,8 @@ def test_bench_falls_back_when_the_exchange_fails_in_the_fits():
     time limit and the fits come back poisoned -- the ranks must agree on that, drop the exchange, take the torch reducer,
     measure again and still print the one line, which names what happened."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", PLS_HIP_XCHG_TIMEOUT_S="1.5", PLS_HIP_TEST_DROP_PUSH="1:2")  # (collective 1 is the self-test)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", PLS_HIP_XCHG_TIMEOUT_S="1.5", PLS_HIP_TEST_DROP_PUSH="1:2",
+               PLS_AMD_LIBRARY=os.path.join(ROOT, "pls_amd", "csrc", "testing", "libpls_hip.so"))  # (collective 1 is the self-test)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--workload", "tiny", "--backend", "gloo", "--reducer", "ipc", "--no-alt"], capture_output=True, text=True,
                        timeout=600, env=env)

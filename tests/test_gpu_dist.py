@@ -387,7 +387,8 @@ def test_sharded_fit_over_the_ipc_exchange(world, splits, algo, method):
 
 def _ipc_timeout_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      PLS_HIP_XCHG_TIMEOUT_S="1.5", PLS_HIP_TEST_DROP_PUSH="1:4")
+                      PLS_HIP_XCHG_TIMEOUT_S="1.5", PLS_HIP_TEST_DROP_PUSH="1:4",
+                      PLS_AMD_LIBRARY=os.path.join(ROOT, "pls_amd", "csrc", "testing", "libpls_hip.so"))
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist

@@ -217,7 +217,7 @@ out = g.fit(X, Y, A)          # sequence numbers start over; the injected collec
 print("refit", po.rel_fro(out["B"], Bref) < 1e-10)
 ''' % root
     env = dict(os.environ, PLS_HIP_GROUP_EXCHANGE="device", GPU_MAX_HW_QUEUES="16", PLS_HIP_XCHG_TIMEOUT_S="1.5",
-               PLS_HIP_TEST_DROP_PUSH="1:4")
+               PLS_HIP_TEST_DROP_PUSH="1:4", PLS_AMD_LIBRARY=os.path.join(root, "pls_amd", "csrc", "testing", "libpls_hip.so"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "error 5" in r.stdout and "refit True" in r.stdout, r.stdout[-1500:]
