@@ -396,53 +396,170 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
     }
 }
 
+
+// ---- TWO diagonal blocks per workgroup (round 5) ------------------------------------------------------------------------------
+// A diagonal block alone gives its eight waves 5 + 4 tiles (36 of 64) with 7 operand reads per 5 MFMAs and X^T Y as VALU work on
+// LDS data of its own: 0.63 of the matrix pipe on 27 % of config 3's tiles, and its row splits never balance exactly against
+// the full blocks'.  Here a workgroup takes the diagonal blocks ba and bb TOGETHER -- both panels in LDS, exactly the LDS-DMA
+// stream of an off-diagonal workgroup -- and wave w computes row w of the upper triangle of ba (tiles (w, w..7): 8 - w of them)
+// and row 7 - w of bb's (w + 1 tiles): NINE tiles for every wave, 9 operand reads per step (the diagonal tile's two operands are
+// the same register).  X^T Y costs no read of X at all: a wave's two ROW operands are the X values (row kk + lq, column 16 w + li)
+// and (.., 16 (7 - w) + li) that X^T Y needs, every row tile of the two panels is the row operand of exactly one wave, so
+// X^T Y = one broadcast LDS read of Y and two FMAs per response and 4-row step, summed over the four lq lane groups at the end.
+// MT: responses the instantiation carries accumulators for (0: no X^T Y).
+template <typename T, int MT>
+__device__ __forceinline__ void syrk8_dd_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int ba, int bb, i64 s0, int nsplit,
+                                              const T *__restrict__ zeros, double *__restrict__ out, const T *__restrict__ Y, i64 ldy,
+                                              int M, double *__restrict__ xy_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
+    T *lds = reinterpret_cast<T *>(slab_raw);
+    constexpr int V = 16 / sizeof(T), RB = 8 * V, CS = 8 * V, PANEL = SYRK_TB * CS;
+    constexpr int NT9 = 9;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int fl = li >> 1;
+    const int scol = lane >> 3, spos = lane & 7;
+    const int na = 8 - wv;  // tiles of panel A: (wv, wv .. 7); the other NT9 - na of panel B: (7 - wv, 7 - wv .. 7)
+    const int rb = 7 - wv;
+    f64x4 acc[NT9];
+#pragma unroll
+    for (int t = 0; t < NT9; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    double accy[2][MT > 0 ? MT : 1];
+#pragma unroll
+    for (int m = 0; m < (MT > 0 ? MT : 1); ++m) accy[0][m] = accy[1][m] = 0.0;
+    i64 s, nslabs;
+    syrk8_slab_range(N, RB, s0, nsplit, s, nslabs);
+    auto issue = [&](i64 s, int buf) {
+        syrk8_dma<T>(lds, buf, X, ldx, N, K, ba, bb, false, s, zeros, wv, scol, spos);
+        if constexpr (MT > 0) {
+            if (wv == 0) {
+                const int m = lane >> 3, pos = lane & 7;
+                const i64 row = s * RB + (i64)pos * V;
+                const T *gy = (row < N && m < M) ? Y + row + (i64)m * ldy : zeros;
+                glds16(gy, lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS));
+            }
+        }
+    };
+    int buf = 0;
+    if (s < nslabs) issue(s, 0);
+    for (; s < nslabs; ++s, buf ^= 1) {
+        __syncthreads();
+        const T *As = lds + (size_t)buf * 2 * PANEL, *Bs = As + PANEL;
+        const T *Ys = lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS);
+        if (s + 1 < nslabs) issue(s + 1, buf ^ 1);
+#pragma unroll
+        for (int kk = 0; kk < RB; kk += 4) {
+            const int r = kk + lq;
+            const int off = (((r / V) ^ fl) * V) + (r % V);
+            const double opa = (double)As[(16 * wv + li) * CS + off], opb = (double)Bs[(16 * rb + li) * CS + off];
+            double b[NT9];
+#pragma unroll
+            for (int t = 1; t < NT9; ++t) {  // (tile 0 is the diagonal tile of row wv: both operands are opa)
+                const bool inA = t < na;
+                const int col = inA ? wv + t : rb + (t - na);
+                b[t] = (double)(inA ? As : Bs)[(16 * col + li) * CS + off];
+            }
+            // (the first tile of the B segment, t == na, is bb's diagonal tile: its column operand equals opb -- the read above
+            // fetched the same element again, which costs less than a select in every tile)
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(opa, opa, acc[0], 0, 0, 0);
+#pragma unroll
+            for (int t = 1; t < NT9; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((t < na) ? opa : opb, b[t], acc[t], 0, 0, 0);
+            if constexpr (MT > 0) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const double y = (double)Ys[(m * 8 + r / V) * V + r % V];  // (responses >= M: zeros came with the DMA)
+                    accy[0][m] = fma(opa, y, accy[0][m]);
+                    accy[1][m] = fma(opb, y, accy[1][m]);
+                }
+            }
+        }
+    }
+    if constexpr (MT > 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const double sum = xor_range_sum<16, 64>(accy[h][m]);  // over the four lq groups
+                const int col = (h == 0 ? ba * SYRK_TB + 16 * wv : bb * SYRK_TB + 16 * rb) + li;
+                if (lq == 0 && m < M && col < K) xy_out[col + (i64)m * K] = sum;
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < NT9; ++t) {
+        const bool inA = t < na;
+        const int blk = inA ? ba : bb, ti = inA ? wv : rb, tj = inA ? wv + t : rb + (t - na);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ga_ = blk * SYRK_TB + 16 * ti + lq + 4 * r;
+            const int gb_ = blk * SYRK_TB + 16 * tj + li;
+            if (ga_ < K && gb_ < K) {
+                const double v = acc[t][r];
+                out[ga_ + (i64)gb_ * K] = v;
+                out[gb_ + (i64)ga_ * K] = v;
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(512, 4) void syrk_glds8_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, int nbk,
                                                             const T *__restrict__ zeros, double *__restrict__ part, int so, int sd,
-                                                            const T *__restrict__ Y, i64 ldy, int M, double *__restrict__ xypart) {
+                                                            const T *__restrict__ Y, i64 ldy, int M, double *__restrict__ xypart,
+                                                            int pairs) {
     // (Round 4: starting half of the workgroups late -- the second half of the grid, odd ids, or every second group of 8, by
     // 16 ... 96 x 64 cycles -- so that the two workgroups of a CU do not sit at their slab barriers together: no effect,
     // 4.91-4.96 ms in all 18 combinations, profiles/r4/syrk_stagger.txt.)
-    // 1-D grid, exactly the workgroups that have rows: first so splits of every off-diagonal block, then sd of every diagonal
-    // block (workgroups that only exit still take a dispatch slot: a 2-D grid with idle members ran 7.8 ms instead of 6.1).  A
+    // 1-D grid, exactly the workgroups that have rows: first so splits of every off-diagonal block, then sd of every PAIR of
+    // diagonal blocks (pairs != 0: blocks 2 p and 2 p + 1 in one workgroup, syrk8_dd_body), then sd of every diagonal block left
+    // (workgroups that only exit still take a dispatch slot: a 2-D grid with idle members ran 7.8 ms instead of 6.1).  A
     // diagonal block has fewer partials than the so the reduction sums: its workgroup j also zeroes the slots j + sd, ... < so.
-    const int ndiag = nbk, noff = nbk * (nbk + 1) / 2 - nbk;
-    int id = blockIdx.x, split, blk;
-    bool diag;
+    const int npair = pairs ? nbk / 2 : 0, nsingle = nbk - 2 * npair, noff = nbk * (nbk + 1) / 2 - nbk;
+    int id = blockIdx.x, split, blk, kind;  // kind 0: off-diagonal, 1: a pair of diagonal blocks, 2: one diagonal block
     if (id < noff * so) {
-        diag = false;
+        kind = 0;
         blk = id % noff;
         split = id / noff;
-    } else {
-        diag = true;
+    } else if (id < noff * so + npair * sd) {
+        kind = 1;
         id -= noff * so;
-        blk = id % ndiag;
-        split = id / ndiag;
-    }
-    int bi, bj;
-    if (diag) {
-        bi = bj = blk;
+        blk = id % npair;
+        split = id / npair;
     } else {
-        bi = 0;
-        int rem = blk;
-        while (rem >= nbk - 1 - bi) { rem -= nbk - 1 - bi; ++bi; }
-        bj = bi + 1 + rem;
+        kind = 2;
+        id -= noff * so + npair * sd;
+        blk = 2 * npair + id % nsingle;
+        split = id / nsingle;
     }
     double *out = part + (i64)split * ((i64)K * K);
-    if (diag) {
-        for (int z = split + sd; z < so; z += sd) {
-            double *zo = part + (i64)z * ((i64)K * K);
-            for (int e = threadIdx.x; e < SYRK_TB * SYRK_TB; e += 512) {
-                const int ga_ = bi * SYRK_TB + (e & (SYRK_TB - 1)), gb_ = bj * SYRK_TB + e / SYRK_TB;
-                if (ga_ < K && gb_ < K) zo[ga_ + (i64)gb_ * K] = 0.0;
+    if (kind != 0) {
+        for (int q = 0; q < (kind == 1 ? 2 : 1); ++q) {
+            const int bz = kind == 1 ? 2 * blk + q : blk;
+            for (int z = split + sd; z < so; z += sd) {
+                double *zo = part + (i64)z * ((i64)K * K);
+                for (int e = threadIdx.x; e < SYRK_TB * SYRK_TB; e += 512) {
+                    const int ga_ = bz * SYRK_TB + (e & (SYRK_TB - 1)), gb_ = bz * SYRK_TB + e / SYRK_TB;
+                    if (ga_ < K && gb_ < K) zo[ga_ + (i64)gb_ * K] = 0.0;
+                }
             }
         }
+    }
+    double *xyo = xypart + (i64)split * ((i64)K * M);
+    if (kind == 1) {
+        if (!Y) syrk8_dd_body<T, 0>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, nullptr, 0, 0, nullptr);
+        else if (M <= 1) syrk8_dd_body<T, 1>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, Y, ldy, M, xyo);
+        else if (M <= 4) syrk8_dd_body<T, 4>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, Y, ldy, M, xyo);
+        else syrk8_dd_body<T, 8>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, Y, ldy, M, xyo);
+    } else if (kind == 2) {
         if (Y)
-            syrk8_diag_body<T, true>(X, ldx, N, K, bi, split, sd, zeros, out, Y, ldy, M, xypart + (i64)split * ((i64)K * M));
+            syrk8_diag_body<T, true>(X, ldx, N, K, blk, split, sd, zeros, out, Y, ldy, M, xyo);
         else
-            syrk8_diag_body<T, false>(X, ldx, N, K, bi, split, sd, zeros, out, nullptr, 0, 0, nullptr);
+            syrk8_diag_body<T, false>(X, ldx, N, K, blk, split, sd, zeros, out, nullptr, 0, 0, nullptr);
     } else {
-        syrk8_full_body<T>(X, ldx, N, K, bi, bj, split, so, zeros, out);
+        int bi = 0, rem = blk;
+        while (rem >= nbk - 1 - bi) { rem -= nbk - 1 - bi; ++bi; }
+        syrk8_full_body<T>(X, ldx, N, K, bi, bi + 1 + rem, split, so, zeros, out);
     }
 }
 
@@ -487,24 +604,32 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         // workgroup balance coarsely -- K = 2048: 136 blocks, 3 + 2 splits, 392 of 512 slots, 0.58 of the matrix pipe -- while eight
         // waves of workgroups balance themselves and have few diagonal blocks among many: K = 1024 0.77 -> 0.80, 1280 0.68 -> 0.80,
         // 1536 0.65 -> 0.81, 2048 0.58 -> 0.82 (profiles/r4/syrk_scan.txt)
-        const double dw = fuse_y0 ? (M == 1 ? 0.74 : 0.82) : 0.66;
-        if (nblocks <= slots && (i64)(slots / ((nblocks - nbk) + dw * nbk)) >= 16) {
+        // Diagonal blocks in PAIRS (syrk8_dd_body: 72 tiles per workgroup and slab against a full block's 64, nine reads per nine
+        // MFMAs against six per eight): a pair weighs dw2 full blocks, a diagonal block left over (odd block count) rides with
+        // the pairs' row splits.
+        static const int exp_pairs = getenv("PLS_HIP_EXP_SYRK_PAIRS") ? atoi(getenv("PLS_HIP_EXP_SYRK_PAIRS")) : 1;  // EXPERIMENT
+        static const double exp_dw2 = getenv("PLS_HIP_EXP_SYRK_DW2") ? atof(getenv("PLS_HIP_EXP_SYRK_DW2")) : 1.25;  // EXPERIMENT
+        const int pairs = (exp_pairs && nbk >= 2) ? 1 : 0;
+        const int npair = pairs ? nbk / 2 : 0, nsingle = nbk - 2 * npair;
+        const i64 ndunits = pairs ? npair + nsingle : nbk;  // workgroup kinds on the diagonal, per row split
+        const double dw = pairs ? 1.0 / exp_dw2 : (fuse_y0 ? (M == 1 ? 0.74 : 0.82) : 0.66);
+        if (nblocks <= slots && (i64)(slots / ((nblocks - nbk) + dw * ndunits)) >= 16) {
             // measured optima of the row-split weight (profiles/r3/syrk_diagonal_weight_sweep.txt): 0.74 with X^T Y of one
             // response on board, 0.82 for several, 0.66 without
-            const double units = (nblocks - nbk) + dw * nbk;
+            const double units = (nblocks - nbk) + dw * ndunits;
             Sg = (i64)(slots / units);
             Sd = std::max<i64>(1, (i64)(dw * Sg));
-            while ((nblocks - nbk) * Sg + nbk * Sd > slots && Sg > 1) { --Sg; Sd = std::max<i64>(1, (i64)(dw * Sg)); }
+            while ((nblocks - nbk) * Sg + ndunits * Sd > slots && Sg > 1) { --Sg; Sd = std::max<i64>(1, (i64)(dw * Sg)); }
         }
         Sg = std::max<i64>(1, std::min<i64>(Sg, nslabs_g));
         Sg = std::min<i64>(Sg, part_capacity_doubles / ((i64)K * K));
         if (Sg < 1) return 1;
         Sd = Sd ? std::min<i64>(Sd, Sg) : Sg;
         if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_glds8_kernel<T>), (int)LDS_G)) return 1;
-        const i64 nwg8 = (i64)(nblocks - nbk) * Sg + (i64)nbk * Sd;
+        const i64 nwg8 = (i64)(nblocks - nbk) * Sg + ndunits * Sd;
         const bool fuse_y8 = fuse_y0 && Sd * (i64)K * M <= xypart_capacity_doubles;
         hipLaunchKernelGGL(syrk_glds8_kernel<T>, dim3((unsigned)nwg8), dim3(512), LDS_G, stream, X, ldx, N, K, nbk,
-                           static_cast<const T *>(zeros), part, (int)Sg, (int)Sd, fuse_y8 ? Y : nullptr, ldy, M, xypart);
+                           static_cast<const T *>(zeros), part, (int)Sg, (int)Sd, fuse_y8 ? Y : nullptr, ldy, M, xypart, pairs);
         if (fuse_y8) *nb_xy = (int)Sd;
         *nb = (int)Sg;
         return 0;

@@ -29,8 +29,9 @@ def _split(N, world, rank, splits):
     return sum(splits[:rank]), splits[rank]
 
 
-def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0, splits=None, reducer="torch"):
+def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0, splits=None, reducer="torch", env=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(env or {})
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -69,13 +70,13 @@ def _worker(rank, world, port, N, K, M, A, algo, fuse, q, method=0, splits=None,
         dist.destroy_process_group()
 
 
-def _run(world, N, K, M, A, algo, fuse, method=0, splits=None, timeout=180, reducer="torch"):
+def _run(world, N, K, M, A, algo, fuse, method=0, splits=None, timeout=180, reducer="torch", env=None):
     """spawn `world` ranks sharing the GPU; returns [(rank, outputs)] sorted by rank"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, K, M, A, algo, fuse, q, method, splits, reducer))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, K, M, A, algo, fuse, q, method, splits, reducer, env))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -383,6 +384,32 @@ def test_sharded_fit_over_the_ipc_exchange(world, splits, algo, method):
         T = np.concatenate([out["T"] for _, out in res], axis=0)
         G = T.T @ T
         assert np.abs(G - np.diag(np.diag(G))).max() < 1e-9 * np.diag(G).max()
+
+
+@pytest.mark.parametrize("tail", ["1", "2"], ids=["update-kernel", "update-in-the-tail"])
+@pytest.mark.parametrize("splits,algo", [([8192 + 64, 8192 - 64], 1), ([12288, 512, 0, 3584], 1), ([16000, 384], 0)],
+                         ids=["2ranks-nipals", "4ranks-small-and-empty-shards-nipals", "2ranks-one-small-kernel"])
+def test_sharded_one_response_routes_agree_bit_for_bit(splits, algo, tail):
+    """One response over the device-side exchange.  The ranks of one fit may take DIFFERENT routes through a component: a
+    shard of 32 tiles or more sums its partial rows in the tail of the pass and pushes from there (PLS_HIP_TAIL=2: it also waits
+    for the peers and runs the update there -- one launch per component), a smaller one goes pass -> reduce -> exchange -> update
+    kernel, an empty one has no pass at all.  The one-response update is ONE piece of arithmetic for all of them
+    (update_m1.hpp), so the replicas must agree bit for bit -- the library's own guard checks it too -- and with the oracle."""
+    from oracle import pls_oracle as po
+    N, K, M, A = sum(splits), 192, 1, 7
+    res = _run(len(splits), N, K, M, A, algo, 1, splits=splits, reducer="ipc", env={"PLS_HIP_TAIL": tail})
+    ora = po.OracleLib()
+    Xh, Yh = ora.synth_x(0, N, K), ora.synth_y(0, N, M)
+    ref = ora.plsr(Xh, Yh, A)
+    Bref = ora.coefficients(ref["R"], ref["Q"])
+    for rank, out in res:
+        assert po.rel_fro(out["B"], Bref) < 1e-10, rank
+        for k in "WPQRB":
+            assert np.array_equal(out[k], res[0][1][k]), (rank, k)
+    T = np.concatenate([out["T"] for _, out in res], axis=0)
+    for a in range(A):
+        s = np.sign(T[:, a] @ ref["T"][:, a])
+        assert po.rel_fro(s * T[:, a], ref["T"][:, a]) < 1e-9, a
 
 
 def _ipc_timeout_worker(rank, world, port, q):

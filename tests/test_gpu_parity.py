@@ -5,12 +5,14 @@ star's bar); W,P,Q,R,T compared per component modulo sign (the reference leaves 
 sign open) within 1e-9.  Integer/bit-exact checks: the synthetic generator.
 """
 import glob
+import subprocess
+import sys
 import os
 
 import numpy as np
 import pytest
 
-from conftest import handle_with_env, DATA, GOLDEN
+from conftest import handle_with_env, DATA, GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -191,6 +193,31 @@ def test_x_not_modified_and_deterministic(handle, oracle, po, mode):
     assert _torch().equal(X, X0), "the caller's X must never be written (const at the API, pls.h:188)"
     for k in "WPQRTB":  # fixed-order reductions: bit-identical run to run
         assert _torch().equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("N,K,A,dt,algo", [(32 * 300, 512, 9, "f64", 1), (32 * 300 + 1, 200, 6, "f64", 1), (64 * 90, 1000, 5, "f32", 1),
+                                           (32 * 64, 100, 4, "f64", 0), (16 * 300, 1024, 4, "f64", 1)])
+def test_one_response_update_routes_bit_identical(N, K, A, dt, algo):
+    """PLS_HIP_TAIL = 0 / 1 / 2: partial rows summed by reduce_partials_kernel, in the tail of the pass, and with the one-response
+    component update as the last act of that tail (one launch per component).  Same sums in the same order, one piece of update
+    arithmetic (update_m1.hpp): W, P, Q, R, T, B equal bit for bit."""
+    code = '''
+import sys, hashlib
+sys.path.insert(0, %r)
+import torch, pls_amd
+h = pls_amd.Handle()
+h.set_option(pls_amd.OPT_ALGO, %d)
+dt = torch.float64 if %r == "f64" else torch.float32
+X = h.synth_x(0, %d, %d, 77, dtype=dt); Y = h.synth_y(0, %d, 1, 77, dtype=dt)
+out = h.fit_device(X, Y, %d); h.synchronize()
+print("DIGEST", hashlib.sha256(b"".join(out[k].cpu().numpy().tobytes() for k in "WPQRTB")).hexdigest())
+''' % (ROOT, algo, dt, N, K, N, A)
+    digests = []
+    for tail in ("0", "1", "2"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PLS_HIP_TAIL=tail), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert digests[0] == digests[1] == digests[2], digests
 
 
 @pytest.mark.parametrize("N,K,M,A,dt", [(3000, 96, 3, 7, "f64"), (4098, 513, 1, 5, "f64"), (32 * 700 + 2, 40, 2, 4, "f64"),
