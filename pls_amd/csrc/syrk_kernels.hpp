@@ -191,36 +191,104 @@ __device__ __forceinline__ void syrk8_slab_range(i64 N, int RB, i64 split, int n
     end = min(nall, first + per);
 }
 
+// Arguments of an out-of-line device function arrive in VECTOR registers: the compiler no longer knows that they are the same
+// in every lane, keeps the slab counter and every pointer derived from them per lane, and wraps each buffer instruction whose
+// descriptor it cannot prove uniform in a read-first-lane loop.  uni() hands the value back as a scalar.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ i64 uni(i64 x) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x & 0xffffffffll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)x >> 32));
+    return (i64)(((unsigned long long)hi << 32) | lo);
+}
+template <typename P>
+__device__ __forceinline__ P *uni(P *p) { return reinterpret_cast<P *>(uni((i64)reinterpret_cast<uintptr_t>(p))); }
+
+// The LDS-DMA of one slab through BUFFER descriptors (round 5): buffer_load_dwordx4 ... lds.  A wave's two DMA instructions per
+// panel cover the column groups i = wv and wv + 8 (8 columns each); one descriptor per (panel, group) -- base = the group's first
+// column, num_records = its columns that exist x ldx -- lives in scalar registers for the whole slab loop, the lane's offset
+// (column inside the group, swizzled row position) in ONE vector register per group, and the slab's row offset rides in the
+// instruction's scalar offset.  No 64-bit address arithmetic per slab, no select against a zero block: columns >= K are out of
+// range (zeros), rows >= N get an out-of-range lane offset.  (With global_load_lds the pointers cost the loop 8-16 vector
+// registers -- the difference between the nine-tile diagonal body fitting its 128 registers and reloading spilled addresses
+// behind s_waitcnt vmcnt(0), i.e. behind the NEXT slab's DMA, in every 4-row step.)
+constexpr int SYRK_BUF_WORD3 = 0x00020000;  // raw buffer, 32-bit data format, stride 0 (fused_kernels.hpp: BUF_WORD3)
 template <typename T>
-__device__ __forceinline__ void syrk8_dma(T *lds, int buf, const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, int bj, bool diag,
-                                          i64 s, const T *__restrict__ zeros, int wv, int scol, int spos) {
-    constexpr int V = 16 / sizeof(T), RB = 8 * V, CS = 8 * V, PANEL = SYRK_TB * CS;
-    T *Ab = lds + (size_t)buf * 2 * PANEL, *Bb = Ab + PANEL;
+struct SyrkDma {
+    __amdgpu_buffer_rsrc_t ra[2], rb[2];  // panels A and B, column groups wv and wv + 8
+    uint32_t voff[2];                     // the lane's byte offset inside its group
+    uint32_t rowq[2];                     // V x its swizzled row position (for the rows >= N test)
+};
+template <typename T>
+__device__ __forceinline__ SyrkDma<T> syrk8_dma_setup(const T *__restrict__ X, i64 ldx, int K, int bi, int bj, int wv, int scol, int spos) {
+    constexpr int V = 16 / sizeof(T);
+    SyrkDma<T> d;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = wv + 8 * j;
         const int col = 8 * i + scol;
         const int q = spos ^ ((col >> 1) & 7);
-        const i64 row = s * RB + (i64)q * V;
-        const bool ok = row < N;
-        const int ca = min(bi * SYRK_TB + col, K - 1);
-        glds16(ok ? X + row + (i64)ca * ldx : zeros, Ab + i * (8 * CS));
-        if (!diag) {
-            const int cb = min(bj * SYRK_TB + col, K - 1);
-            glds16(ok ? X + row + (i64)cb * ldx : zeros, Bb + i * (8 * CS));
-        }
+        d.voff[j] = (uint32_t)(((i64)scol * ldx + (i64)q * V) * (i64)sizeof(T));
+        d.rowq[j] = (uint32_t)(q * V);
+        const int ca0 = bi * SYRK_TB + 8 * i, cb0 = bj * SYRK_TB + 8 * i;
+        const int na = max(0, min(8, K - ca0)), nb = max(0, min(8, K - cb0));
+        // (everything in a descriptor is wave-uniform; said explicitly, or the buffer instruction is wrapped in a read-first-lane loop)
+        d.ra[j] = __builtin_amdgcn_make_buffer_rsrc(uni(const_cast<T *>(X + (i64)min(ca0, K - 1) * ldx)), (short)0,
+                                                    uni((int)((i64)na * ldx * (i64)sizeof(T))), SYRK_BUF_WORD3);
+        d.rb[j] = __builtin_amdgcn_make_buffer_rsrc(uni(const_cast<T *>(X + (i64)min(cb0, K - 1) * ldx)), (short)0,
+                                                    uni((int)((i64)nb * ldx * (i64)sizeof(T))), SYRK_BUF_WORD3);
+    }
+    return d;
+}
+__device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t r, void *lds_base, uint32_t voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_base, 16, (int)voff, soff, 0, 0);
+#else
+    (void)r; (void)lds_base; (void)voff; (void)soff;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void syrk8_dma(T *lds, int buf, const SyrkDma<T> &d, i64 N, bool diag, i64 s, int wv) {
+    constexpr int V = 16 / sizeof(T), RB = 8 * V, CS = 8 * V, PANEL = SYRK_TB * CS;
+    T *Ab = lds + (size_t)buf * 2 * PANEL, *Bb = Ab + PANEL;
+    const i64 row0 = s * RB;
+    const int soff = (int)(row0 * (i64)sizeof(T));
+    const bool whole = row0 + RB <= N;  // (uniform) every row of the slab exists: all but the last slab of an N % RB != 0 matrix
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = wv + 8 * j;
+        const uint32_t vo = (whole || row0 + d.rowq[j] < N) ? d.voff[j] : 0xFFFFFFF0u;  // rows >= N: out of range, zeros
+        bufdma16(d.ra[j], Ab + i * (8 * CS), vo, soff);
+        if (!diag) bufdma16(d.rb[j], Bb + i * (8 * CS), vo, soff);
     }
 }
 
+// the slab's rows of Y: [response m (8 of them)][8 row positions of 16 bytes]; responses >= M and rows >= N arrive as zeros
 template <typename T>
-__device__ __forceinline__ void syrk8_full_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, int bj, i64 s0, int nsplit,
-                                             const T *__restrict__ zeros, double *__restrict__ out) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t syrk8_y_rsrc(const T *Y, i64 ldy, int M) {
+    return __builtin_amdgcn_make_buffer_rsrc(uni(const_cast<T *>(Y)), (short)0, uni((int)((i64)M * ldy * (i64)sizeof(T))), SYRK_BUF_WORD3);
+}
+template <typename T>
+__device__ __forceinline__ void syrk8_dma_y(T *lds_dst, __amdgpu_buffer_rsrc_t ry, i64 ldy, i64 N, i64 s, int lane) {
+    constexpr int V = 16 / sizeof(T), RB = 8 * V;
+    const int m = lane >> 3, pos = lane & 7;
+    const i64 row = s * RB + (i64)pos * V;
+    const uint32_t vo = row < N ? (uint32_t)(((i64)m * ldy + (i64)pos * V) * (i64)sizeof(T)) : 0xFFFFFFF0u;
+    bufdma16(ry, lds_dst, vo, (int)(s * RB * (i64)sizeof(T)));
+}
+
+// (one out-of-line body per wave index W, as for the paired diagonal blocks below: tile offsets are instruction immediates)
+template <typename T, int W>
+__device__ __noinline__ void syrk8_full_wave(const T *X_, i64 ldx_, i64 N_, int K_, int bi_, int bj_, i64 s0_, int nsplit_, double *out_) {
+    const T *__restrict__ X = uni(X_);
+    double *__restrict__ out = uni(out_);
+    const i64 ldx = uni(ldx_), N = uni(N_), s0 = uni(s0_);
+    const int K = uni(K_), bi = uni(bi_), bj = uni(bj_), nsplit = uni(nsplit_);
     extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
     T *lds = reinterpret_cast<T *>(slab_raw);
     constexpr int V = 16 / sizeof(T), RB = 8 * V, CS = 8 * V, PANEL = SYRK_TB * CS;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int a0 = (W >> 1) * 32, b0 = (W & 1) * 64;
+    const int lane = threadIdx.x & 63;
     const int li = lane & 15, lq = lane >> 4;
-    const int a0 = (wv >> 1) * 32, b0 = (wv & 1) * 64;
     const int fl = li >> 1;
     const int scol = lane >> 3, spos = lane & 7;
     f64x4 acc[2][4];
@@ -231,20 +299,24 @@ __device__ __forceinline__ void syrk8_full_body(const T *__restrict__ X, i64 ldx
     i64 s, nslabs;
     syrk8_slab_range(N, RB, s0, nsplit, s, nslabs);
     int buf = 0;
-    if (s < nslabs) syrk8_dma<T>(lds, 0, X, ldx, N, K, bi, bj, false, s, zeros, wv, scol, spos);
+    const SyrkDma<T> dma = syrk8_dma_setup<T>(X, ldx, K, bi, bj, W, scol, spos);
+    if (s < nslabs) syrk8_dma<T>(lds, 0, dma, N, false, s, W);
     for (; s < nslabs; ++s, buf ^= 1) {
+        // (the slab's DMA must have LANDED: for buffer_load ... lds the compiler does not put the wait in front of the barrier
+        // by itself -- it left vmcnt(3) there, and repeated fits differed: test_race_screen_repeated_fits)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const T *As = lds + (size_t)buf * 2 * PANEL, *Bs = As + PANEL;
-        if (s + 1 < nslabs) syrk8_dma<T>(lds, buf ^ 1, X, ldx, N, K, bi, bj, false, s + 1, zeros, wv, scol, spos);
+        const T *As = lds + (size_t)buf * 2 * PANEL + li * CS, *Bs = As + PANEL;
+        if (s + 1 < nslabs) syrk8_dma<T>(lds, buf ^ 1, dma, N, false, s + 1, W);
 #pragma unroll
         for (int kk = 0; kk < RB; kk += 4) {
             const int r = kk + lq;
             const int off = (((r / V) ^ fl) * V) + (r % V);
             double a[2], b[4];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = (double)As[(a0 + 16 * m + li) * CS + off];
+            for (int m = 0; m < 2; ++m) a[m] = (double)As[(a0 + 16 * m) * CS + off];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = (double)Bs[(b0 + 16 * n + li) * CS + off];
+            for (int n = 0; n < 4; ++n) b[n] = (double)Bs[(b0 + 16 * n) * CS + off];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -265,6 +337,16 @@ __device__ __forceinline__ void syrk8_full_body(const T *__restrict__ X, i64 ldx
                     out[gb_ + (i64)ga_ * K] = v;
                 }
             }
+}
+
+template <typename T>
+__device__ __forceinline__ void syrk8_full_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, int bj, i64 s0, int nsplit,
+                                             const T *__restrict__ zeros, double *__restrict__ out) {
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {  // (wave-uniform: a scalar branch)
+#define FULL_WAVE(W_) case W_: syrk8_full_wave<T, W_>(X, ldx, N, K, bi, bj, s0, nsplit, out); break;
+        FULL_WAVE(0) FULL_WAVE(1) FULL_WAVE(2) FULL_WAVE(3) FULL_WAVE(4) FULL_WAVE(5) FULL_WAVE(6) FULL_WAVE(7)
+#undef FULL_WAVE
+    }
 }
 
 // tile t of the upper triangle of the 8 x 8 tile grid, row by row: (i, j), i <= j
@@ -317,20 +399,20 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
     const int ykey = (yc >> 1) & 7;
     i64 s, nslabs;
     syrk8_slab_range(N, RB, s0, nsplit, s, nslabs);
+    const SyrkDma<T> dma = syrk8_dma_setup<T>(X, ldx, K, bi, bi, wv, scol, spos);
+    const __amdgpu_buffer_rsrc_t ry = syrk8_y_rsrc<T>(Y, ldy, WITH_Y ? M : 0);
     auto issue = [&](i64 s, int buf) {
-        syrk8_dma<T>(lds, buf, X, ldx, N, K, bi, bi, true, s, zeros, wv, scol, spos);
+        syrk8_dma<T>(lds, buf, dma, N, true, s, wv);
         if constexpr (WITH_Y) {
-            if (wv == 0) {
-                const int m = lane >> 3, pos = lane & 7;
-                const i64 row = s * RB + (i64)pos * V;
-                const T *gy = (row < N && m < M) ? Y + row + (i64)m * ldy : zeros;
-                glds16(gy, lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS));
-            }
+            if (wv == 0) syrk8_dma_y<T>(lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS), ry, ldy, N, s, lane);
         }
     };
     int buf = 0;
     if (s < nslabs) issue(s, 0);
     for (; s < nslabs; ++s, buf ^= 1) {
+        // (the slab's DMA must have LANDED: for buffer_load ... lds the compiler does not put the wait in front of the barrier
+        // by itself -- it left vmcnt(3) there, and repeated fits differed: test_race_screen_repeated_fits)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const T *As = lds + (size_t)buf * 2 * PANEL;
         if (s + 1 < nslabs) issue(s + 1, buf ^ 1);
@@ -407,71 +489,70 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
 // and (.., 16 (7 - w) + li) that X^T Y needs, every row tile of the two panels is the row operand of exactly one wave, so
 // X^T Y = one broadcast LDS read of Y and two FMAs per response and 4-row step, summed over the four lq lane groups at the end.
 // MT: responses the instantiation carries accumulators for (0: no X^T Y).
-template <typename T, int MT>
-__device__ __forceinline__ void syrk8_dd_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int ba, int bb, i64 s0, int nsplit,
-                                              const T *__restrict__ zeros, double *__restrict__ out, const T *__restrict__ Y, i64 ldy,
-                                              int M, double *__restrict__ xy_out) {
+// One out-of-line body per WAVE INDEX W: every tile index, LDS offset and operand choice is a compile-time constant (a body
+// with the wave index at run time selects operands per tile and spills 50-100 registers at the 128 four waves per SIMD leave;
+// round 2 found the same for the single diagonal block's patterns).  The waves of a workgroup run different functions with the
+// same slab loop, so they meet at the same barriers.
+template <typename T, int MT, int W>
+__device__ __noinline__ void syrk8_dd_wave(const T *X_, i64 ldx_, i64 N_, int K_, int ba_, int bb_, i64 s0_, int nsplit_, double *out_,
+                                           const T *Y_, i64 ldy_, int M_, double *xy_out_) {
+    const T *__restrict__ X = uni(X_), *__restrict__ Y = uni(Y_);
+    double *__restrict__ out = uni(out_), *__restrict__ xy_out = uni(xy_out_);
+    const i64 ldx = uni(ldx_), N = uni(N_), s0 = uni(s0_), ldy = uni(ldy_);
+    const int K = uni(K_), ba = uni(ba_), bb = uni(bb_), nsplit = uni(nsplit_), M = uni(M_);
     extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
     T *lds = reinterpret_cast<T *>(slab_raw);
     constexpr int V = 16 / sizeof(T), RB = 8 * V, CS = 8 * V, PANEL = SYRK_TB * CS;
-    constexpr int NT9 = 9;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NA = 8 - W, NB = W + 1, RBW = 7 - W;  // tiles (W, W .. 7) of panel A, (RBW, RBW .. 7) of panel B
+    const int lane = threadIdx.x & 63;
     const int li = lane & 15, lq = lane >> 4;
     const int fl = li >> 1;
     const int scol = lane >> 3, spos = lane & 7;
-    const int na = 8 - wv;  // tiles of panel A: (wv, wv .. 7); the other NT9 - na of panel B: (7 - wv, 7 - wv .. 7)
-    const int rb = 7 - wv;
-    f64x4 acc[NT9];
+    f64x4 acca[NA], accb[NB];
 #pragma unroll
-    for (int t = 0; t < NT9; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < NA; ++t) acca[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NB; ++t) accb[t] = f64x4{0.0, 0.0, 0.0, 0.0};
     double accy[2][MT > 0 ? MT : 1];
 #pragma unroll
     for (int m = 0; m < (MT > 0 ? MT : 1); ++m) accy[0][m] = accy[1][m] = 0.0;
     i64 s, nslabs;
     syrk8_slab_range(N, RB, s0, nsplit, s, nslabs);
+    const SyrkDma<T> dma = syrk8_dma_setup<T>(X, ldx, K, ba, bb, W, scol, spos);
+    const __amdgpu_buffer_rsrc_t ry = syrk8_y_rsrc<T>(Y, ldy, MT > 0 ? M : 0);
     auto issue = [&](i64 s, int buf) {
-        syrk8_dma<T>(lds, buf, X, ldx, N, K, ba, bb, false, s, zeros, wv, scol, spos);
-        if constexpr (MT > 0) {
-            if (wv == 0) {
-                const int m = lane >> 3, pos = lane & 7;
-                const i64 row = s * RB + (i64)pos * V;
-                const T *gy = (row < N && m < M) ? Y + row + (i64)m * ldy : zeros;
-                glds16(gy, lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS));
-            }
-        }
+        syrk8_dma<T>(lds, buf, dma, N, false, s, W);
+        if constexpr (MT > 0 && W == 0) syrk8_dma_y<T>(lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS), ry, ldy, N, s, lane);
     };
     int buf = 0;
     if (s < nslabs) issue(s, 0);
     for (; s < nslabs; ++s, buf ^= 1) {
+        // (the slab's DMA must have LANDED: for buffer_load ... lds the compiler does not put the wait in front of the barrier
+        // by itself -- it left vmcnt(3) there, and repeated fits differed: test_race_screen_repeated_fits)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const T *As = lds + (size_t)buf * 2 * PANEL, *Bs = As + PANEL;
+        const T *As = lds + (size_t)buf * 2 * PANEL + li * CS, *Bs = As + PANEL;  // (+ the lane's column inside a tile)
         const T *Ys = lds + (size_t)2 * 2 * PANEL + (size_t)buf * (8 * CS);
         if (s + 1 < nslabs) issue(s + 1, buf ^ 1);
 #pragma unroll
         for (int kk = 0; kk < RB; kk += 4) {
             const int r = kk + lq;
             const int off = (((r / V) ^ fl) * V) + (r % V);
-            const double opa = (double)As[(16 * wv + li) * CS + off], opb = (double)Bs[(16 * rb + li) * CS + off];
-            double b[NT9];
+            double xa[NA], xb[NB];  // column operands; xa[0] / xb[0] are the row operands too (the diagonal tiles)
 #pragma unroll
-            for (int t = 1; t < NT9; ++t) {  // (tile 0 is the diagonal tile of row wv: both operands are opa)
-                const bool inA = t < na;
-                const int col = inA ? wv + t : rb + (t - na);
-                b[t] = (double)(inA ? As : Bs)[(16 * col + li) * CS + off];
-            }
-            // (the first tile of the B segment, t == na, is bb's diagonal tile: its column operand equals opb -- the read above
-            // fetched the same element again, which costs less than a select in every tile)
-            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(opa, opa, acc[0], 0, 0, 0);
+            for (int t = 0; t < NA; ++t) xa[t] = (double)As[(16 * (W + t)) * CS + off];
 #pragma unroll
-            for (int t = 1; t < NT9; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((t < na) ? opa : opb, b[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NB; ++t) xb[t] = (double)Bs[(16 * (RBW + t)) * CS + off];
+#pragma unroll
+            for (int t = 0; t < NA; ++t) acca[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0], xa[t], acca[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NB; ++t) accb[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[0], xb[t], accb[t], 0, 0, 0);
             if constexpr (MT > 0) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const double y = (double)Ys[(m * 8 + r / V) * V + r % V];  // (responses >= M: zeros came with the DMA)
-                    accy[0][m] = fma(opa, y, accy[0][m]);
-                    accy[1][m] = fma(opb, y, accy[1][m]);
+                    accy[0][m] = fma(xa[0], y, accy[0][m]);
+                    accy[1][m] = fma(xb[0], y, accy[1][m]);
                 }
             }
         }
@@ -482,24 +563,36 @@ __device__ __forceinline__ void syrk8_dd_body(const T *__restrict__ X, i64 ldx, 
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const double sum = xor_range_sum<16, 64>(accy[h][m]);  // over the four lq groups
-                const int col = (h == 0 ? ba * SYRK_TB + 16 * wv : bb * SYRK_TB + 16 * rb) + li;
+                const int col = (h == 0 ? ba * SYRK_TB + 16 * W : bb * SYRK_TB + 16 * RBW) + li;
                 if (lq == 0 && m < M && col < K) xy_out[col + (i64)m * K] = sum;
             }
     }
-#pragma unroll
-    for (int t = 0; t < NT9; ++t) {
-        const bool inA = t < na;
-        const int blk = inA ? ba : bb, ti = inA ? wv : rb, tj = inA ? wv + t : rb + (t - na);
+    auto store = [&](const f64x4 &acc, int blk, int ti, int tj) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ga_ = blk * SYRK_TB + 16 * ti + lq + 4 * r;
             const int gb_ = blk * SYRK_TB + 16 * tj + li;
             if (ga_ < K && gb_ < K) {
-                const double v = acc[t][r];
+                const double v = acc[r];
                 out[ga_ + (i64)gb_ * K] = v;
                 out[gb_ + (i64)ga_ * K] = v;
             }
         }
+    };
+#pragma unroll
+    for (int t = 0; t < NA; ++t) store(acca[t], ba, W, W + t);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) store(accb[t], bb, RBW, RBW + t);
+}
+
+template <typename T, int MT>
+__device__ __forceinline__ void syrk8_dd_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int ba, int bb, i64 s0, int nsplit,
+                                              const T *__restrict__ zeros, double *__restrict__ out, const T *__restrict__ Y, i64 ldy,
+                                              int M, double *__restrict__ xy_out) {
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {  // (wave-uniform: a scalar branch)
+#define DD_WAVE(W_) case W_: syrk8_dd_wave<T, MT, W_>(X, ldx, N, K, ba, bb, s0, nsplit, out, Y, ldy, M, xy_out); break;
+        DD_WAVE(0) DD_WAVE(1) DD_WAVE(2) DD_WAVE(3) DD_WAVE(4) DD_WAVE(5) DD_WAVE(6) DD_WAVE(7)
+#undef DD_WAVE
     }
 }
 
@@ -533,24 +626,29 @@ __global__ __launch_bounds__(512, 4) void syrk_glds8_kernel(const T *__restrict_
         split = id / nsingle;
     }
     double *out = part + (i64)split * ((i64)K * K);
-    if (kind != 0) {
-        for (int q = 0; q < (kind == 1 ? 2 : 1); ++q) {
-            const int bz = kind == 1 ? 2 * blk + q : blk;
-            for (int z = split + sd; z < so; z += sd) {
-                double *zo = part + (i64)z * ((i64)K * K);
-                for (int e = threadIdx.x; e < SYRK_TB * SYRK_TB; e += 512) {
-                    const int ga_ = bz * SYRK_TB + (e & (SYRK_TB - 1)), gb_ = bz * SYRK_TB + e / SYRK_TB;
-                    if (ga_ < K && gb_ < K) zo[ga_ + (i64)gb_ * K] = 0.0;
-                }
+    // the reduction sums max(so, sd) partial matrices: a block with fewer row splits zeroes the slots it does not write
+    const int nslots = max(so, sd);
+    auto zero_block = [&](int bzi, int bzj, int mine) {
+        for (int z = split + mine; z < nslots; z += mine) {
+            double *zo = part + (i64)z * ((i64)K * K);
+            for (int e = threadIdx.x; e < SYRK_TB * SYRK_TB; e += 512) {
+                const int ga_ = bzi * SYRK_TB + (e & (SYRK_TB - 1)), gb_ = bzj * SYRK_TB + e / SYRK_TB;
+                if (ga_ < K && gb_ < K) zo[ga_ + (i64)gb_ * K] = 0.0;
             }
         }
+    };
+    if (kind == 1) {
+        zero_block(2 * blk, 2 * blk, sd);
+        zero_block(2 * blk + 1, 2 * blk + 1, sd);
+    } else if (kind == 2) {
+        zero_block(blk, blk, sd);
     }
     double *xyo = xypart + (i64)split * ((i64)K * M);
     if (kind == 1) {
         if (!Y) syrk8_dd_body<T, 0>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, nullptr, 0, 0, nullptr);
         else if (M <= 1) syrk8_dd_body<T, 1>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, Y, ldy, M, xyo);
-        else if (M <= 4) syrk8_dd_body<T, 4>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, Y, ldy, M, xyo);
-        else syrk8_dd_body<T, 8>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, Y, ldy, M, xyo);
+        else if (M <= 2) syrk8_dd_body<T, 2>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, Y, ldy, M, xyo);
+        else syrk8_dd_body<T, 4>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, Y, ldy, M, xyo);  // (M <= 4: the launcher)
     } else if (kind == 2) {
         if (Y)
             syrk8_diag_body<T, true>(X, ldx, N, K, blk, split, sd, zeros, out, Y, ldy, M, xyo);
@@ -559,6 +657,10 @@ __global__ __launch_bounds__(512, 4) void syrk_glds8_kernel(const T *__restrict_
     } else {
         int bi = 0, rem = blk;
         while (rem >= nbk - 1 - bi) { rem -= nbk - 1 - bi; ++bi; }
+        if (so < nslots) {
+            zero_block(bi, bi + 1 + rem, so);
+            zero_block(bi + 1 + rem, bi, so);
+        }
         syrk8_full_body<T>(X, ldx, N, K, bi, bi + 1 + rem, split, so, zeros, out);
     }
 }
@@ -607,12 +709,17 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         // Diagonal blocks in PAIRS (syrk8_dd_body: 72 tiles per workgroup and slab against a full block's 64, nine reads per nine
         // MFMAs against six per eight): a pair weighs dw2 full blocks, a diagonal block left over (odd block count) rides with
         // the pairs' row splits.
-        static const int exp_pairs = getenv("PLS_HIP_EXP_SYRK_PAIRS") ? atoi(getenv("PLS_HIP_EXP_SYRK_PAIRS")) : 1;  // EXPERIMENT
-        static const double exp_dw2 = getenv("PLS_HIP_EXP_SYRK_DW2") ? atof(getenv("PLS_HIP_EXP_SYRK_DW2")) : 1.25;  // EXPERIMENT
-        const int pairs = (exp_pairs && nbk >= 2) ? 1 : 0;
+        // Measured at config 3 (profiles/r5/syrk_pairs.txt, same box): one diagonal block per workgroup 4.83 ms (0.746 of the fp64
+        // matrix pipe); pairs at dw2 = 0.95 / 1.0 / 1.05 / 1.1 / 1.15 / 1.2 / 1.3: 4.61 / 4.41 / 4.38 / 4.32 / 4.296 / 4.306 / 4.38 ms
+        // (0.840).  PLS_HIP_SYRK_PAIRS=0 keeps the single blocks (A/B measurements; read once per process).
+        static const int exp_pairs = getenv("PLS_HIP_SYRK_PAIRS") ? atoi(getenv("PLS_HIP_SYRK_PAIRS")) : 1;
+        constexpr double exp_dw2 = 1.17;
+        // (more than 4 responses on board: 2 x M accumulators beside the 72 of the tiles no longer fit the 128 registers of four
+        // waves per SIMD -- those fits keep one diagonal block per workgroup)
+        const int pairs = (exp_pairs && nbk >= 2 && !(fuse_y0 && M > 4)) ? 1 : 0;
         const int npair = pairs ? nbk / 2 : 0, nsingle = nbk - 2 * npair;
         const i64 ndunits = pairs ? npair + nsingle : nbk;  // workgroup kinds on the diagonal, per row split
-        const double dw = pairs ? 1.0 / exp_dw2 : (fuse_y0 ? (M == 1 ? 0.74 : 0.82) : 0.66);
+        const double dw = pairs ? exp_dw2 : (fuse_y0 ? (M == 1 ? 0.74 : 0.82) : 0.66);
         if (nblocks <= slots && (i64)(slots / ((nblocks - nbk) + dw * ndunits)) >= 16) {
             // measured optima of the row-split weight (profiles/r3/syrk_diagonal_weight_sweep.txt): 0.74 with X^T Y of one
             // response on board, 0.82 for several, 0.66 without
@@ -624,14 +731,15 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
         Sg = std::max<i64>(1, std::min<i64>(Sg, nslabs_g));
         Sg = std::min<i64>(Sg, part_capacity_doubles / ((i64)K * K));
         if (Sg < 1) return 1;
-        Sd = Sd ? std::min<i64>(Sd, Sg) : Sg;
+        Sd = Sd ? std::min<i64>(Sd, std::min<i64>(nslabs_g, part_capacity_doubles / ((i64)K * K))) : Sg;
         if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_glds8_kernel<T>), (int)LDS_G)) return 1;
         const i64 nwg8 = (i64)(nblocks - nbk) * Sg + ndunits * Sd;
         const bool fuse_y8 = fuse_y0 && Sd * (i64)K * M <= xypart_capacity_doubles;
+        const i64 nslots = std::max(Sg, Sd);
         hipLaunchKernelGGL(syrk_glds8_kernel<T>, dim3((unsigned)nwg8), dim3(512), LDS_G, stream, X, ldx, N, K, nbk,
                            static_cast<const T *>(zeros), part, (int)Sg, (int)Sd, fuse_y8 ? Y : nullptr, ldy, M, xypart, pairs);
         if (fuse_y8) *nb_xy = (int)Sd;
-        *nb = (int)Sg;
+        *nb = (int)nslots;
         return 0;
     }
     if (!raise_dynamic_lds(reinterpret_cast<const void *>(&syrk_kernel<T>), (int)SYRK_LDS_BYTES)) return 1;

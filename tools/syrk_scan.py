@@ -6,7 +6,7 @@ import torch, pls_amd
 h = pls_amd.Handle(); h.set_option(pls_amd.OPT_PROFILE, 1); h.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_GRAM)
 lines = []
 for dt, es in ((torch.float64, 8), (torch.float32, 4)):
-    for K in (64, 128, 192, 256, 320, 384, 448, 512):
+    for K in (64, 128, 256, 384, 512, 768, 896, 1024, 1280, 1536, 2048, 4096):
         for gb in (0.5, 4.0):
             N = int(gb * 1e9 / (K * es)) // 64 * 64
             if N < 1024: continue
