@@ -489,8 +489,11 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) vo
     // MI355X the XCDs do not stream alike: in a read+write sweep the odd ones need 5-10 % longer per tile whatever the tile
     // (profiles/r5/pass_stamps_shapes.txt), so with equal shares half the chip idles for the last 8 % of the launch.
     // Static, so the tile set of a workgroup -- and with it every sum -- is the same in every run.
-    const int wfast = (wk.nfull >= 0 && EDGE != 2) ? ((wk.mask >> (blockIdx.x & 7)) & 1) : 0;
-    const i64 wswitch = (wk.nfull >= 0 && EDGE != 2) ? (i64)wk.nfull * gridDim.x : (i64)1 << 62;
+    // (compiled into the deflating instantiations only: the read-only ones sit exactly at their 128 registers, and the loop's
+    // extra state cost the KERNEL plan's pass 0.66 -> 0.79 ms at config 3 -- profiles/r5/vs_r4.txt, first run)
+    constexpr bool WEIGHTED = DEFL && EDGE != 2;
+    const int wfast = (WEIGHTED && wk.nfull >= 0) ? ((wk.mask >> (blockIdx.x & 7)) & 1) : 0;
+    const i64 wswitch = (WEIGHTED && wk.nfull >= 0) ? (i64)wk.nfull * gridDim.x : (i64)1 << 62;
     i64 wstep = walk.step();
     bool wshared = true;
     for (i64 tile = walk.first(); tile * R < walk.nlim(N); buf ^= 1) {
@@ -633,6 +636,10 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) vo
         for (int j = 0; j < CPT; ++j)
 #pragma unroll
             for (int e = 0; e < V; ++e) pacc[j] = fma((double)x[j].v[e], t[e], pacc[j]);
+        if constexpr (!WEIGHTED) {
+            tile += walk.step();
+            continue;
+        }
         tile += wstep;
         if (wshared && tile >= wswitch) {  // (uniform) the shared rounds are over
             if (!wfast) break;
@@ -1442,6 +1449,8 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
                 wk.mask = fast_mask;
             }
         }
+        // (the one-descriptor form for READ-ONLY passes over the copy was built in round 5: 52 bytes of scratch per lane instead
+        // of 24 -- the 128-register shape's spills are its 64 tile + 32 accumulator registers, not its descriptors)
         if (CGX > 32 && defl && !tiled) return 1;
 #define FUSED_LAUNCH(CPT_, DEFL_, EDGE_, TILED_, dyn_)                                                                    \
     do {                                                                                                                  \
