@@ -72,13 +72,15 @@ struct pls_hip_context {
     //   PLS_HIP_CV_REFIT=1       pls_hip_cv_folds as one device refit per fold (the general form; tests compare)
     //   PLS_HIP_TAIL=0           partial rows summed by reduce_partials_kernel behind the pass, sharded collectives through
     //                            the reducer call (the launches of round 3; A/B measurements)
-    //   PLS_HIP_TAIL=2           the one-response update as the last act of the tail too -- ONE launch per component, sharded
-    //                            over the device-side exchange as well (push, wait for the peers, update).  Measured equal or
-    //                            slower on one GPU (profiles/r5/tail_ab.txt: the tail's loads queue behind the write drain of
-    //                            the sweep), so the default stays 1: sums + push in the tail, the update a launch of its own
+    //   PLS_HIP_TAIL=1 / 2       the one-response update as the last act of the tail -- ONE launch per component, sharded over
+    //                            the device-side exchange as well (push, wait for the peers, update) -- never (1) / behind every
+    //                            pass (2).  Default (unset): behind READ-ONLY passes only; behind a deflating sweep the tail's loads
+    //                            queue behind the write drain and the update is faster as a launch of its own
+    //                            (profiles/r5/tail_ab.txt)
     //   PLS_HIP_REPLICA_GUARD=0  no replica-divergence check after a sharded fit (must be the same on every rank)
     struct Env {
-        bool tiny = true, cv_refit = false, tail = true, tail_update = false, replica_guard = true;
+        bool tiny = true, cv_refit = false, tail = true, replica_guard = true;
+        int tail_update = 1;  // 0: never, 1: in the tail of READ-ONLY passes (default), 2: of every pass
     } env;
     // replica guard of sharded fits (small_kernels.hpp): host-mapped flag "the ranks derived different W/P/Q/R/B"
     int *diverged = nullptr, *diverged_dev = nullptr;

@@ -203,10 +203,16 @@ __device__ __forceinline__ void slice_tail(const SliceTail &st, const double *pa
                                         double *sm, double *scratch, double *wl) {
     static_assert(NT >= WG, "the t^T t sum takes the first four waves");
     const int tid = threadIdx.x, nb = st.nrows, nwg = gridDim.x, b = blockIdx.x;
-    const int sl = (int)(((i64)(b + 1) * RED_SLICES + nb - 1) / nb) - 1;  // lo(sl) <= b < hi(sl)
-    const int lo = (int)((i64)nb * sl / RED_SLICES), hi = (int)((i64)nb * (sl + 1) / RED_SLICES);
+    // (Round 5 measured the tail on SMALL grids too -- one arrival counter, the last workgroup sums all slices, update behind it:
+    // the last workgroup then spends 9 us in the tail of a 3 us pass (every hand-off is a round trip to memory on a chip that
+    // idles at a low clock) and mid-size fits LOSE to the three launches, 300 x 400: 132 against 94 us for five components,
+    // 3,000 x 100: 129 against 92 -- profiles/r5/small_vs_r4_tail_on_small_grids.txt.  The tail stays with grids of
+    // TAIL_MIN_WG workgroups or more.)
+    constexpr int NSL = RED_SLICES;
+    const int sl = (int)(((i64)(b + 1) * NSL + nb - 1) / nb) - 1;  // lo(sl) <= b < hi(sl)
     if (tid == 0) {
-        const unsigned mine = (unsigned)(min(hi, nwg) - lo);  // workgroups of this launch in the slice
+        const int lo_ = (int)((i64)nb * sl / NSL), hi_ = (int)((i64)nb * (sl + 1) / NSL);
+        const unsigned mine = (unsigned)(min(hi_, nwg) - lo_);  // workgroups of this launch behind this counter
         const unsigned ticket = __hip_atomic_fetch_add(st.cnt + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (ticket + 1u == mine);
         if (last) {
@@ -218,71 +224,77 @@ __device__ __forceinline__ void slice_tail(const SliceTail &st, const double *pa
     if (!*role) return;
     const i64 LP = K + 1;
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    double ssl = 0.0;  // t^T t of the slice, this thread's strided share: loaded ahead of the rows
     {
-        const __amdgpu_buffer_rsrc_t rq =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(sspart), (short)0, nb * 8, BUF_WORD3);
-        if (tid < WG)
-            for (int r = lo + tid; r < hi; r += WG) {
-                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rq, (uint32_t)r * 8u, 0, AUX_SC1);
+        const int s8 = sl;
+        const int lo = (int)((i64)nb * s8 / RED_SLICES), hi = (int)((i64)nb * (s8 + 1) / RED_SLICES);
+        double ssl = 0.0;  // t^T t of the slice, this thread's strided share: loaded ahead of the rows
+        {
+            const __amdgpu_buffer_rsrc_t rq =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(sspart), (short)0, nb * 8, BUF_WORD3);
+            if (tid < WG)
+                for (int r = lo + tid; r < hi; r += WG) {
+                    const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rq, (uint32_t)r * 8u, 0, AUX_SC1);
+                    double d;
+                    __builtin_memcpy(&d, &raw, 8);
+                    ssl += d;
+                }
+        }
+        {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(part + (i64)lo * K), (short)0,
+                                                                                (int)((i64)(hi - lo) * K * 8), BUF_WORD3);
+            auto ld = [&](int row, int j) -> double {  // (rows beyond hi - lo: out of range, zero)
+                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs, (uint32_t)(((i64)row * K + j) * 8), 0, AUX_SC1);
                 double d;
                 __builtin_memcpy(&d, &raw, 8);
-                ssl += d;
+                return d;
+            };
+            const int nr = hi - lo;
+            for (int j = tid; j < K; j += NT) {
+                double c[4] = {0.0, 0.0, 0.0, 0.0};
+                int r = 0;
+                for (; r + 16 <= nr; r += 16) {  // 16 loads in flight per lane; chain q takes the rows lo + q, lo + q + 4, ...
+                    double x[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) x[u] = ld(r + u, j);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) c[u & 3] += x[u];
+                }
+                for (; r < nr; r += 4) {
+                    double x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = (r + u < nr) ? ld(r + u, j) : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (r + u < nr) c[u] += x[u];
+                }
+                st_agent(st.red + (i64)s8 * LP + j, (c[0] + c[1]) + (c[2] + c[3]));
             }
-    }
-    {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(part + (i64)lo * K), (short)0,
-                                                                            (int)((i64)(hi - lo) * K * 8), BUF_WORD3);
-        auto ld = [&](int row, int j) -> double {  // (rows beyond hi - lo: out of range, zero)
-            const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs, (uint32_t)(((i64)row * K + j) * 8), 0, AUX_SC1);
-            double d;
-            __builtin_memcpy(&d, &raw, 8);
-            return d;
-        };
-        const int nr = hi - lo;
-        for (int j = tid; j < K; j += NT) {
-            double c[4] = {0.0, 0.0, 0.0, 0.0};
-            int r = 0;
-            for (; r + 16 <= nr; r += 16) {  // 16 loads in flight per lane; chain q takes the rows lo + q, lo + q + 4, ...
-                double x[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) x[u] = ld(r + u, j);
-#pragma unroll
-                for (int u = 0; u < 16; ++u) c[u & 3] += x[u];
-            }
-            for (; r < nr; r += 4) {
-                double x[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = (r + u < nr) ? ld(r + u, j) : 0.0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (r + u < nr) c[u] += x[u];
-            }
-            st_agent(st.red + (i64)sl * LP + j, (c[0] + c[1]) + (c[2] + c[3]));
         }
-    }
-    {  // t^T t of the slice: reduce_partials_kernel's sum -- 256 strided sums, wave sums, waves 0..3 in order
-        double s = wave_sum(ssl);
-        __syncthreads();
-        if ((tid & 63) == 0 && tid < WG) sm[tid >> 6] = s;
-        __syncthreads();
-        if (tid == 0) st_agent(st.red + (i64)sl * LP + K, ((sm[0] + sm[1]) + sm[2]) + sm[3]);
+        {  // t^T t of the slice: reduce_partials_kernel's sum -- 256 strided sums, wave sums, waves 0..3 in order
+            double sw = wave_sum(ssl);
+            __syncthreads();
+            if ((tid & 63) == 0 && tid < WG) sm[tid >> 6] = sw;
+            __syncthreads();
+            if (tid == 0) st_agent(st.red + (i64)s8 * LP + K, ((sm[0] + sm[1]) + sm[2]) + sm[3]);
+        }
     }
     if (st.npush <= 0 && !st.upd.XY) return;
     // ---- the last of the RED_SLICES slice reducers: the sums of all slices -> every member's inbox (sharded), the component
     // update (one response)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(st.cnt + RED_SLICES, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (ticket + 1u == (unsigned)RED_SLICES);
-        if (last) {
-            __hip_atomic_store(st.cnt + RED_SLICES, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        if (tid == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(st.cnt + RED_SLICES, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (ticket + 1u == (unsigned)NSL);
+            if (last) {
+                __hip_atomic_store(st.cnt + RED_SLICES, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *role = last;
         }
-        *role = last;
+        __syncthreads();
+        if (!*role) return;
     }
-    __syncthreads();
-    if (!*role) return;
     const __amdgpu_buffer_rsrc_t rr =
         __builtin_amdgcn_make_buffer_rsrc(st.red, (short)0, (int)((i64)RED_SLICES * LP * 8), BUF_WORD3);
     if (st.npush > 0) {
@@ -405,9 +417,12 @@ struct TileWalk<true, R> {
 // descriptor per column group (the caller's column-major matrix needs those: a column group spans CG ld s bytes) the
 // compiler carried 2 x 16 descriptors across the tile loop as running pointers -- 141 spilled SGPRs and 11 spilled VGPRs
 // in the headline kernel, 0.29 GB of scratch stores per launch at config 3 (profiles/r3/pmc_traffic_C3_nipals_fused.txt).
+// ONEWG: a read-only pass at 16 or fewer columns per lane compiled for ONE workgroup per CU (its default is two, 5 % faster
+// on a long sweep): the form that may sum its partial rows -- and run the one-response update -- in its own tail, which is
+// what a SHORT pass wants (below ~1.5 GB the two launches behind the pass cost more than the 5 %).
 template <typename T, int V, int R, int NT, int CPT, bool DEFL, int LDAUX_ = AUX_NT, int STAUX = AUX_NT, bool RDST = false,
-          int EDGE = 0, bool TILED = false>
-__global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) void fused_pass_kernel(
+          int EDGE = 0, bool TILED = false, bool ONEWG = false>
+__global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL && !ONEWG) ? 2 : 1)) void fused_pass_kernel(
     const T *X, i64 ldx, i64 tsx, T *dst, i64 ldd, i64 tsd, i64 N, int K,  // dst may alias X (in-place deflation)
     const double *__restrict__ v, const T *__restrict__ tprev, const double *__restrict__ pprev,
     T *__restrict__ tout, double *__restrict__ part, double *__restrict__ sspart, int rdst, i64 NV, const SliceTail st,
@@ -663,7 +678,7 @@ __global__ __launch_bounds__(NT, (NT / 256) * ((CPT <= 16 && !DEFL) ? 2 : 1)) vo
     if (tid == 0) st_agent(sspart + blockIdx.x, ss);
     // (the tail exists in the instantiations launched with ONE workgroup per CU only -- see slice_tail; the two-per-CU read-only
     // shapes carry neither its code nor the registers of the out-of-line update)
-    constexpr bool ONE_PER_CU = !(CPT <= 16 && !DEFL);
+    constexpr bool ONE_PER_CU = !(CPT <= 16 && !DEFL) || ONEWG;
     if (ONE_PER_CU && st.cnt) {  // (uniform) the partial rows are summed inside this launch
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1392,7 +1407,12 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         // never fit two.
         // (512 column groups: the operand vector of a read-only pass is 64 KB of LDS, two workgroups fit; a deflating pass
         // holds p_prev as well, 128 KB)
-        const int per_cu = (K <= CG * 16 && !defl) ? 2 : 1;
+        // (a SHORT read-only pass at <= 16 columns per lane: one per CU as well -- the ONEWG instantiations, whose tail sums the
+        // partial rows and may run the update: one launch per component instead of three)
+        // (from a full chip of tiles up to ~1.5 GB: below, the tail loses to the launches -- slice_tail -- above, the 5 % do)
+        const bool onewg = !defl && K <= CG * 16 && CGX <= 64 && edge == 0 && tail && tail->cnt && rdst == 0 &&
+                           ntiles >= (i64)num_cu && (double)ntiles * R * K * sizeof(T) <= 1.5e9;
+        const int per_cu = (K <= CG * 16 && !defl && !onewg) ? 2 : 1;
         grid = grid_hint > 0 ? grid_hint : per_cu * (i64)num_cu;
         grid = std::min<i64>(std::min<i64>(grid, ntiles), max_rows - 1);
         if (grid < 1) return 1;
@@ -1454,6 +1474,13 @@ int launch_fused_pass(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 t
         if (CGX > 32 && defl && !tiled) return 1;
 #define FUSED_LAUNCH(CPT_, DEFL_, EDGE_, TILED_, dyn_)                                                                    \
     do {                                                                                                                  \
+        if constexpr (!(DEFL_) && (CPT_) <= 16 && CGX <= 64 && (EDGE_) == 0) {                                            \
+            if (onewg) {                                                                                                  \
+                auto kfn1 = &fused_pass_kernel<T, V, R, NT, CPT_, DEFL_, AUX_NT, AUX_NT, false, EDGE_, TILED_, true>;     \
+                hipLaunchKernelGGL(kfn1, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, 0, N, st, wk); \
+                break;                                                                                                    \
+            }                                                                                                             \
+        }                                                                                                                 \
         auto kfn = &fused_pass_kernel<T, V, R, NT, CPT_, DEFL_, AUX_NT, AUX_NT, false, EDGE_, TILED_>;                   \
         if ((dyn_) > 48 * 1024 && !raise_dynamic_lds(reinterpret_cast<const void *>(kfn), (int)(dyn_))) return 1;         \
         hipLaunchKernelGGL(kfn, g, b, dyn_, stream, X, ldx, tsx, dst, ldd, tsd, Nf, K, v, tprev, pprev, tout, part, sspart, (TILED_) ? (2 * (CPT_)) | 0x10000 : 0, N, st, wk); \

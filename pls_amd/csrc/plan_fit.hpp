@@ -333,8 +333,9 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         // one response: the update is the last act of the pass's tail (update_m1.hpp) -- ONE launch per component; sharded
         // over the device-side exchange the tail pushes, waits for the peers' pushes and updates (other reducers: a call
         // between the pass and the update, so the update stays a launch of its own)
-        const bool want_upd = tail.cnt && c->env.tail_update && M == 1 && K <= plsk::UPD1_KMAX && update_is_single(K, M, A, a) &&
-                              (!c->reducer || want_push);
+        const bool defl_pass = nipals && a > 0;
+        const bool want_upd = tail.cnt && (c->env.tail_update == 2 || (c->env.tail_update == 1 && !defl_pass)) && M == 1 &&
+                              K <= plsk::UPD1_KMAX && update_is_single(K, M, A, a) && (!c->reducer || want_push);
         tail.npush = 0;
         tail.upd = plsk::TailUpdate();
         tail.gx = plsk::XchgGather();

@@ -77,7 +77,7 @@ int pls_hip_create(pls_hip_handle *out, int device, void *stream) {
         c->env.tail = !off("PLS_HIP_TAIL");
         {
             const char *e = getenv("PLS_HIP_TAIL");
-            c->env.tail_update = e && atoi(e) >= 2;
+            c->env.tail_update = e ? (atoi(e) >= 2 ? 2 : 0) : 1;
         }
         c->env.replica_guard = !off("PLS_HIP_REPLICA_GUARD");
     }

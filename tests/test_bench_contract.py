@@ -102,15 +102,21 @@ def test_bench_gpus_flag_alone_starts_the_ranks():
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_over_the_device_side_exchange():
+@pytest.mark.parametrize("algo,tail", [("nipals", None), ("kernel", None), ("nipals", "2")],
+                         ids=["nipals", "kernel-plan", "nipals-update-in-the-tail"])
+def test_bench_two_ranks_over_the_device_side_exchange(algo, tail):
     """The reducer `bench.py --gpus N` takes by default on a multi-GPU node (`--reducer ipc`: the library's device-side
     exchange between processes), rehearsed with two ranks on the one GPU (gloo only carries the set-up): one contract
-    line, the reducer it reports is the exchange itself (no fall-back), and the replica guard at the end stayed quiet."""
+    line, the reducer it reports is the exchange itself (no fall-back), and the replica guard at the end stayed quiet.
+    Under the NIPALS plan (the headline), the KERNEL plan (what a `PLS::Model` takes by default) and with the one-response
+    update run inside the pass's tail (PLS_HIP_TAIL=2: one launch per sharded component)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if tail:
+        env["PLS_HIP_TAIL"] = tail
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--workload", "tiny", "--backend", "gloo", "--reducer", "ipc"], capture_output=True, text=True,
-                       timeout=600, env=env)
+                        "--workload", "tiny", "--backend", "gloo", "--reducer", "ipc", "--algo", algo, "--no-alt"],
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
