@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collects the measurement evidence of a round on the GPU box into gpurun_out/evidence/ (copy what is to be judged
 # into profiles/rNN/ afterwards).  rocprofv3: the program goes directly after `--`; counters in their own passes.
-# usage: bash tools/collect_evidence.sh [part ...]   parts: c3 deflate c4 c5 eighth edge narrow wide group host roctx small fuzz   (default: all but fuzz)
+# usage: bash tools/collect_evidence.sh [part ...]   parts: c3 gram deflate c4 c5 eighth edge narrow wide group host roctx small fuzz   (default: all but fuzz)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 E=gpurun_out/evidence; mkdir -p $E
-PARTS="${*:-c3 deflate c4 c5 eighth edge narrow wide group host roctx small}"
+PARTS="${*:-c3 gram deflate c4 c5 eighth edge narrow wide group host roctx small}"
 stats() {  # name, command...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $E/tmp_$name -o p -- "$@" > $E/${name}_bench_under_rocprof.json 2> $E/tmp_$name.err
@@ -26,6 +26,14 @@ c3)
   pmc C3_nipals_fused python3 bench.py --steps 2 --warmup 1 --no-alt --no-cpu
   stats c3_kernel_fused python3 bench.py --algo kernel --steps 5 --warmup 2 --no-alt --no-cpu
   pmc C3_kernel_fused python3 bench.py --algo kernel --steps 2 --warmup 1 --no-alt --no-cpu ;;
+gram)
+  # the SYRK (X^T X + X^T Y of config 3 in one launch): 100 timed launches behind 5 warm-ups, so that the rocprofv3 average
+  # means what bench.py's alt.gram_mfma_syrk / alt.type2_mfma_syrk mean; matrix-pipe utilisation in a counter pass of its own
+  python3 bench.py --algo gram --steps 20 --warmup 5 --no-cpu --no-alt > $E/bench_C3_gram_plan.json 2> /dev/null
+  python3 tools/syrk_time.py 100 > $E/syrk_hip_events.txt 2> /dev/null
+  stats c3_gram python3 tools/syrk_time.py 100
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $E/tmp_mfma -o p -- python3 tools/syrk_time.py 10 > /dev/null 2> $E/tmp_mfma.err
+  python3 tools/mfma_util.py $E/tmp_mfma/p_counter_collection.csv syrk > $E/syrk_mfma_pmc.txt 2>&1; rm -rf $E/tmp_mfma $E/tmp_mfma.err ;;
 deflate)
   python3 tools/deflate_run.py > $E/deflate_piece_hip_events.txt 2> /dev/null
   stats deflate_piece python3 tools/deflate_run.py
