@@ -86,10 +86,6 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     const bool type2 = (method == PLS_HIP_KERNEL_TYPE2) || gram;
     const bool nipals = !type2 && (algo == PLS_HIP_ALGO_NIPALS);
     const int nip = nipals ? 1 : 0;
-    // EXPERIMENT: where the library's copy of X lies relative to the caller's matrix (retile_xty is bimodal per process)
-    static const size_t exp_work_off = getenv("PLS_HIP_EXP_WORK_OFF") ? (size_t)atoll(getenv("PLS_HIP_EXP_WORK_OFF")) : 0;
-    static const bool exp_work_print = getenv("PLS_HIP_EXP_WORK_PRINT") != nullptr;
-    const size_t exp_work_slack = exp_work_off ? ((size_t)64 << 20) : 0;
     const i64 L0 = (i64)K * M;
     const i64 redn = (i64)plsk::RED_SLICES * std::max<i64>(L0, K + 1);
     const i64 prow = max_partial_rows(c, N, K);
@@ -171,7 +167,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                             : (K <= 128 * 16 ? 128 : (K <= 256 * 16 ? 256 : ((wide_src && (!nipals || wide_only)) ? 512 : 0)));
     if (retile_fit) {  // the copy is optional: without room for it the one-product kernels do the job
         const i64 wr = (512 / wide_groups) * (i64)(16 / sizeof(T));
-        if (ensure(c, c->work, (size_t)((N + wr - 1) / wr) * wr * K * sizeof(T) + exp_work_slack) != PLS_HIP_OK) {
+        if (ensure(c, c->work, (size_t)((N + wr - 1) / wr) * wr * K * sizeof(T)) != PLS_HIP_OK) {
             retile_fit = false;
             c->err.clear();
         }
@@ -188,14 +184,13 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     const int work_cg = wide_cg ? wide_cg : (mid_cg ? mid_cg : tall_cg);
     const i64 WR = (512 / work_cg) * (i64)(16 / sizeof(T));  // rows per tile of the working copy
     if ((nipals && A > 1 && N > 0) || retile_fit)
-        CHK(ensure(c, c->work, ((tiled_work || retile_fit) ? (size_t)((N + WR - 1) / WR) * WR * K * sizeof(T)
-                                                           : (size_t)((N + 3) & ~(i64)3) * K * sizeof(T)) + exp_work_slack));
+        CHK(ensure(c, c->work, (tiled_work || retile_fit) ? (size_t)((N + WR - 1) / WR) * WR * K * sizeof(T)
+                                                          : (size_t)((N + 3) & ~(i64)3) * K * sizeof(T)));
     double *part = (double *)c->part.p, *sspart = (double *)c->sspart.p;
     double *XY = (double *)c->xy.p, *v = (double *)c->v.p;
-    T *work = (T *)((char *)c->work.p + exp_work_off);
-    if (exp_work_print && c->work.p)
-        fprintf(stderr, "pls_hip work placement: X %p work %p (work - X) mod 2^26 = %lld\n", (const void *)X, (void *)work,
-                (long long)(((uintptr_t)work - (uintptr_t)X) & ((1ull << 26) - 1)));
+    // (round 5 moved this copy around inside its allocation -- 20 offsets from 256 bytes to 32 MB, profiles/r5/retile_offsets.txt:
+    // retile_xty takes the same 1.60-1.63 ms wherever it lies)
+    T *work = (T *)c->work.p;
     // The partial rows of a fused pass are summed in the tail of the pass itself (slice_tail: no reduce launch behind it),
     // and with the device-side exchange attached the push of a sharded component rides there too, the gather in front of
     // the update: pass -> update.  PLS_HIP_TAIL=0: the launches of round 3 (A/B measurements).
