@@ -344,7 +344,12 @@ def test_power_iteration_close_eigenvalues(handle, oracle, po):
     check_against(po, out, ref, Bref, ref["T"], col_err=cerr)
 
 
-@pytest.mark.parametrize("N,K,M,A", [(9, 7, 2, 4), (1000, 64, 1, 12), (777, 33, 3, 8), (2048, 130, 8, 6)])
+@pytest.mark.parametrize("N,K,M,A", [(9, 7, 2, 4), (1000, 64, 1, 12), (777, 33, 3, 8), (2048, 130, 8, 6),
+                                     # the SYRK's diagonal blocks in PAIRS (M <= 4, two or more column blocks): a pair + a single block
+                                     # (K = 384), a ragged second / third block, row counts that are no multiple of the 16-row slab,
+                                     # 2 and 4 responses on board, eight waves of workgroups (K >= 1024)
+                                     (4104, 384, 1, 8), (3000, 200, 2, 6), (2050, 300, 4, 5), (1040, 256, 1, 7), (3000, 1100, 1, 4),
+                                     (33000, 512, 1, 6)])
 def test_kernel_type2(handle, oracle, po, N, K, M, A):
     """METHOD::KERNEL_TYPE2 (src/pls.cpp:398,422-425): XX = X^T X once, no pass over X in the loop, T
     not computed.  Same W,P,Q,R,B as KERNEL_TYPE1 up to rounding."""
@@ -356,11 +361,12 @@ def test_kernel_type2(handle, oracle, po, N, K, M, A):
     check_against(po, out, ref, oracle.coefficients(ref["R"], ref["Q"]), None, col_err=cerr)
 
 
-def test_kernel_type2_fp32_storage(handle, oracle, po):
-    """KERNEL_TYPE2 on fp32 storage: fp32 panels through LDS, converted to fp64 at the MFMA operand read."""
+@pytest.mark.parametrize("N,K,M,A", [(1500, 70, 2, 5), (5004, 640, 3, 5), (4096, 256, 1, 6)])
+def test_kernel_type2_fp32_storage(handle, oracle, po, N, K, M, A):
+    """KERNEL_TYPE2 on fp32 storage: fp32 panels through LDS, converted to fp64 at the MFMA operand read (single diagonal blocks,
+    pairs with 3 responses on board over five column blocks, pairs at one response)."""
     import pls_amd
     torch = _torch()
-    N, K, M, A = 1500, 70, 2, 5
     X = handle.synth_x(0, N, K, 21, dtype=torch.float32); Y = handle.synth_y(0, N, M, 21, dtype=torch.float32)
     Xh = X.cpu().numpy().astype(np.float64); Yh = Y.cpu().numpy().astype(np.float64)
     ref = oracle.plsr(Xh, Yh, A, method=1)
