@@ -184,10 +184,15 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_base) {
 // apart: 3.6 -> 4.06 TB/s of panel reads, 0.734 -> 0.826 of the matrix pipe in the stand-alone form of this kernel
 // (pls_amd/csrc/tune/syrk_stream_probe.hip, profiles/r4/syrk_stream_probe.txt) -- the same as padding the columns' stride
 // away from a power of two does.
+// (Round 5 also weighted the row splits by DISPATCH POSITION -- the workgroups of the first residency wave, ids below the CU
+// count, win the arbitration for their CU's matrix pipe and finish at 3.6 ms where the second workgroup of each CU takes 4.4
+// (tools/syrk_stamps.py) -- first wave : second = 1.07 ... 1.23 x the pair's weight 1.17 ... 1.6: nothing below the unweighted
+// 4.29 ms (profiles/r5/syrk_position_weights.txt); the launch is bound by what the CUs' pipes take in all, as the streaming
+// sweeps are by the memory.)
 __device__ __forceinline__ void syrk8_slab_range(i64 N, int RB, i64 split, int nsplit, i64 &first, i64 &end) {
     const i64 nall = (N + RB - 1) / RB;
     const i64 per = (nall + nsplit - 1) / nsplit;
-    first = split * per;
+    first = min(nall, split * per);
     end = min(nall, first + per);
 }
 
@@ -278,11 +283,12 @@ __device__ __forceinline__ void syrk8_dma_y(T *lds_dst, __amdgpu_buffer_rsrc_t r
 
 // (one out-of-line body per wave index W, as for the paired diagonal blocks below: tile offsets are instruction immediates)
 template <typename T, int W>
-__device__ __noinline__ void syrk8_full_wave(const T *X_, i64 ldx_, i64 N_, int K_, int bi_, int bj_, i64 s0_, int nsplit_, double *out_) {
+__device__ __noinline__ void syrk8_full_wave(const T *X_, i64 ldx_, i64 N_, int K_, int bi_, int bj_, i64 s0_, i64 s1_, double *out_) {
     const T *__restrict__ X = uni(X_);
     double *__restrict__ out = uni(out_);
     const i64 ldx = uni(ldx_), N = uni(N_), s0 = uni(s0_);
-    const int K = uni(K_), bi = uni(bi_), bj = uni(bj_), nsplit = uni(nsplit_);
+    const int K = uni(K_), bi = uni(bi_), bj = uni(bj_);
+    const i64 s1 = uni(s1_);
     extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
     T *lds = reinterpret_cast<T *>(slab_raw);
     constexpr int V = 16 / sizeof(T), RB = 8 * V, CS = 8 * V, PANEL = SYRK_TB * CS;
@@ -296,8 +302,8 @@ __device__ __noinline__ void syrk8_full_wave(const T *X_, i64 ldx_, i64 N_, int 
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
-    i64 s, nslabs;
-    syrk8_slab_range(N, RB, s0, nsplit, s, nslabs);
+    i64 s = s0;
+    const i64 nslabs = s1;  // this workgroup's slabs [s0, s1): syrk_glds8_kernel
     int buf = 0;
     const SyrkDma<T> dma = syrk8_dma_setup<T>(X, ldx, K, bi, bj, W, scol, spos);
     if (s < nslabs) syrk8_dma<T>(lds, 0, dma, N, false, s, W);
@@ -340,10 +346,10 @@ __device__ __noinline__ void syrk8_full_wave(const T *X_, i64 ldx_, i64 N_, int 
 }
 
 template <typename T>
-__device__ __forceinline__ void syrk8_full_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, int bj, i64 s0, int nsplit,
+__device__ __forceinline__ void syrk8_full_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, int bj, i64 s0, i64 s1,
                                              const T *__restrict__ zeros, double *__restrict__ out) {
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {  // (wave-uniform: a scalar branch)
-#define FULL_WAVE(W_) case W_: syrk8_full_wave<T, W_>(X, ldx, N, K, bi, bj, s0, nsplit, out); break;
+#define FULL_WAVE(W_) case W_: syrk8_full_wave<T, W_>(X, ldx, N, K, bi, bj, s0, s1, out); break;
         FULL_WAVE(0) FULL_WAVE(1) FULL_WAVE(2) FULL_WAVE(3) FULL_WAVE(4) FULL_WAVE(5) FULL_WAVE(6) FULL_WAVE(7)
 #undef FULL_WAVE
     }
@@ -357,7 +363,7 @@ __device__ __forceinline__ void syrk8_tri_tile(int t, int &i, int &j) {
 }
 
 template <typename T, bool WITH_Y>
-__device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, i64 s0, int nsplit,
+__device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int bi, i64 s0, i64 s1,
                                              const T *__restrict__ zeros, double *__restrict__ out, const T *__restrict__ Y, i64 ldy,
                                              int M, double *__restrict__ xy_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
@@ -397,8 +403,8 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
     for (int m = 0; m < 8; ++m) accy[m] = 0.0;
     const int yc = tid >> 2, yh = tid & 3;  // X^T Y: column of the panel, quarter of the slab's 8 row positions
     const int ykey = (yc >> 1) & 7;
-    i64 s, nslabs;
-    syrk8_slab_range(N, RB, s0, nsplit, s, nslabs);
+    i64 s = s0;
+    const i64 nslabs = s1;  // this workgroup's slabs [s0, s1): syrk_glds8_kernel
     const SyrkDma<T> dma = syrk8_dma_setup<T>(X, ldx, K, bi, bi, wv, scol, spos);
     const __amdgpu_buffer_rsrc_t ry = syrk8_y_rsrc<T>(Y, ldy, WITH_Y ? M : 0);
     auto issue = [&](i64 s, int buf) {
@@ -494,12 +500,13 @@ __device__ __forceinline__ void syrk8_diag_body(const T *__restrict__ X, i64 ldx
 // round 2 found the same for the single diagonal block's patterns).  The waves of a workgroup run different functions with the
 // same slab loop, so they meet at the same barriers.
 template <typename T, int MT, int W>
-__device__ __noinline__ void syrk8_dd_wave(const T *X_, i64 ldx_, i64 N_, int K_, int ba_, int bb_, i64 s0_, int nsplit_, double *out_,
+__device__ __noinline__ void syrk8_dd_wave(const T *X_, i64 ldx_, i64 N_, int K_, int ba_, int bb_, i64 s0_, i64 s1_, double *out_,
                                            const T *Y_, i64 ldy_, int M_, double *xy_out_) {
     const T *__restrict__ X = uni(X_), *__restrict__ Y = uni(Y_);
     double *__restrict__ out = uni(out_), *__restrict__ xy_out = uni(xy_out_);
     const i64 ldx = uni(ldx_), N = uni(N_), s0 = uni(s0_), ldy = uni(ldy_);
-    const int K = uni(K_), ba = uni(ba_), bb = uni(bb_), nsplit = uni(nsplit_), M = uni(M_);
+    const int K = uni(K_), ba = uni(ba_), bb = uni(bb_), M = uni(M_);
+    const i64 s1 = uni(s1_);
     extern __shared__ __attribute__((aligned(16))) unsigned char slab_raw[];
     T *lds = reinterpret_cast<T *>(slab_raw);
     constexpr int V = 16 / sizeof(T), RB = 8 * V, CS = 8 * V, PANEL = SYRK_TB * CS;
@@ -516,8 +523,8 @@ __device__ __noinline__ void syrk8_dd_wave(const T *X_, i64 ldx_, i64 N_, int K_
     double accy[2][MT > 0 ? MT : 1];
 #pragma unroll
     for (int m = 0; m < (MT > 0 ? MT : 1); ++m) accy[0][m] = accy[1][m] = 0.0;
-    i64 s, nslabs;
-    syrk8_slab_range(N, RB, s0, nsplit, s, nslabs);
+    i64 s = s0;
+    const i64 nslabs = s1;  // this workgroup's slabs [s0, s1): syrk_glds8_kernel
     const SyrkDma<T> dma = syrk8_dma_setup<T>(X, ldx, K, ba, bb, W, scol, spos);
     const __amdgpu_buffer_rsrc_t ry = syrk8_y_rsrc<T>(Y, ldy, MT > 0 ? M : 0);
     auto issue = [&](i64 s, int buf) {
@@ -586,11 +593,11 @@ __device__ __noinline__ void syrk8_dd_wave(const T *X_, i64 ldx_, i64 N_, int K_
 }
 
 template <typename T, int MT>
-__device__ __forceinline__ void syrk8_dd_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int ba, int bb, i64 s0, int nsplit,
+__device__ __forceinline__ void syrk8_dd_body(const T *__restrict__ X, i64 ldx, i64 N, int K, int ba, int bb, i64 s0, i64 s1,
                                               const T *__restrict__ zeros, double *__restrict__ out, const T *__restrict__ Y, i64 ldy,
                                               int M, double *__restrict__ xy_out) {
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {  // (wave-uniform: a scalar branch)
-#define DD_WAVE(W_) case W_: syrk8_dd_wave<T, MT, W_>(X, ldx, N, K, ba, bb, s0, nsplit, out, Y, ldy, M, xy_out); break;
+#define DD_WAVE(W_) case W_: syrk8_dd_wave<T, MT, W_>(X, ldx, N, K, ba, bb, s0, s1, out, Y, ldy, M, xy_out); break;
         DD_WAVE(0) DD_WAVE(1) DD_WAVE(2) DD_WAVE(3) DD_WAVE(4) DD_WAVE(5) DD_WAVE(6) DD_WAVE(7)
 #undef DD_WAVE
     }
@@ -608,6 +615,9 @@ __global__ __launch_bounds__(512, 4) void syrk_glds8_kernel(const T *__restrict_
     // diagonal blocks (pairs != 0: blocks 2 p and 2 p + 1 in one workgroup, syrk8_dd_body), then sd of every diagonal block left
     // (workgroups that only exit still take a dispatch slot: a 2-D grid with idle members ran 7.8 ms instead of 6.1).  A
     // diagonal block has fewer partials than the so the reduction sums: its workgroup j also zeroes the slots j + sd, ... < so.
+#ifdef PLS_STAMP
+    PLS_STAMP(0);
+#endif
     const int npair = pairs ? nbk / 2 : 0, nsingle = nbk - 2 * npair, noff = nbk * (nbk + 1) / 2 - nbk;
     int id = blockIdx.x, split, blk, kind;  // kind 0: off-diagonal, 1: a pair of diagonal blocks, 2: one diagonal block
     if (id < noff * so) {
@@ -644,16 +654,19 @@ __global__ __launch_bounds__(512, 4) void syrk_glds8_kernel(const T *__restrict_
         zero_block(blk, blk, sd);
     }
     double *xyo = xypart + (i64)split * ((i64)K * M);
+    constexpr int RBK = 8 * (16 / (int)sizeof(T));
+    i64 s0, s1;  // this workgroup's slabs
+    syrk8_slab_range(N, RBK, split, kind == 0 ? so : sd, s0, s1);
     if (kind == 1) {
-        if (!Y) syrk8_dd_body<T, 0>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, nullptr, 0, 0, nullptr);
-        else if (M <= 1) syrk8_dd_body<T, 1>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, Y, ldy, M, xyo);
-        else if (M <= 2) syrk8_dd_body<T, 2>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, Y, ldy, M, xyo);
-        else syrk8_dd_body<T, 4>(X, ldx, N, K, 2 * blk, 2 * blk + 1, split, sd, zeros, out, Y, ldy, M, xyo);  // (M <= 4: the launcher)
+        if (!Y) syrk8_dd_body<T, 0>(X, ldx, N, K, 2 * blk, 2 * blk + 1, s0, s1, zeros, out, nullptr, 0, 0, nullptr);
+        else if (M <= 1) syrk8_dd_body<T, 1>(X, ldx, N, K, 2 * blk, 2 * blk + 1, s0, s1, zeros, out, Y, ldy, M, xyo);
+        else if (M <= 2) syrk8_dd_body<T, 2>(X, ldx, N, K, 2 * blk, 2 * blk + 1, s0, s1, zeros, out, Y, ldy, M, xyo);
+        else syrk8_dd_body<T, 4>(X, ldx, N, K, 2 * blk, 2 * blk + 1, s0, s1, zeros, out, Y, ldy, M, xyo);  // (M <= 4: the launcher)
     } else if (kind == 2) {
         if (Y)
-            syrk8_diag_body<T, true>(X, ldx, N, K, blk, split, sd, zeros, out, Y, ldy, M, xyo);
+            syrk8_diag_body<T, true>(X, ldx, N, K, blk, s0, s1, zeros, out, Y, ldy, M, xyo);
         else
-            syrk8_diag_body<T, false>(X, ldx, N, K, blk, split, sd, zeros, out, nullptr, 0, 0, nullptr);
+            syrk8_diag_body<T, false>(X, ldx, N, K, blk, s0, s1, zeros, out, nullptr, 0, 0, nullptr);
     } else {
         int bi = 0, rem = blk;
         while (rem >= nbk - 1 - bi) { rem -= nbk - 1 - bi; ++bi; }
@@ -661,8 +674,11 @@ __global__ __launch_bounds__(512, 4) void syrk_glds8_kernel(const T *__restrict_
             zero_block(bi, bi + 1 + rem, so);
             zero_block(bi + 1 + rem, bi, so);
         }
-        syrk8_full_body<T>(X, ldx, N, K, bi, bi + 1 + rem, split, so, zeros, out);
+        syrk8_full_body<T>(X, ldx, N, K, bi, bi + 1 + rem, s0, s1, zeros, out);
     }
+#ifdef PLS_STAMP
+    PLS_STAMP(1);
+#endif
 }
 
 // (Round 4: a 16-wave form with 32-row slabs -- 256-byte DMA pieces, half the barriers, one workgroup per CU -- was built after
