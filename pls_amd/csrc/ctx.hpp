@@ -67,6 +67,8 @@ struct pls_hip_context {
         const long long *limit = nullptr;
     } xep;
     DevBuf tailcnt;  // arrival counters of slice_tail (fused_kernels.hpp)
+    DevBuf resident;  // resident_fit_kernel: two arrival counters (256 bytes) + [2][G][LP] partial vectors
+    unsigned long long resident_launches = 0;
     // The environment switches of the library, read ONCE when the handle is created (INTEGRATION.md lists them):
     //   PLS_HIP_TINY=0           small fits on the general plan instead of the single-launch kernels (tests compare the two)
     //   PLS_HIP_CV_REFIT=1       pls_hip_cv_folds as one device refit per fold (the general form; tests compare)
@@ -77,9 +79,10 @@ struct pls_hip_context {
     //                            pass (2).  Default (unset): behind READ-ONLY passes only; behind a deflating sweep the tail's loads
     //                            queue behind the write drain and the update is faster as a launch of its own
     //                            (profiles/r5/tail_ab.txt)
+    //   PLS_HIP_RESIDENT=0       mid-size single-response fits on the general plan instead of the one-launch resident fit
     //   PLS_HIP_REPLICA_GUARD=0  no replica-divergence check after a sharded fit (must be the same on every rank)
     struct Env {
-        bool tiny = true, cv_refit = false, tail = true, replica_guard = true;
+        bool tiny = true, cv_refit = false, tail = true, replica_guard = true, resident = true;
         int tail_update = 1;  // 0: never, 1: in the tail of READ-ONLY passes (default), 2: of every pass
     } env;
     // replica guard of sharded fits (small_kernels.hpp): host-mapped flag "the ranks derived different W/P/Q/R/B"

@@ -106,19 +106,24 @@ int compute_xx(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, double *XX
 // Sharded fits: every rank must have derived the same bits (small_kernels.hpp, "replica guard").  Two small launches and one
 // 512-byte all-reduce per fit; the verdict lands in a host-mapped flag that pls_hip_synchronize (and the host-memory entry)
 // turn into PLS_HIP_ERR_REDUCER.
+// the handle's host-mapped status words: [0] the replicas of a sharded fit diverged, [1] a wait of the resident fit ran out
+bool host_flags(pls_hip_context *c) {
+    if (c->diverged) return true;
+    if (hipHostMalloc((void **)&c->diverged, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->diverged_dev, c->diverged, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        c->diverged = nullptr;
+        return false;
+    }
+    c->diverged[0] = c->diverged[1] = 0;
+    return true;
+}
+
 int replica_guard(pls_hip_context *c, const double *W, const double *P, const double *Q, const double *R, const double *B,
                   int K, int M, int A) {
     if (!c->reducer || c->nranks < 2 || c->nranks > 1024) return PLS_HIP_OK;
     if (!c->env.replica_guard) return PLS_HIP_OK;
-    if (!c->diverged) {
-        if (hipHostMalloc((void **)&c->diverged, 64, hipHostMallocMapped) != hipSuccess ||
-            hipHostGetDevicePointer((void **)&c->diverged_dev, c->diverged, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            c->diverged = nullptr;
-            return PLS_HIP_OK;  // (no mapped host memory: the guard is an extra, not a precondition)
-        }
-        *c->diverged = 0;
-    }
+    if (!host_flags(c)) return PLS_HIP_OK;  // (no mapped host memory: the guard is an extra, not a precondition)
     CHK(ensure(c, c->guard, (size_t)plsk::RED_SLICES * 8 * 8));
     double *g = (double *)c->guard.p;
     hipLaunchKernelGGL(plsk::replica_checksum_kernel, dim3(1), dim3(plsk::UPD_THREADS), 0, c->stream, W, P, R, Q, B, (i64)K * A,
@@ -136,6 +141,12 @@ void xchg_release(pls_hip_context *c);
 
 int check_diverged(pls_hip_context *c) {  // (the stream has been synchronised)
     CHK(check_xchg(c));
+    if (c->diverged && c->diverged[1]) {
+        c->diverged[1] = 0;
+        return fail(c, PLS_HIP_ERR_DEVICE, "the one-launch resident fit waited longer than its time limit for its workgroups to become "
+                                           "resident (another process or stream holds the GPU's CUs): results are invalid; "
+                                           "PLS_HIP_RESIDENT=0 takes the general plan");
+    }
     if (c->diverged && *c->diverged) {
         *c->diverged = 0;
         return fail(c, PLS_HIP_ERR_REDUCER, "the ranks of the sharded fit derived different W / P / Q / R / B: the reducer did not "

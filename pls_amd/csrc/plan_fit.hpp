@@ -4,6 +4,37 @@
 
 namespace {
 
+// The resident fits of one process take turns on a device: a launch waits for the previous one's completion event, whatever
+// stream that ran on, and records its own (two such kernels together could each hold CUs the other waits for).
+struct ResidentTurn {
+    std::mutex mu;
+    hipEvent_t ev[64] = {};
+    bool have[64] = {};
+};
+inline ResidentTurn &resident_turns() {
+    static ResidentTurn t;
+    return t;
+}
+inline void resident_turn(pls_hip_context *c) {
+    ResidentTurn &t = resident_turns();
+    std::lock_guard<std::mutex> lock(t.mu);
+    const int d = c->device & 63;
+    if (t.have[d]) (void)hipStreamWaitEvent(c->stream, t.ev[d], 0);
+}
+inline void resident_done(pls_hip_context *c) {
+    ResidentTurn &t = resident_turns();
+    std::lock_guard<std::mutex> lock(t.mu);
+    const int d = c->device & 63;
+    if (!t.have[d]) {
+        if (hipEventCreateWithFlags(&t.ev[d], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        t.have[d] = true;
+    }
+    (void)hipEventRecord(t.ev[d], c->stream);
+}
+
 // ---- the fit on device pointers -----------------------------------------------------------
 template <typename T>
 int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64 N, int K, int M,
@@ -29,6 +60,46 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                            W, P, Q, R, Tm, ldt, B, (const i64 *)nullptr, 0, (i64)0, (double *)nullptr);
         LAUNCH_CHECK(c);
         return PLS_HIP_OK;
+    }
+    // Mid-size single-response data (beyond one workgroup's 1024 rows, up to ~50 MB): the same single launch on up to 256
+    // workgroups with one grid-wide exchange per component (resident_kernels.hpp)
+    if (method == PLS_HIP_KERNEL_TYPE1 && (c->opt_algo == PLS_HIP_ALGO_KERNEL || c->opt_algo == PLS_HIP_ALGO_AUTO) && c->opt_fuse &&
+        !c->reducer && c->env.tiny && c->env.resident && plsk::elem_aligned<T>(X) && plsk::elem_aligned<T>(Y) && Tm) {
+        const int wps = plsk::resident_wps(N, K, M, A, ldx, sizeof(T), c->num_cu);
+        if (wps > 0 && host_flags(c)) {
+            const int G = (int)((N + (i64)plsk::WAVE * wps - 1) / ((i64)plsk::WAVE * wps));
+            const int LP = (K + 1 + 7) & ~7;
+            const size_t need = 256 + (size_t)2 * G * LP * 8;
+            if (c->resident.bytes < need) {
+                CHK(ensure(c, c->resident, need));
+                HIPCHK(c, hipMemsetAsync(c->resident.p, 0, 256, c->stream));  // both counters start from zero
+                c->resident_launches = 0;
+            }
+            if (!plsk::raise_dynamic_lds((const void *)plsk::resident_fit_kernel<T>, (int)plsk::TINY_LDS_MAX))
+                return fail(c, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the resident fit could not be raised");
+            plsk::ResidentSync sy;
+            unsigned *ctr = (unsigned *)c->resident.p;
+            sy.bar = ctr + 16 * (c->resident_launches & 1);        // (64 bytes apart)
+            sy.bar_next = ctr + 16 * ((c->resident_launches + 1) & 1);
+            ++c->resident_launches;
+            sy.part = (double *)((char *)c->resident.p + 256);
+            sy.status = c->diverged_dev + 1;
+            sy.limit = (long long)(0.05 * 1e8);  // 50 ms of the 100 MHz wall clock
+#ifdef PLS_HIP_TESTING
+            if (const char *e = getenv("PLS_HIP_TEST_RESIDENT_LIMIT_TICKS")) sy.limit = atoll(e);  // (the time-out path, tests only)
+#endif
+            sy.LP = LP;
+            Range r_fit("pls_hip_fit (single launch, resident)");
+            Scope s(c, PLS_HIP_FAM_SMALL, ((i64)N * K + (i64)N + (i64)N * A) * (i64)sizeof(T) + (3 * (i64)K + 1) * A * 8);
+            // all G workgroups must be resident together: the resident fits of ONE process take turns (an event chain per
+            // device across its streams); a foreign kernel holding CUs ends in the bounded wait's error, not in a hang
+            resident_turn(c);
+            hipLaunchKernelGGL((plsk::resident_fit_kernel<T>), dim3(G), dim3(plsk::UPD_THREADS), (size_t)2 * K * A * 8, c->stream, X, ldx, Y,
+                               N, K, A, W, P, Q, R, Tm, ldt, B, wps, sy);
+            LAUNCH_CHECK(c);
+            resident_done(c);
+            return PLS_HIP_OK;
+        }
     }
     // The smallest problems (N <= 64, K <= 32, 1..8 responses: the reference's README example) as ONE WAVE (micro_fit_kernel)
     if (method == PLS_HIP_KERNEL_TYPE1 && (c->opt_algo == PLS_HIP_ALGO_KERNEL || c->opt_algo == PLS_HIP_ALGO_AUTO) && c->opt_fuse &&

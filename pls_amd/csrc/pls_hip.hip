@@ -24,6 +24,7 @@
 #include "wide1_update.hpp"
 #include "largem_kernels.hpp"
 #include "tiny_kernels.hpp"
+#include "resident_kernels.hpp"
 #include "stream_kernels.hpp"
 #include "syrk_kernels.hpp"
 #include "cv_kernels.hpp"
@@ -80,6 +81,7 @@ int pls_hip_create(pls_hip_handle *out, int device, void *stream) {
             c->env.tail_update = e ? (atoi(e) >= 2 ? 2 : 0) : 1;
         }
         c->env.replica_guard = !off("PLS_HIP_REPLICA_GUARD");
+        c->env.resident = !off("PLS_HIP_RESIDENT");
     }
     c->device = device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -93,7 +95,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->tailcnt, &h->zeros, &h->part, &h->sspart, &h->xbpart, &h->wide1, &h->red, &h->red2, &h->xx, &h->xyp, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
+    DevBuf *bufs[] = {&h->tailcnt, &h->resident, &h->zeros, &h->part, &h->sspart, &h->xbpart, &h->wide1, &h->red, &h->red2, &h->xx, &h->xyp, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
                       &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->cvtx, &h->cvty, &h->cvtt, &h->cvm, &h->cvkeep, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)

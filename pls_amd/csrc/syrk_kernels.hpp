@@ -709,7 +709,11 @@ int launch_syrk(hipStream_t stream, int num_cu, const T *X, i64 ldx, i64 N, int 
     S = std::min<i64>(S, part_capacity_doubles / ((i64)K * K));
     if (S < 1) return 1;
     constexpr int V = SyrkCfg<T>::V;
-    if (zeros && N % V == 0 && K >= 1) {  // LDS-DMA variant: slabs of 8 V rows, two LDS buffers of two panels
+    // (the LDS-DMA variant addresses a group of 8 columns through one 32-bit buffer descriptor and a slab through a 32-bit scalar
+    // offset: 8 ld s and N s below 2^32 -- 67 M fp64 rows per column; beyond, the register-staged kernel)
+    const bool dma_span_ok = (i64)8 * ldx * (i64)sizeof(T) < (1ll << 32) - 4096 && (i64)N * (i64)sizeof(T) < (1ll << 32) - 4096 &&
+                             (!Y || (i64)8 * ldy * (i64)sizeof(T) < (1ll << 32) - 4096);
+    if (zeros && N % V == 0 && K >= 1 && dma_span_ok) {  // LDS-DMA variant: slabs of 8 V rows, two LDS buffers of two panels
         constexpr int RBG = 8 * V;
         constexpr size_t LDS_G = 2 * 2 * (size_t)SYRK_TB * 128 + 2 * 1024;  // two buffers of two panels + two slabs of Y
         const i64 nslabs_g = (N + RBG - 1) / RBG;
