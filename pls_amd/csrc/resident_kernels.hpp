@@ -34,7 +34,8 @@ constexpr int RESIDENT_MAX_WG = 256;
 
 // rows per workgroup = 64 * wps; 0: the shape is not covered
 inline int resident_wps(i64 N, int K, int M, int A, i64 ldx, size_t es, int num_cu) {
-    if (M != 1 || N <= UPD_THREADS || A > K || K < 1 || (i64)TINY_KMAX * ldx * (i64)es >= (1ll << 31)) return 0;
+    if (M != 1 || N < 1 || A > K || K < 1 || (i64)TINY_KMAX * ldx * (i64)es >= (1ll << 31)) return 0;
+    if (tiny_fit_covers(N, K, M, A, ldx, es) || micro_fit_covers(N, K, M, A, ldx, es)) return 0;  // (one workgroup / one wave does it)
     if ((size_t)2 * K * A * 8 > TINY_LDS_MAX) return 0;
     // the TALLEST row block whose column slices still hold K columns: the fewest workgroups -- a workgroup's work per component
     // is its 26 register values per thread whatever the block's shape, while the exchange costs by the number of partial vectors
