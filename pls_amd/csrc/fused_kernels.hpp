@@ -960,7 +960,10 @@ __global__ __launch_bounds__(NT, NT / 256) void retile_xty_kernel(const T *src, 
             const i64 i0 = (tile + u) * R + (i64)rp * V;
             const bool rowok = (tile + u < tile1) && (i0 < N);
             const uint32_t dof = rowok ? doff : OOR;
-            if constexpr (!LT) {
+            if (!dst) {
+                // (no copy asked for: X^T Y alone -- the stand-alone product of 8 responses, which as a kernel of its own re-reads
+                // the Y packs of a row chunk for every 4 columns: twice the bytes of X through the texture path)
+            } else if constexpr (!LT) {
 #pragma unroll
                 for (int j = 0; j < CPTB; ++j) {
                     const int k = cg + CG * (g0 + j);
@@ -1047,15 +1050,18 @@ inline int edge_level(const void *q, i64 ld, int cg_all, int cg_wave) {
 template <typename T, int CGX = 32>
 int launch_retile_xty(hipStream_t stream, int num_cu, const T *src, i64 lds_, const T *Y, i64 ldy, T *dst, i64 ldd, i64 tsd,
                       int rdst, i64 N, int K, int M, double *part, int max_rows, int *nb) {
+    // dst == nullptr: X^T Y alone (no copy): ldd, tsd, rdst are ignored
     constexpr int V = 16 / sizeof(T);
     constexpr int R = (512 / CGX) * V, NT = 512;
     constexpr int CG = NT / (R / V);
-    if (!cols_aligned<T>(dst, ldd) || tsd % V != 0 || rdst < V || R % rdst != 0 || N < 1 || M < 1 || M > 8 || max_rows < 2 ||
+    const bool nostore = dst == nullptr;
+    if (nostore) { ldd = R; tsd = (i64)R * K; rdst = R; }
+    if ((!nostore && !cols_aligned<T>(dst, ldd)) || tsd % V != 0 || rdst < V || R % rdst != 0 || N < 1 || M < 1 || M > 8 || max_rows < 2 ||
         !elem_aligned<T>(Y))
         return 1;
     const int edge = edge_level<T>(src, lds_, CG, WAVE / (R / V));
     if (edge < 0) return 1;
-    if (((i64)(R / rdst) * tsd + (i64)CG * ldd) * (i64)sizeof(T) >= (1ll << 31)) return 1;
+    if (!nostore && ((i64)(R / rdst) * tsd + (i64)CG * ldd) * (i64)sizeof(T) >= (1ll << 31)) return 1;
     const i64 Nf = N - N % V;
     int gx = 0;
     if (Nf > 0) {
@@ -1066,14 +1072,15 @@ int launch_retile_xty(hipStream_t stream, int num_cu, const T *src, i64 lds_, co
         // ONE workgroup per CU in total (consecutive tiles per workgroup), at most max_rows - 1 row chunks: like every
         // read+write sweep of this library the copy is faster with less in flight -- config 4 (8 responses) 0.797 -> 0.719 ms,
         // 65,536 x 8,192 fp32 1.088 -> 1.020 ms, config 3 -1.5 % (three alternating pairs, profiles/r4/retile_xty_wgs.txt)
-        const i64 want = std::max<i64>(1, std::min<i64>(((i64)num_cu + nkb - 1) / nkb, max_rows - 1));
+        // (a read-only sweep -- no copy -- wants more in flight: four workgroups per CU in all)
+        const i64 want = std::max<i64>(1, std::min<i64>(((i64)(nostore ? 4 : 1) * num_cu + nkb - 1) / nkb, max_rows - 1));
         const i64 tpw = (ntiles + want - 1) / want;
         gx = (int)((ntiles + tpw - 1) / tpw);
         const dim3 g((unsigned)gx, (unsigned)nkb), b(NT);
         // destination tiles of ONE row pack, one or two responses: transposed through LDS (the 32-group source tile only).
         // Measured: 87,381 x 6,144 fp64 3.14 -> 2.17 ms; with 8 responses (4 columns per lane, two tiles in flight) no gain,
         // and two-pack tiles (config 4: 128-byte runs already) lose, 0.82 -> 1.10 ms -- those keep the direct stores.
-        const bool lt = CGX == 32 && rdst == V && M <= 2;
+        const bool lt = CGX == 32 && rdst == V && M <= 2 && !nostore;
 #define RX_LAUNCH(CPTB_, MT_, E_) \
     hipLaunchKernelGGL((retile_xty_kernel<T, V, R, NT, CPTB_, MT_, E_>), g, b, 0, stream, src, lds_, Y, ldy, dst, ldd, tsd, rdst, Nf, K, M, part, (int)tpw)
 #define RX_LAUNCH_LT(CPTB_, MT_, E_)                                                                                      \
