@@ -10,6 +10,8 @@ struct ResidentTurn {
     std::mutex mu;
     hipEvent_t ev[64] = {};
     bool have[64] = {};
+    hipStream_t last[64] = {};  // the stream of the last resident launch (the same stream again: its own order is enough)
+    bool any[64] = {};
 };
 inline ResidentTurn &resident_turns() {
     static ResidentTurn t;
@@ -19,7 +21,7 @@ inline void resident_turn(pls_hip_context *c) {
     ResidentTurn &t = resident_turns();
     std::lock_guard<std::mutex> lock(t.mu);
     const int d = c->device & 63;
-    if (t.have[d]) (void)hipStreamWaitEvent(c->stream, t.ev[d], 0);
+    if (t.have[d] && t.any[d] && t.last[d] != c->stream) (void)hipStreamWaitEvent(c->stream, t.ev[d], 0);
 }
 inline void resident_done(pls_hip_context *c) {
     ResidentTurn &t = resident_turns();
@@ -33,6 +35,8 @@ inline void resident_done(pls_hip_context *c) {
         t.have[d] = true;
     }
     (void)hipEventRecord(t.ev[d], c->stream);
+    t.last[d] = c->stream;
+    t.any[d] = true;
 }
 
 // ---- the fit on device pointers -----------------------------------------------------------
@@ -64,7 +68,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     // Mid-size single-response data (beyond one workgroup's 1024 rows, up to ~50 MB): the same single launch on up to 256
     // workgroups with one grid-wide exchange per component (resident_kernels.hpp)
     if (method == PLS_HIP_KERNEL_TYPE1 && (c->opt_algo == PLS_HIP_ALGO_KERNEL || c->opt_algo == PLS_HIP_ALGO_AUTO) && c->opt_fuse &&
-        !c->reducer && c->env.tiny && c->env.resident && plsk::elem_aligned<T>(X) && plsk::elem_aligned<T>(Y) && Tm) {
+        !c->reducer && c->env.tiny && c->env.resident && !c->opt_graph /* (a replayed graph would re-use one launch's arrival counter) */ &&
+        plsk::elem_aligned<T>(X) && plsk::elem_aligned<T>(Y) && Tm) {
         const int wps = plsk::resident_wps(N, K, M, A, ldx, sizeof(T), c->num_cu);
         if (wps > 0 && host_flags(c)) {
             const int G = (int)((N + (i64)plsk::WAVE * wps - 1) / ((i64)plsk::WAVE * wps));
@@ -96,6 +101,50 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             resident_turn(c);
             hipLaunchKernelGGL((plsk::resident_fit_kernel<T>), dim3(G), dim3(plsk::UPD_THREADS), (size_t)2 * K * A * 8, c->stream, X, ldx, Y,
                                N, K, A, W, P, Q, R, Tm, ldt, B, wps, sy);
+            LAUNCH_CHECK(c);
+            resident_done(c);
+            return PLS_HIP_OK;
+        }
+    }
+    // ... and the same for 2..8 responses (resident_fit_m_kernel)
+    if (method == PLS_HIP_KERNEL_TYPE1 && (c->opt_algo == PLS_HIP_ALGO_KERNEL || c->opt_algo == PLS_HIP_ALGO_AUTO) && c->opt_fuse &&
+        !c->reducer && c->env.tiny && c->env.resident && !c->opt_graph /* (a replayed graph would re-use one launch's arrival counter) */ &&
+        plsk::elem_aligned<T>(X) && plsk::elem_aligned<T>(Y) && Tm) {
+        const int wps = plsk::resident_m_wps(N, K, M, A, ldx, sizeof(T), c->num_cu);
+        if (wps > 0 && host_flags(c)) {
+            const int G = (int)((N + (i64)plsk::WAVE * wps - 1) / ((i64)plsk::WAVE * wps));
+            const int LP = (std::max(K + 1, std::min(K * M, (int)plsk::UPD_THREADS)) + 7) & ~7;
+            const size_t need = 256 + (size_t)2 * G * LP * 8;
+            if (c->resident.bytes < need) {
+                CHK(ensure(c, c->resident, need));
+                HIPCHK(c, hipMemsetAsync(c->resident.p, 0, 256, c->stream));
+                c->resident_launches = 0;
+            }
+            plsk::ResidentSync sy;
+            unsigned *ctr = (unsigned *)c->resident.p;
+            sy.bar = ctr + 16 * (c->resident_launches & 1);
+            sy.bar_next = ctr + 16 * ((c->resident_launches + 1) & 1);
+            ++c->resident_launches;
+            sy.part = (double *)((char *)c->resident.p + 256);
+            sy.status = c->diverged_dev + 1;
+            sy.limit = (long long)(0.05 * 1e8);
+#ifdef PLS_HIP_TESTING
+            if (const char *e = getenv("PLS_HIP_TEST_RESIDENT_LIMIT_TICKS")) sy.limit = atoll(e);
+#endif
+            sy.LP = LP;
+            const size_t lds = (size_t)(2 * K + M) * A * 8;
+            Range r_fit("pls_hip_fit (single launch, resident)");
+            Scope s(c, PLS_HIP_FAM_SMALL, ((i64)N * K + (i64)N * M + (i64)N * A) * (i64)sizeof(T) + (3 * (i64)K + M) * A * 8);
+#define RES_M(MM_)                                                                                                              \
+    do {                                                                                                                        \
+        if (!plsk::raise_dynamic_lds((const void *)plsk::resident_fit_m_kernel<T, MM_>, (int)plsk::TINY_LDS_MAX))                 \
+            return fail(c, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the resident fit could not be raised");                      \
+        resident_turn(c);                                                                                                       \
+        hipLaunchKernelGGL((plsk::resident_fit_m_kernel<T, MM_>), dim3(G), dim3(plsk::UPD_THREADS), lds, c->stream, X, ldx, Y, ldy,  \
+                           N, K, M, A, (int)c->opt_power_iters, W, P, Q, R, Tm, ldt, B, wps, sy);                               \
+    } while (0)
+            if (M <= 2) RES_M(2); else if (M <= 4) RES_M(4); else RES_M(8);
+#undef RES_M
             LAUNCH_CHECK(c);
             resident_done(c);
             return PLS_HIP_OK;

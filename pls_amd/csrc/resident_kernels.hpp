@@ -231,4 +231,176 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
     (void)ok;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same one launch for 2 <= M <= 8 responses: tiny_fit_m_kernel's workgroup (XY of K x M in LDS, the direction by the one-wave
+// eigen solver) x G, with X^T Y exchanged once -- the K M values in pieces of at most 1024 -- and [X^T t, t^T t] per component.
+// Dynamic LDS: (2 K + M) A doubles.
+// ---------------------------------------------------------------------------------------------------------------------
+inline int resident_m_wps(i64 N, int K, int M, int A, i64 ldx, size_t es, int num_cu) {
+    if (M < 2 || M > 8 || N < 1 || A > K || K < 1 || (i64)TINY_KMAX * ldx * (i64)es >= (1ll << 31)) return 0;
+    if (tiny_fit_m_covers(N, K, M, A, ldx, es) || micro_fit_covers(N, K, M, A, ldx, es)) return 0;
+    if ((size_t)(2 * K + M) * A * 8 > TINY_LDS_MAX) return 0;
+    for (int wps = UPD_WAVES; wps >= 1; wps /= 2) {
+        const i64 G = (N + (i64)WAVE * wps - 1) / ((i64)WAVE * wps);
+        if (K <= (UPD_WAVES / wps) * TINY_RC && G <= std::min(num_cu, RESIDENT_MAX_WG)) return wps;
+    }
+    return 0;
+}
+
+template <typename T, int MM>
+__global__ __launch_bounds__(UPD_THREADS) void resident_fit_m_kernel(const T *__restrict__ X, i64 ldx, const T *__restrict__ Y, i64 ldy,
+                                                                     i64 N, int K, int M, int A, int power_iters,
+                                                                     double *__restrict__ W, double *__restrict__ P,
+                                                                     double *__restrict__ Q, double *__restrict__ R,
+                                                                     T *__restrict__ Tm, i64 ldt, double *__restrict__ B, int wps,
+                                                                     const ResidentSync sy) {
+    static_assert(MM * MM <= WAVE, "one wave solves the eigenproblem");
+    extern __shared__ double dyn[];
+    double *Pl = dyn, *Rl = dyn + (i64)K * A, *Ql = dyn + 2 * (i64)K * A;  // P[:, j], R[:, j], Q[:, j] as they are produced
+    __shared__ double tp[UPD_THREADS], colp[UPD_WAVES][TINY_RC], praw[TINY_KMAX + 8], tot[UPD_THREADS], xy[MM][TINY_KMAX], wl[TINY_KMAX],
+        vsl[TINY_KMAX];
+    __shared__ double cs[TINY_KMAX], sred[UPD_WAVES], Gs[MM * MM], Bs[MM * MM], Cs[MM * MM], qs[MM], qa[MM];
+    __shared__ int flag;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    TinyShape shp(1);
+    shp.wps = wps;
+    shp.S = UPD_WAVES / wps;
+    const i64 row0 = (i64)blockIdx.x * WAVE * wps;
+    const int s = wv / shp.wps, rb = wv % shp.wps, il = rb * WAVE + lane;
+    const i64 i = row0 + il;
+    const bool act = s < shp.S && i < N;
+    const int k = tid;
+    const bool kok = k < K;
+    const bool lead = blockIdx.x == 0;
+    const int slot = (k % shp.S) * TINY_RC + k / shp.S;
+
+    const uint32_t nrec = (uint32_t)(((i64)(K - 1) * ldx + N) * (i64)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X), (short)0, (int)nrec, BUF_WORD3);
+    const uint32_t voff = act ? (uint32_t)((i + (i64)s * ldx) * (i64)sizeof(T)) : 0x80000000u;
+    const uint32_t cstep = (uint32_t)((i64)shp.S * ldx * (i64)sizeof(T));
+    double x[TINY_RC];
+#pragma unroll
+    for (int j = 0; j < TINY_RC; ++j) x[j] = tiny_ld<T>(rs, voff, (uint32_t)j * cstep);
+    for (int c = tid; c < TINY_KMAX; c += UPD_THREADS) vsl[c] = 0.0;
+    unsigned phase = 0;
+    bool ok = true;
+    if (lead && tid == 0) __hip_atomic_store(sy.bar_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // XY = X^T Y (:396): this workgroup's rows, response by response; then the K M values meet in pieces of <= 1024
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        if (m < M) {
+            const double yv = act ? (double)Y[i + (i64)m * ldy] : 0.0;
+            tiny_column_sums(x, yv, colp, K, shp, xy[m]);
+        } else if (kok) {
+            xy[m][k] = 0.0;
+        }
+    }
+    lds_barrier();
+    {
+        const int L = K * M;
+        for (int f0 = 0; f0 < L; f0 += UPD_THREADS) {
+            const int n = min(UPD_THREADS, L - f0);
+            if (tid < n) tot[tid] = xy[(f0 + tid) / K][(f0 + tid) % K];  // (the exchange reads its input before it writes its output)
+            lds_barrier();
+            ok = resident_grid_sum(tot, n, sy, phase++, tot, tp, &flag, ok);
+            if (tid < n) xy[(f0 + tid) / K][(f0 + tid) % K] = tot[tid];
+            lds_barrier();
+        }
+    }
+    const double *vs = vsl + s * TINY_RC;
+    for (int a = 0; a < A; ++a) {
+        // ---- direction (:403-411): G = XY^T XY, one wave per pair (i <= j)
+        lds_barrier();  // XY complete
+        for (int pr = wv; pr < MM * (MM + 1) / 2; pr += UPD_WAVES) {
+            int gi = 0, rem = pr;
+            while (rem >= MM - gi) { rem -= MM - gi; ++gi; }
+            const int gj = gi + rem;
+            double g = 0.0;
+            for (int kk = lane; kk < K; kk += WAVE) g = fma(xy[gi][kk], xy[gj][kk], g);
+            g = wave_sum(g);
+            if (lane == 0) { Gs[gi + gj * MM] = g; Gs[gj + gi * MM] = g; }
+        }
+        lds_barrier();
+        if (wv == 0) dominant_eigvec_wave<MM>(Gs, Bs, Cs, qs, power_iters);
+        lds_barrier();
+        double wk = 0.0;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) wk = fma(kok ? xy[m][k] : 0.0, qs[m], wk);  // w = XY q (:408)
+        wk = wk / sqrt(tiny_block_sum(wk * wk, sred));                          // (:411)
+        if (kok) {
+            if (lead) W[k + (i64)a * K] = wk;
+            wl[k] = wk;
+        }
+        lds_barrier();
+        for (int j = wv; j < a; j += UPD_WAVES) {  // c_j = p_j^T w, against the ORIGINAL w (:415)
+            double c = 0.0;
+            for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
+            c = wave_sum(c);
+            if (lane == 0) cs[j] = c;
+        }
+        lds_barrier();
+        double r = wk;
+        for (int j = 0; j < a; ++j) r -= cs[j] * Rl[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
+        if (kok) {
+            if (lead) R[k + (i64)a * K] = r;
+            Rl[k + (i64)a * K] = r;
+            vsl[slot] = r;
+        }
+        lds_barrier();  // r_a complete
+        // ---- score, loading (:419-427)
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < TINY_RC; ++j) {
+            acc = fma(x[j], vs[j], acc);
+            if (j % 8 == 7) asm volatile("" ::: "memory");
+        }
+        tp[tid] = acc;
+        lds_barrier();
+        double ti = 0.0;
+        if (act)
+            for (int q = 0; q < shp.S; ++q) ti += tp[(q * shp.wps + rb) * WAVE + lane];
+        ti = (double)(T)ti;  // the score as stored
+        if (act && s == 0) Tm[i + (i64)a * ldt] = (T)ti;
+        const double ttl = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // this workgroup's rows of t^T t (:420)
+        tiny_column_sums(x, ti, colp, K, shp, praw);                              // ... and of X^T t (:421)
+        if (tid == 0) praw[K] = ttl;
+        lds_barrier();
+        ok = resident_grid_sum(praw, K + 1, sy, phase++, tot, tp, &flag, ok);
+        const double tt = tot[K];
+        const double p = kok ? tot[k] / tt : 0.0;  // (:427)
+        if (kok) {
+            if (lead) P[k + (i64)a * K] = p;
+            Pl[k + (i64)a * K] = p;
+        }
+        // ---- q = XY^T r / tt (:428): one wave per response
+        if (wv < MM) {
+            double c = 0.0;
+            for (int kk = lane; kk < K; kk += WAVE) c = fma(Rl[kk + (i64)a * K], xy[wv][kk], c);
+            c = wave_sum(c) / tt;
+            if (lane == 0) {
+                qa[wv] = c;
+                if (wv < M) {
+                    Ql[wv + (i64)a * M] = c;
+                    if (lead) Q[wv + (i64)a * M] = c;
+                }
+            }
+        }
+        lds_barrier();
+        if (kok) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m) xy[m][k] -= (p * qa[m]) * tt;  // XY -= (p q^T) tt (:429)
+        }
+    }
+    lds_barrier();
+    if (B && kok && lead)  // B = R Q^T (:444-447)
+        for (int m = 0; m < M; ++m) {
+            double b = 0.0;
+            for (int a = 0; a < A; ++a) b = fma(Rl[k + (i64)a * K], Ql[m + (i64)a * M], b);
+            B[k + (i64)m * K] = b;
+        }
+    (void)ok;
+}
+
 }  // namespace plsk

@@ -225,8 +225,10 @@ def test_sharded_gram_and_type2(algo, method):
 
 
 def _nccl_worker(port, q):
+    # (PLS_HIP_RESIDENT=0: the reducer-free fit of this size would otherwise be the one-launch resident fit, whose sums meet
+    # in another order -- the comparison below is bit for bit between the SAME launches with and without a reducer)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", PLS_HIP_RESIDENT="0")
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -263,6 +265,7 @@ def test_nccl_reducer_single_rank():
 
 def _rccl_direct_worker(q):
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["PLS_HIP_RESIDENT"] = "0"  # (the same launches with and without the reducer: see _nccl_worker)
     sys.path.insert(0, ROOT)
     import torch
     import pls_amd

@@ -859,7 +859,10 @@ def test_auto_plan_choice(handle):
         assert tm["launches"]["fused"] == 2                                      # two components: passes are cheaper
         Xs = handle.synth_x(0, 500, 64, 5); Ys = handle.synth_y(0, 500, 1, 5)
         handle.fit_device(Xs, Ys, 20); tm = handle.timing()
-        assert tm["launches"]["fused"] == 20                                     # small N: KERNEL
+        assert tm["launches"]["fused"] == 0 and tm["launches"]["xty"] == 0          # small N: the one-launch resident fit
+        Xw = handle.synth_x(0, 2000, 600, 5); Yw = handle.synth_y(0, 2000, 1, 5)
+        handle.fit_device(Xw, Yw, 20); tm = handle.timing()
+        assert tm["launches"]["fused"] == 20                                     # beyond its 416 columns: KERNEL
     finally:
         handle.set_option(pls_amd.OPT_ALGO, 0)
         handle.set_option(pls_amd.OPT_PROFILE, 0)
@@ -973,10 +976,12 @@ def test_more_than_4096_components(handle, po):
     assert np.abs(G / np.outer(d, d) - np.eye(40)).max() < 1e-8
 
 
-@pytest.mark.parametrize("N,K,A,dt,pad", [(1025, 26, 5, "f64", 0), (5000, 128, 10, "f64", 0), (4001, 416, 6, "f64", 3), (20000, 16, 5, "f64", 1),
-                                          (100000, 40, 12, "f64", 0), (262144, 26, 4, "f64", 0), (3001, 77, 7, "f32", 5), (70000, 50, 9, "f32", 0)])
-def test_resident_single_launch_fit(handle, oracle, po, N, K, A, dt, pad):
-    """Mid-size single-response fits run as ONE launch on up to 256 workgroups (resident_kernels.hpp): every workgroup keeps its
+@pytest.mark.parametrize("N,K,A,dt,pad,M", [(1025, 26, 5, "f64", 0, 1), (5000, 128, 10, "f64", 0, 1), (4001, 416, 6, "f64", 3, 1), (20000, 16, 5, "f64", 1, 1),
+                                            (100000, 40, 12, "f64", 0, 1), (262144, 26, 4, "f64", 0, 1), (3001, 77, 7, "f32", 5, 1), (70000, 50, 9, "f32", 0, 1),
+                                            (1024, 40, 6, "f64", 0, 1), (1025, 26, 5, "f64", 0, 3), (5000, 128, 8, "f64", 2, 4), (4001, 416, 5, "f64", 0, 2),
+                                            (100000, 40, 12, "f64", 0, 8), (3001, 77, 7, "f32", 1, 5), (2000, 300, 4, "f64", 0, 8)])
+def test_resident_single_launch_fit(handle, oracle, po, N, K, A, dt, pad, M):
+    """Mid-size fits of 1..8 responses run as ONE launch on up to 256 workgroups (resident_kernels.hpp): every workgroup keeps its
     rows of X in registers, one grid-wide exchange per component.  Every rows-per-workgroup shape (64 ... 1024), ragged last
     workgroups, a padded leading dimension, fp32 storage: results against the oracle and the general plan (PLS_HIP_RESIDENT=0),
     one launch in all, repeated fits equal bit for bit."""
@@ -986,7 +991,7 @@ def test_resident_single_launch_fit(handle, oracle, po, N, K, A, dt, pad):
     Xbig = torch.zeros((K, N + pad), dtype=tdt, device="cuda")
     Xbig[:, :N] = handle.synth_x(5, N, K, 31, dtype=tdt).T
     Xd = Xbig.T[:N]                                   # column-major view, ld = N + pad
-    Yd = handle.synth_y(5, N, 1, 31, dtype=tdt)
+    Yd = handle.synth_y(5, N, M, 31, dtype=tdt)
     Xh = np.asfortranarray(Xd.cpu().numpy().astype(np.float64)); Yh = np.asfortranarray(Yd.cpu().numpy().astype(np.float64))
     ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
     handle.set_option(pls_amd.OPT_PROFILE, 2)
@@ -1151,9 +1156,8 @@ def test_graph_replay_of_repeated_fits(oracle, po):
     import pls_amd
     torch = _torch()
     side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        h = pls_amd.Handle()
-        N, K, M, A = 3000, 96, 2, 5
+    with torch.cuda.stream(side), handle_with_env(PLS_HIP_RESIDENT=0) as h:  # (the launches of the general plan, eager and replayed:
+        N, K, M, A = 3000, 96, 2, 5                                          #  the one-launch resident fit is never captured)
         X = h.synth_x(0, N, K, 11); Y = h.synth_y(0, N, M, 11)
         for algo in (pls_amd.ALGO_KERNEL, pls_amd.ALGO_NIPALS):
             h.set_option(pls_amd.OPT_ALGO, algo)
@@ -1176,7 +1180,6 @@ def test_graph_replay_of_repeated_fits(oracle, po):
         ref = oracle.plsr(X[:2000].cpu().numpy(), Y[:2000].cpu().numpy(), A)
         assert po.rel_fro(o3["B"].cpu().numpy(), oracle.coefficients(ref["R"], ref["Q"])) < 1e-10
         h.set_option(pls_amd.OPT_GRAPH, 0)
-        h.close()
 
 
 def _fold_reference(oracle, Xh, Yh, A, idx):

@@ -8,10 +8,12 @@ from oracle import pls_oracle as po
 one = po.OracleLib(omp=False)
 h = pls_amd.Handle()
 bad = 0
-for (N, K, A, dt) in ((1025, 26, 5, "f64"), (2000, 30, 5, "f64"), (5000, 128, 10, "f64"), (5000, 20, 5, "f64"), (8000, 100, 5, "f64"), (4000, 400, 5, "f64"),
-                      (20000, 16, 5, "f64"), (10000, 64, 8, "f64"), (100000, 40, 12, "f64"), (200000, 26, 6, "f64"), (3001, 77, 7, "f32"), (65537, 50, 9, "f32")):
+for (N, K, A, dt, M) in ((1025, 26, 5, "f64", 1), (2000, 30, 5, "f64", 1), (5000, 128, 10, "f64", 1), (5000, 20, 5, "f64", 1), (8000, 100, 5, "f64", 1), (4000, 400, 5, "f64", 1),
+                      (20000, 16, 5, "f64", 1), (10000, 64, 8, "f64", 1), (100000, 40, 12, "f64", 1), (200000, 26, 6, "f64", 1), (3001, 77, 7, "f32", 1), (65537, 50, 9, "f32", 1),
+                      (1025, 26, 5, "f64", 3), (2000, 30, 5, "f64", 2), (5000, 128, 10, "f64", 4), (8000, 100, 5, "f64", 8), (4000, 400, 5, "f64", 3), (20000, 16, 5, "f64", 5),
+                      (100000, 40, 12, "f64", 8), (200000, 26, 6, "f64", 2), (3001, 77, 7, "f32", 3), (65537, 50, 9, "f32", 8)):
     tdt = torch.float64 if dt == "f64" else torch.float32
-    X = h.synth_x(3, N, K, 11, dtype=tdt); Y = h.synth_y(3, N, 1, 11, dtype=tdt)
+    X = h.synth_x(3, N, K, 11, dtype=tdt); Y = h.synth_y(3, N, M, 11, dtype=tdt)
     Xh = X.cpu().numpy().astype(np.float64); Yh = Y.cpu().numpy().astype(np.float64)
     ref = one.plsr(Xh, Yh, A); Bref = one.coefficients(ref["R"], ref["Q"])
     res = {}
@@ -31,6 +33,6 @@ for (N, K, A, dt) in ((1025, 26, 5, "f64"), (2000, 30, 5, "f64"), (5000, 128, 10
     tol = 1e-10 if dt == "f64" else 2e-5
     flag = "" if res["1"][1] < tol and res["1"][2] < (1e-8 if dt == "f64" else 1e-3) else "   <-- BAD"
     bad += bool(flag)
-    print("N=%7d K=%4d A=%2d %s  resident %8.1f us (B err %.1e, T err %.1e)   general plan %8.1f us (B err %.1e)   x%.2f%s" % (
-        N, K, A, dt, res["1"][0], res["1"][1], res["1"][2], res["0"][0], res["0"][1], res["0"][0] / res["1"][0], flag), flush=True)
+    print("N=%7d K=%4d M=%d A=%2d %s  resident %8.1f us (B err %.1e, T err %.1e)   general plan %8.1f us (B err %.1e)   x%.2f%s" % (
+        N, K, M, A, dt, res["1"][0], res["1"][1], res["1"][2], res["0"][0], res["0"][1], res["0"][0] / res["1"][0], flag), flush=True)
 print("done:", bad, "bad")
