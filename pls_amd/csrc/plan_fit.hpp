@@ -70,7 +70,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
     if (method == PLS_HIP_KERNEL_TYPE1 && (c->opt_algo == PLS_HIP_ALGO_KERNEL || c->opt_algo == PLS_HIP_ALGO_AUTO) && c->opt_fuse &&
         !c->reducer && c->env.tiny && c->env.resident && !c->opt_graph /* (a replayed graph would re-use one launch's arrival counter) */ &&
         plsk::elem_aligned<T>(X) && plsk::elem_aligned<T>(Y) && Tm) {
-        const int wps = plsk::resident_wps(N, K, M, A, ldx, sizeof(T), c->num_cu);
+        // (the score columns go out through one buffer descriptor per workgroup: A ld s below 2^31)
+        const int wps = (i64)A * ldt * (i64)sizeof(T) < (1ll << 31) ? plsk::resident_wps(N, K, M, A, ldx, sizeof(T), c->num_cu) : 0;
         if (wps > 0 && host_flags(c)) {
             const int G = (int)((N + (i64)plsk::WAVE * wps - 1) / ((i64)plsk::WAVE * wps));
             const int LP = (K + 1 + 7) & ~7;

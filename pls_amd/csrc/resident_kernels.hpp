@@ -149,6 +149,12 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
     const double yv = act ? (double)Y[i] : 0.0;
     unsigned phase = 0;
     bool ok = true;
+    // outputs through buffer descriptors (tiny_kernels.hpp, out_rsrc): only the first workgroup writes the K-sized ones
+    const i64 ka8 = lead ? (i64)K * A * 8 : 0;
+    const __amdgpu_buffer_rsrc_t rW = out_rsrc(W, ka8), rP = out_rsrc(P, ka8), rR = out_rsrc(R, ka8);
+    const __amdgpu_buffer_rsrc_t rT = out_rsrc(Tm + row0, ((i64)(A - 1) * ldt + min((i64)WAVE * wps, N - row0)) * (i64)sizeof(T));
+    const uint32_t kof = kok ? (uint32_t)k * 8u : 0x80000000u;
+    const uint32_t tof = (act && s == 0) ? (uint32_t)il * (uint32_t)sizeof(T) : 0x80000000u;
 
     tiny_column_sums(x, yv, colp, K, shp, praw);  // this workgroup's rows of XY = X^T Y (:396)
     lds_barrier();
@@ -157,11 +163,9 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
     double xyk = kok ? tot[k] : 0.0;
     {  // w_0 = XY / |XY| (:404, :411), r_0 = w_0
         const double w = xyk / sqrt(tiny_block_sum(xyk * xyk, sred));
+        st_out(rW, kof, 0, w);
+        st_out(rR, kof, 0, w);
         if (kok) {
-            if (lead) {
-                W[k] = w;
-                R[k] = w;
-            }
             Rl[k] = w;
             vsl[slot] = w;
         }
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
         if (act)
             for (int q = 0; q < shp.S; ++q) ti += tp[(q * shp.wps + rb) * WAVE + lane];
         ti = (double)(T)ti;  // the score as stored
-        if (act && s == 0) Tm[i + (i64)a * ldt] = (T)ti;
+        st_score<T>(rT, tof, (uint32_t)((i64)a * ldt * (i64)sizeof(T)), ti);
         const double ttl = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // this workgroup's rows of t^T t (:420)
         tiny_column_sums(x, ti, colp, K, shp, praw);                                     // ... and of X^T t (:427)
         if (tid == 0) praw[K] = ttl;
@@ -190,10 +194,8 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
         const double tt = tot[K];
         const double p = kok ? tot[k] / tt : 0.0;                                                      // (:427)
         const double q = tiny_block_sum(kok ? Rl[k + (i64)a * K] * xyk : 0.0, sred) / tt;        // q = r^T XY / tt (:428)
-        if (kok) {
-            if (lead) P[k + (i64)a * K] = p;
-            Pl[k + (i64)a * K] = p;
-        }
+        st_out(rP, kof, (uint32_t)a * (uint32_t)K * 8u, p);
+        if (kok) Pl[k + (i64)a * K] = p;
         if (tid == 0) {
             if (lead) Q[a] = q;
             ql[a] = q;
@@ -202,10 +204,8 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
         const int n = a + 1;
         if (n >= A) break;
         const double w = xyk / sqrt(tiny_block_sum(xyk * xyk, sred));  // (:404, :411)
-        if (kok) {
-            if (lead) W[k + (i64)n * K] = w;
-            wl[k] = w;
-        }
+        st_out(rW, kof, (uint32_t)n * (uint32_t)K * 8u, w);
+        if (kok) wl[k] = w;
         lds_barrier();
         for (int j = wv; j < n; j += UPD_WAVES) {  // c_j = p_j^T w, against the ORIGINAL w (:415)
             double c = 0.0;
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
         lds_barrier();
         double r = w;
         for (int j = 0; j < n; ++j) r -= cs[j] * Rl[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
+        st_out(rR, kof, (uint32_t)n * (uint32_t)K * 8u, r);
         if (kok) {
-            if (lead) R[k + (i64)n * K] = r;
             Rl[k + (i64)n * K] = r;
             vsl[slot] = r;
         }

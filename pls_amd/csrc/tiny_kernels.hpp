@@ -45,6 +45,31 @@ __device__ __forceinline__ double tiny_ld(__amdgpu_buffer_rsrc_t rs, uint32_t vo
     }
 }
 
+// The K x A outputs (W, P, R) and the score columns are STORED through buffer descriptors as well: one lane offset (k or i) in a
+// vector register, the column (a K, a ld) in the instruction's scalar offset.  With plain pointers the compiler keeps a 64-bit
+// per-lane address for every output across the component loop -- and, at the 128 registers a 1024-thread workgroup leaves,
+// spills them: 17 scratch reloads per component in tiny_fit_kernel (round 5).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(const void *p, i64 bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)bytes, BUF_WORD3);
+}
+__device__ __forceinline__ void st_out(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, double v) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 raw;
+    __builtin_memcpy(&raw, &v, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(raw, r, voff, soff, 0);
+}
+template <typename T>
+__device__ __forceinline__ void st_score(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, double v) {
+    if constexpr (sizeof(T) == 8) {
+        st_out(r, voff, soff, v);
+    } else {
+        const float f = (float)v;
+        unsigned raw;
+        __builtin_memcpy(&raw, &f, 4);
+        __builtin_amdgcn_raw_buffer_store_b32(raw, r, voff, soff, 0);
+    }
+}
+
 constexpr size_t TINY_LDS_MAX = 96 * 1024;  // dynamic LDS: the P and R columns, 2 * K * A doubles
 inline bool tiny_fit_covers(i64 N, int K, int M, int A, i64 ldx, size_t es) {
     if (M != 1 || N < 1 || N > UPD_THREADS || A > K || (i64)TINY_KMAX * ldx * (i64)es >= (1 << 30)) return false;  // 32-bit byte offsets
@@ -125,6 +150,12 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
     for (int c = tid; c < TINY_KMAX; c += UPD_THREADS) vsl[c] = 0.0;  // read (times x = 0) beyond K
 
     const bool fold = fold_idx != nullptr;
+    // output descriptors (fold mode writes none of them: zero records, every store dropped)
+    const i64 ka8 = fold ? 0 : (i64)K * A * 8;
+    const __amdgpu_buffer_rsrc_t rW = out_rsrc(W, ka8), rP = out_rsrc(P, ka8), rR = out_rsrc(R, ka8);
+    const __amdgpu_buffer_rsrc_t rT = out_rsrc(Tm, fold ? 0 : ((i64)(A - 1) * ldt + N) * (i64)sizeof(T));
+    const uint32_t kof = kok ? (uint32_t)k * 8u : 0x80000000u;                                   // lane offset of entry k
+    const uint32_t tof = (act && s == 0) ? (uint32_t)i * (uint32_t)sizeof(T) : 0x80000000u;      // ... of row i
     int hpos = -1;  // position of this thread's row in the fold's held-out list
     if (fold && act)
         for (int j = 0; j < ts; ++j)
@@ -137,11 +168,9 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
     double xyk = kok ? xy[k] : 0.0;
     {  // w_0 = XY / |XY| (:404, :411), r_0 = w_0
         const double w = xyk / sqrt(tiny_block_sum(xyk * xyk, sred));
+        st_out(rW, kof, 0, w);
+        st_out(rR, kof, 0, w);
         if (kok) {
-            if (!fold) {
-                W[k] = w;
-                R[k] = w;
-            }
             Rl[k] = w;
             vsl[slot] = w;
         }
@@ -162,16 +191,14 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
             for (int q = 0; q < shp.S; ++q) ti += tp[(q * shp.wps + rb) * WAVE + lane];
         const double ui = ti;     // x_i . r_a, also for a held-out row
         if (held) ti = 0.0;       // ... which has no score in its fold's fit
-        if (act && s == 0 && !fold) Tm[i + (i64)a * ldt] = (T)ti;
+        st_score<T>(rT, tof, (uint32_t)((i64)a * ldt * (i64)sizeof(T)), ti);
         const double tt = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // (:420)
         tiny_column_sums(x, ti, colp, K, shp, praw);                                    // X^T t (:427)
         lds_barrier();
         const double p = kok ? praw[k] / tt : 0.0;                                                        // (:427)
         const double q = tiny_block_sum(kok ? Rl[k + (i64)a * K] * xyk : 0.0, sred) / tt;          // q = r^T XY / tt (:428)
-        if (kok) {
-            if (!fold) P[k + (i64)a * K] = p;
-            Pl[k + (i64)a * K] = p;
-        }
+        st_out(rP, kof, (uint32_t)a * (uint32_t)K * 8u, p);
+        if (kok) Pl[k + (i64)a * K] = p;
         if (tid == 0) {
             if (!fold) Q[a] = q;
             ql[a] = q;
@@ -184,10 +211,8 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
         const int n = a + 1;
         if (n >= A) break;
         const double w = xyk / sqrt(tiny_block_sum(xyk * xyk, sred));  // (:404, :411)
-        if (kok) {
-            if (!fold) W[k + (i64)n * K] = w;
-            wl[k] = w;
-        }
+        st_out(rW, kof, (uint32_t)n * (uint32_t)K * 8u, w);
+        if (kok) wl[k] = w;
         lds_barrier();
         for (int j = wv; j < n; j += UPD_WAVES) {  // c_j = p_j^T w, against the ORIGINAL w (:415)
             double c = 0.0;
@@ -198,8 +223,8 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
         lds_barrier();
         double r = w;
         for (int j = 0; j < n; ++j) r -= cs[j] * Rl[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
+        st_out(rR, kof, (uint32_t)n * (uint32_t)K * 8u, r);
         if (kok) {
-            if (!fold) R[k + (i64)n * K] = r;
             Rl[k + (i64)n * K] = r;
             vsl[slot] = r;
         }
