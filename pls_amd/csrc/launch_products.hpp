@@ -131,6 +131,41 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
                 continue;
             }
         }
+        if (rem > 4 && c->env.xb4 && vec_ok<T>(X, ldx, FV) && vec_ok<T>(o, ldo, FV)) {
+            // 5..32 columns (fp32 storage: ..24) with all of Bm in LDS: the 4 x 4 x 4 MFMA form, columns padded to 4 (xb_mfma4.hpp)
+            const int use = std::min(rem, sizeof(T) == 8 ? 32 : 24);
+            const int ncg = (use + 3) / 4;
+            const i64 ntiles = N / (16 * FV);
+            const size_t lds = (size_t)plsk::xb4_kp(K, plsk::xb4_u(FV, ncg)) * plsk::xb4_stride(ncg) * 8;
+            const int waves = plsk::XB4_WG / plsk::WAVE;
+            if (lds <= 152 * 1024 && ntiles >= (i64)2 * waves * c->num_cu && 36 * std::max(ldx, ldo) * (i64)sizeof(T) < ((i64)1 << 31)) {
+                const void *fn = nullptr;
+#define XB4_CASE(G_) case G_: fn = (const void *)plsk::xb_mfma4_kernel<T, FV, G_>; break;
+                switch (ncg) {
+                    XB4_CASE(2) XB4_CASE(3) XB4_CASE(4) XB4_CASE(5) XB4_CASE(6)
+                    default:
+                        if constexpr (sizeof(T) == 8) {
+                            switch (ncg) { XB4_CASE(7) XB4_CASE(8) default: break; }
+                        }
+                        break;
+                }
+#undef XB4_CASE
+                if (fn && plsk::raise_dynamic_lds(fn, (int)lds)) {
+                    const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
+                    Scope s(c, PLS_HIP_FAM_XB, bytes);
+                    const unsigned grid = (unsigned)std::min<i64>(c->num_cu, (ntiles + waves - 1) / waves);
+                    int ncols = use;
+                    void *args[] = {(void *)&X, (void *)&ldx, (void *)&N, (void *)&K, (void *)&b, (void *)&ldb, (void *)&ncols, (void *)&o, (void *)&ldo};
+                    if (hipLaunchKernel(fn, dim3(grid), dim3(plsk::XB4_WG), args, lds, c->stream) != hipSuccess) {
+                        c->err = "kernel launch: xb_mfma4";
+                        (void)hipGetLastError();
+                        return PLS_HIP_ERR_DEVICE;
+                    }
+                    c0 += use;
+                    continue;
+                }
+            }
+        }
         if (sizeof(T) == 4 && rem > 8 && vec_ok<T>(X, ldx, FV)) {
             // fp32 storage, many columns: up to 32 per pass on the matrix cores (xb_mfma_kernel) -- the LDS-staged
             // VALU kernel below holds only 8 columns of fp64 accumulators per pass at 4 rows per lane.  (For fp64

@@ -26,6 +26,7 @@
 #include "tiny_kernels.hpp"
 #include "resident_kernels.hpp"
 #include "stream_kernels.hpp"
+#include "xb_mfma4.hpp"
 #include "syrk_kernels.hpp"
 #include "cv_kernels.hpp"
 #include "synth_kernels.hpp"
@@ -82,6 +83,7 @@ int pls_hip_create(pls_hip_handle *out, int device, void *stream) {
         }
         c->env.replica_guard = !off("PLS_HIP_REPLICA_GUARD");
         c->env.resident = !off("PLS_HIP_RESIDENT");
+        if (const char *e = getenv("PLS_HIP_XB4")) c->env.xb4 = atoi(e);
     }
     c->device = device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

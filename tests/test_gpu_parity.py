@@ -570,6 +570,29 @@ def test_xb_many_columns(handle, N, K, C, dt):
     assert err < (2e-7 if dt == "f32" else 1e-14), err
 
 
+@pytest.mark.parametrize("N,K,C,dt", [(262144 + 37, 70, 20, "f64"), (262144, 64, 5, "f64"), (300000, 33, 19, "f64"), (270001, 130, 32, "f64"),
+                                      (262144 + 31, 32, 8, "f64"), (524288 + 5, 33, 24, "f32"), (524288, 40, 5, "f32"), (600001, 18, 13, "f32")])
+def test_xb_tall_5_to_32_columns(handle, N, K, C, dt):
+    """X * B with 5..32 columns on a TALL matrix (scores T = X R with A columns, src/pls.cpp:439-442): the 4 x 4 x 4 MFMA kernel
+    (xb_mfma4.hpp) -- K not a multiple of the 4-column step or of the batch, column counts that are not multiples of 4, the
+    rows beyond the last full tile (one wave's guarded walk), odd N.  Against torch in fp64 on a sample of rows that includes
+    the last ones, and against the older kernels (PLS_HIP_XB4=0) on everything."""
+    torch = _torch()
+    dtype = torch.float32 if dt == "f32" else torch.float64
+    X = handle.synth_x(0, N, K, 23, dtype=dtype)
+    g = torch.Generator(device="cpu"); g.manual_seed(7)
+    Bm = torch.randn(K, C, generator=g, dtype=torch.float64).cuda()
+    got = handle.xb(X, Bm); handle.synchronize()
+    idx = torch.cat([torch.randint(0, N, (8192,), device="cuda"), torch.arange(N - 200, N, device="cuda"), torch.arange(0, 200, device="cuda")])
+    ref = X[idx].double() @ Bm
+    tol = 2e-7 if dt == "f32" else 1e-14
+    assert float((got[idx].double() - ref).norm() / ref.norm()) < tol
+    with handle_with_env(PLS_HIP_XB4=0) as h0:
+        old = h0.xb(X, Bm); h0.synchronize()
+        assert float((got.double() - old.double()).norm() / old.double().norm()) < tol
+        assert bool(torch.isfinite(got).all())
+
+
 @pytest.mark.parametrize("N,K,M,A", [(600, 1100, 2, 5), (257, 1500, 1, 4), (1030, 2048, 1, 6), (130, 2500, 2, 5),
                                      (96, 4096, 1, 4), (66, 4100, 2, 4), (130, 2500, 2, 1), (130, 2500, 2, 2),
                                      (130, 2500, 2, 3), (1030, 700, 1, 2), (1030, 700, 1, 3), (2050, 1024, 3, 4)])
