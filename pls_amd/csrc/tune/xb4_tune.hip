@@ -99,17 +99,21 @@ int main() {
     i64 LDX = N, NN = N;
 #define RUN4(NCG, MAP, WGT, UU, NP, STNT, DBG, BAR) run<NCG, 0, MAP, WGT, UU, NP, 2, STNT, DBG, BAR>("ncg=" #NCG " map=" #MAP " wg=" #WGT " U=" #UU " np=" #NP " staux=" #STNT " dbg=" #DBG " bar=" #BAR, X, LDX, NN, K, B, 4 * NCG, out, maxerr, cus, 1)
     // (MAP = 0: the waves of a workgroup a grid apart; BAR = 1: one barrier per round ahead of the stores; DBG = 1: no stores)
-    RUN4(5, 0, 1024, 0, 1, 2, 0, 1);   // the shipped configuration
-    RUN4(5, 0, 1024, 0, 1, 2, 1, 1);   // ... without its stores
-    RUN4(5, 0, 1024, 0, 1, 2, 0, 0);   // no barrier: the stores of the 16 waves trickle
-    RUN4(5, 16, 1024, 0, 1, 2, 0, 1);  // the workgroup's 16 tiles contiguous (4 KB per column)
-    RUN4(5, 0, 512, 0, 1, 2, 0, 1);
-    RUN4(5, 0, 1024, 0, 1, 0, 0, 1);   // plain stores
-    NN = N - 1;                          // 31 rows beyond the last full tile
-    RUN4(5, 0, 1024, 0, 1, 2, 0, 1);
-    NN = N;
-    RUN4(2, 0, 1024, 0, 1, 2, 0, 1);
-    RUN4(8, 0, 1024, 0, 1, 2, 0, 1);
+    RUN4(5, 0, 1024, 8, 1, 2, 0, 1);
+    RUN4(5, 0, 1024, 4, 1, 2, 0, 1);
+    RUN4(5, 0, 1024, 2, 1, 2, 0, 1);
+    RUN4(5, 0, 1024, 1, 1, 2, 0, 1);
+    RUN4(5, 0, 1024, 4, 1, 2, 1, 1);
+    RUN4(5, 0, 1024, 2, 1, 2, 1, 1);
+    RUN4(5, 0, 1024, 4, 1, 2, 0, 0);
+    RUN4(5, 0, 1024, 2, 1, 2, 0, 0);
+    RUN4(5, 0, 1024, 2, 1, 2, 4, 1);
+    RUN4(5, 0, 512, 4, 1, 2, 0, 1);
+    RUN4(5, 0, 1024, 4, 2, 2, 0, 1);
+    RUN4(2, 0, 1024, 4, 1, 2, 0, 1);
+    RUN4(2, 0, 1024, 2, 1, 2, 0, 1);
+    RUN4(8, 0, 1024, 2, 1, 2, 0, 1);
+    RUN4(5, 0, 1024, 4, 1, 2, 0, 1);
     calibrate(X, N, maxerr, cus);
     return 0;
 }

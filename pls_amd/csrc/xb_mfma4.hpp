@@ -22,15 +22,18 @@
 //   * MAP: the 16 tiles of a workgroup's round lie a whole grid apart (tile = workgroup + grid x wave), the walk of the
 //     fused pass -- workgroup b, on XCD b % 8, only ever touches the 256-byte pieces b mod 256 of every column.  Tiles 1,
 //     2 ... 128 apart (a workgroup's round contiguous in each column) are 4-15 % slower;
-//   * nt stores (STAUX 2) before plain, sc1 or sc0 sc1 ones by 0-1 %; 512-thread workgroups, deeper batches, two row packs
-//     per lane, barriers inside the round, pacing with s_sleep: nothing or worse.
+//   * nt stores (STAUX 2) before plain, sc1 or sc0 sc1 ones by 0-4 %; one burst per TWO rounds (timed with wrong values,
+//     DBG 4) another 1.5 %: not built; 512-thread workgroups, two row packs per lane, barriers inside the round, pacing
+//     with s_sleep: nothing or worse.
 #pragma once
 #include "fused_kernels.hpp"  // buf_ld_so, BUF_WORD3
 
 namespace plsk {
 
 constexpr int XB4_WG = 1024;
-__host__ __device__ constexpr int xb4_u(int v, int ncg) { return v * ncg > 20 ? 2 : v * ncg > 10 ? 4 : 8; }  // loads per batch: two batches + accumulators in 128 registers
+// column steps per batch: 4 (2 where the accumulators of fp32 storage's 4-row packs leave no room) -- 8 fit the registers up to
+// 20 fp64 columns and are 4 % slower with the barrier (0.757 against 0.730 ms; 2: 0.723, 1: 0.791)
+__host__ __device__ constexpr int xb4_u(int v, int ncg) { return v * ncg > 20 ? 2 : 4; }
 __host__ __device__ constexpr int xb4_kp(int K, int u) { return (K + (4 * u > 32 ? 4 * u : 32) - 1) / (4 * u > 32 ? 4 * u : 32) * (4 * u > 32 ? 4 * u : 32); }  // rows of Bm in LDS
 __host__ __device__ constexpr int xb4_stride(int ncg) { return (8 * ncg) % 64 == 0 ? 4 * ncg + 4 : 4 * ncg; }  // (k-rows on disjoint banks)
 
@@ -168,15 +171,28 @@ __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, 
         }
         if (kn == 0) {
             if constexpr (BAR) {
-                if (round < rfull) __syncthreads();
+                if (round < rfull && (!(DBG & 4) || (round & 1))) __syncthreads();
                 ++round;
             }
             // D: lane holds (row 4 b + i, column j) with i = lane / 16, b = (lane / 4) % 4: rows row0 + V (4 b + i) + e, e < V,
             // are contiguous -- one 16-byte store per lane, pack and column group
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + tile * RW, (short)0, 0x7fffffff, BUF_WORD3);
+            if constexpr ((DBG & 4) != 0) {  // (tuning: what one burst per TWO rounds would cost -- wrong values, the same traffic)
+                if (!(round & 1) && tile >= wstride) {
+                    const __amdgpu_buffer_rsrc_t rp =
+                        __builtin_amdgcn_make_buffer_rsrc(out + (tile - wstride) * RW, (short)0, 0x7fffffff, BUF_WORD3);
+#pragma unroll
+                    for (int c = 0; c < NCG; ++c) {
+                        Pack<T, V> o;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) o.v[e] = (T)acc[0][e][c];
+                        buf_st_so<T, V, STNT>(rp, (4 * c + lj < ncols) ? soff : OOR, c * ostep, o);
+                    }
+                }
+            }
 #pragma unroll
             for (int c = 0; c < NCG; ++c) {
-                const bool ok = 4 * c + lj < ncols && (!(DBG & 1) || acc[0][0][c] == 1.2345e300);
+                const bool ok = 4 * c + lj < ncols && (!(DBG & 1) || acc[0][0][c] == 1.2345e300) && (!(DBG & 4) || !(round & 1));
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     Pack<T, V> o;

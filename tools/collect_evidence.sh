@@ -33,7 +33,11 @@ gram)
   python3 tools/syrk_time.py 100 > $E/syrk_hip_events.txt 2> /dev/null
   stats c3_gram python3 tools/syrk_time.py 100
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $E/tmp_mfma -o p -- python3 tools/syrk_time.py 10 > /dev/null 2> $E/tmp_mfma.err
-  python3 tools/mfma_util.py $E/tmp_mfma/p_counter_collection.csv syrk > $E/syrk_mfma_pmc.txt 2>&1; rm -rf $E/tmp_mfma $E/tmp_mfma.err ;;
+  python3 tools/mfma_util.py $E/tmp_mfma/p_counter_collection.csv syrk > $E/syrk_mfma_pmc.txt 2>&1; rm -rf $E/tmp_mfma $E/tmp_mfma.err
+  # the plan's last sweep, T = X R with 20 columns (xb_mfma4_kernel): HIP events and the rocprofv3 average over 60 launches, HBM traffic
+  python3 tools/xb_time.py 60 > $E/xb_hip_events.txt 2> /dev/null
+  stats c3_xb python3 tools/xb_time.py 60
+  pmc C3_xb python3 tools/xb_time.py 3 ;;
 deflate)
   python3 tools/deflate_run.py > $E/deflate_piece_hip_events.txt 2> /dev/null
   stats deflate_piece python3 tools/deflate_run.py
