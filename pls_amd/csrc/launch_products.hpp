@@ -71,7 +71,28 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
     const i64 rows_per_wg_many = (i64)(plsk::WG / plsk::WAVE) * 16 * FV;
     const bool many = C > (sizeof(T) == 4 ? 8 : 32) && vec_ok<T>(X, ldx, FV) &&
                       (N + rows_per_wg_many - 1) / rows_per_wg_many >= c->num_cu / 2;
-    if (N > 0 && K >= 1024 && !many) {
+    // 5..32 columns of a large matrix on the 4 x 4 x 4 MFMA kernels (xb_mfma4.hpp, xb_mfma4w.hpp): one sweep of X where the column-split
+    // path below makes one per 4 columns (20,000 x 2,000, 20 columns: five sweeps, 0.13 of peak).  Not for a handful of columns
+    // of a matrix with fewer than 128: its output is a third of the traffic and the VALU kernels are as fast.
+    // Nor for a matrix with fewer 16 FV-row tiles than CUs (2,000 x 20,000: the column-split path below spreads it).
+    const i64 xb4_tiles = (N + 16 * FV - 1) / (16 * FV);
+    const bool xb4_ok = c->env.xb4 && C > 4 && vec_ok<T>(X, ldx, FV) && vec_ok<T>(out, ldo, FV) &&
+                        36 * std::max(ldx, ldo) * (i64)sizeof(T) < ((i64)1 << 31) && (i64)N * K * (i64)sizeof(T) >= ((i64)32 << 20) &&
+                        (K >= 128 || C > 8) && xb4_tiles >= (i64)c->num_cu;
+    // the resident form (all of Bm in LDS, a wave per tile): at least two rounds of 16 tiles per workgroup
+    auto xb4_resident = [&](int use) {
+        const int ncg = (use + 3) / 4;
+        return c->env.xb4 != 3 &&  // (PLS_HIP_XB4=3: the windowed form everywhere, for measurements)
+               (size_t)plsk::xb4_kp(K, plsk::xb4_u(FV, ncg)) * plsk::xb4_stride(ncg) * 8 <= 152 * 1024 &&
+               N / (16 * FV) >= (i64)2 * (plsk::XB4_WG / plsk::WAVE) * c->num_cu;
+    };
+    // the windowed form: not for fp64 storage with 8 columns or fewer (the VALU kernel holds them in one sweep at 0.72-0.74 of
+    // peak, this one 0.68), not for fp32 beyond 20 (its 24-column form spills)
+    // ... unless those 8 would go down the column-split path (two sweeps: 20,000 x 2,000, 8 columns 0.126 against 0.055 ms)
+    const bool split_shape = K >= 1024 && (N + plsk::WG - 1) / plsk::WG <= (i64)(sizeof(T) == 4 ? 2 : 1) * c->num_cu;
+    auto xb4_windowed = [&](int cols) { return sizeof(T) == 4 ? cols <= 20 : (cols > 8 || split_shape); };  // cols: ALL that remain
+    const bool xb4_first = xb4_ok && (xb4_resident(std::min(C, sizeof(T) == 8 ? 32 : 24)) || xb4_windowed(C));
+    if (N > 0 && K >= 1024 && !many && !xb4_first) {
         const bool v2 = vec_ok<T>(X, ldx, FV) && (N + (i64)FV * plsk::WG - 1) / ((i64)FV * plsk::WG) >= 8;
         const i64 per = (i64)plsk::WG * (v2 ? FV : 1);
         const i64 rg = (N + per - 1) / per;
@@ -131,14 +152,14 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
                 continue;
             }
         }
-        if (rem > 4 && c->env.xb4 && vec_ok<T>(X, ldx, FV) && vec_ok<T>(o, ldo, FV)) {
+        if (rem > 4 && xb4_ok) {
             // 5..32 columns (fp32 storage: ..24) with all of Bm in LDS: the 4 x 4 x 4 MFMA form, columns padded to 4 (xb_mfma4.hpp)
             const int use = std::min(rem, sizeof(T) == 8 ? 32 : 24);
             const int ncg = (use + 3) / 4;
             const i64 ntiles = N / (16 * FV);
             const size_t lds = (size_t)plsk::xb4_kp(K, plsk::xb4_u(FV, ncg)) * plsk::xb4_stride(ncg) * 8;
             const int waves = plsk::XB4_WG / plsk::WAVE;
-            if (lds <= 152 * 1024 && ntiles >= (i64)2 * waves * c->num_cu && 36 * std::max(ldx, ldo) * (i64)sizeof(T) < ((i64)1 << 31)) {
+            if (xb4_resident(use)) {
                 const void *fn = nullptr;
 #define XB4_CASE(G_) case G_: fn = (const void *)plsk::xb_mfma4_kernel<T, FV, G_>; break;
                 switch (ncg) {
@@ -164,6 +185,45 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
                     c0 += use;
                     continue;
                 }
+            }
+        }
+        if (rem > 4 && xb4_ok && xb4_windowed(rem)) {
+            // the same product where Bm does not fit in LDS or the matrix has too few row tiles for a wave each: Bm in windows,
+            // the waves of a workgroup = tile slots x sub-windows (xb_mfma4w.hpp)
+            const int use = std::min(rem, sizeof(T) == 8 ? 32 : 20);
+            const int ncg = (use + 3) / 4;
+            const i64 ntiles = (N + 16 * FV - 1) / (16 * FV);
+            const unsigned grid = (unsigned)std::min<i64>(c->num_cu, ntiles);
+            const i64 tpw = (ntiles + grid - 1) / grid;
+            int tw = 16;
+            for (int cand : {8, 4, 2})
+                if ((tpw + cand - 1) / cand * cand < (tpw + tw - 1) / tw * tw) tw = cand;
+            int sw = 16 / tw;
+            const int kc = 1 << plsk::xb4w_kcl2(FV, ncg);
+            const size_t lds = std::max((size_t)2 * kc * plsk::xb4_stride(ncg) * 8, (size_t)16 * FV * 64 * 8);
+            const void *fn = nullptr;
+#define XB4W_CASE(G_) case G_: fn = (const void *)plsk::xb_mfma4w_kernel<T, FV, G_>; break;
+            switch (ncg) {
+                XB4W_CASE(2) XB4W_CASE(3) XB4W_CASE(4) XB4W_CASE(5) XB4W_CASE(6)
+                default:
+                    if constexpr (sizeof(T) == 8) {
+                        switch (ncg) { XB4W_CASE(7) XB4W_CASE(8) default: break; }
+                    }
+                    break;
+            }
+#undef XB4W_CASE
+            if (fn && plsk::raise_dynamic_lds(fn, (int)lds)) {
+                const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
+                Scope s(c, PLS_HIP_FAM_XB, bytes);
+                int ncols = use;
+                void *args[] = {(void *)&X, (void *)&ldx, (void *)&N, (void *)&K, (void *)&b, (void *)&ldb, (void *)&ncols, (void *)&o, (void *)&ldo, (void *)&sw};
+                if (hipLaunchKernel(fn, dim3(grid), dim3(plsk::XB4_WG), args, lds, c->stream) != hipSuccess) {
+                    c->err = "kernel launch: xb_mfma4w";
+                    (void)hipGetLastError();
+                    return PLS_HIP_ERR_DEVICE;
+                }
+                c0 += use;
+                continue;
             }
         }
         if (sizeof(T) == 4 && rem > 8 && vec_ok<T>(X, ldx, FV)) {

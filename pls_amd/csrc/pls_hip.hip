@@ -27,6 +27,7 @@
 #include "resident_kernels.hpp"
 #include "stream_kernels.hpp"
 #include "xb_mfma4.hpp"
+#include "xb_mfma4w.hpp"
 #include "syrk_kernels.hpp"
 #include "cv_kernels.hpp"
 #include "synth_kernels.hpp"

@@ -571,7 +571,11 @@ def test_xb_many_columns(handle, N, K, C, dt):
 
 
 @pytest.mark.parametrize("N,K,C,dt", [(262144 + 37, 70, 20, "f64"), (262144, 64, 5, "f64"), (300000, 33, 19, "f64"), (270001, 130, 32, "f64"),
-                                      (262144 + 31, 32, 8, "f64"), (524288 + 5, 33, 24, "f32"), (524288, 40, 5, "f32"), (600001, 18, 13, "f32")])
+                                      (262144 + 31, 32, 8, "f64"), (524288 + 5, 33, 24, "f32"), (524288, 40, 5, "f32"), (600001, 18, 13, "f32"),
+                                      # the windowed form (xb_mfma4w.hpp): Bm beyond LDS, few row tiles (tile slots x sub-windows), partial last tile
+                                      (131072, 4096, 8, "f32"), (131072 + 3, 1030, 20, "f64"), (262144, 1024, 32, "f64"), (40001, 200, 19, "f64"),
+                                      (3001, 3000, 7, "f64"), (70000, 130, 24, "f32"), (16388, 2052, 12, "f32"), (65536 + 33, 640, 5, "f64"),
+                                      (20000, 2000, 20, "f32"), (8200, 1500, 9, "f64"), (16390, 700, 17, "f32")])
 def test_xb_tall_5_to_32_columns(handle, N, K, C, dt):
     """X * B with 5..32 columns on a TALL matrix (scores T = X R with A columns, src/pls.cpp:439-442): the 4 x 4 x 4 MFMA kernel
     (xb_mfma4.hpp) -- K not a multiple of the 4-column step or of the batch, column counts that are not multiples of 4, the
@@ -584,6 +588,7 @@ def test_xb_tall_5_to_32_columns(handle, N, K, C, dt):
     Bm = torch.randn(K, C, generator=g, dtype=torch.float64).cuda()
     got = handle.xb(X, Bm); handle.synchronize()
     idx = torch.cat([torch.randint(0, N, (8192,), device="cuda"), torch.arange(N - 200, N, device="cuda"), torch.arange(0, 200, device="cuda")])
+    if N * K > 1 << 27: idx = idx[::8]
     ref = X[idx].double() @ Bm
     tol = 2e-7 if dt == "f32" else 1e-14
     assert float((got[idx].double() - ref).norm() / ref.norm()) < tol

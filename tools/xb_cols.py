@@ -11,7 +11,8 @@ def handle(mode):
     return h
 hs = {m: handle(m) for m in (0, 1)}
 shapes = [(torch.float64, 1 << 20, 512), (torch.float64, 1048575, 512), (torch.float64, 1 << 20, 500), (torch.float64, 4194304, 64),
-          (torch.float64, 262144, 1024), (torch.float32, 1 << 20, 512), (torch.float32, 131072, 4096)]
+          (torch.float64, 262144, 1024), (torch.float32, 1 << 20, 512), (torch.float32, 131072, 4096), (torch.float64, 131072, 4096),
+          (torch.float64, 20000, 2000), (torch.float32, 4194304, 64), (torch.float64, 2000, 20000)]
 if len(sys.argv) > 2: shapes = shapes[:int(sys.argv[2])]
 for dt, N, K in shapes:
     es = 8 if dt == torch.float64 else 4
