@@ -92,6 +92,62 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
     const bool split_shape = K >= 1024 && (N + plsk::WG - 1) / plsk::WG <= (i64)(sizeof(T) == 4 ? 2 : 1) * c->num_cu;
     auto xb4_windowed = [&](int cols) { return sizeof(T) == 4 ? cols <= 20 : (cols > 8 || split_shape); };  // cols: ALL that remain
     const bool xb4_first = xb4_ok && (xb4_resident(std::min(C, sizeof(T) == 8 ? 32 : 24)) || xb4_windowed(C));
+    // VERY short and wide (fewer 16 FV-row tiles than CUs: 2,000 x 20,000, a usual shape of the method), 5 columns or more: the
+    // windowed MFMA kernel with the columns split over blockIdx.y as well, fp64 partial sums, xb_split_finish_kernel behind it --
+    // one sweep of X for up to 32 columns where the split path below makes one per 4
+    if (c->env.xb4 && C > 4 && N > 0 && K >= 1024 && xb4_tiles < (i64)c->num_cu && vec_ok<T>(X, ldx, FV) &&
+        36 * ldx * (i64)sizeof(T) < ((i64)1 << 31) && (i64)N * K * (i64)sizeof(T) >= ((i64)32 << 20)) {
+        const i64 ldp = (N + 63) / 64 * 64;
+        const int fb = (int)((N + 63) / 64);
+        bool ok = true;
+        for (int c0 = 0; c0 < C && ok;) {
+            const int use = std::min(C - c0, sizeof(T) == 8 ? 32 : 20);
+            const int ncg = std::max(2, (use + 3) / 4), nc = 4 * ncg;
+            const int kc = 1 << plsk::xb4w_kcl2(FV, ncg);
+            int sw = 16;  // one tile per workgroup: its 16 waves share the columns of every window
+            int kspl = (int)std::min<i64>((2 * (i64)c->num_cu + xb4_tiles - 1) / xb4_tiles, std::max(1, K / (2 * kc)));
+            const int kper = ((K + kspl - 1) / kspl + kc - 1) / kc * kc;
+            kspl = (K + kper - 1) / kper;
+            const size_t lds = std::max((size_t)2 * kc * plsk::xb4_stride(ncg) * 8, (size_t)16 * FV * 64 * 8);
+            const void *fn = nullptr;
+#define XB4W_CASE(G_) case G_: fn = (const void *)plsk::xb_mfma4w_kernel<T, FV, G_>; break;
+            switch (ncg) {
+                XB4W_CASE(2) XB4W_CASE(3) XB4W_CASE(4) XB4W_CASE(5) XB4W_CASE(6)
+                default:
+                    if constexpr (sizeof(T) == 8) {
+                        switch (ncg) { XB4W_CASE(7) XB4W_CASE(8) default: break; }
+                    }
+                    break;
+            }
+#undef XB4W_CASE
+            if (!fn || kspl > 65535 || !plsk::raise_dynamic_lds(fn, (int)lds) ||
+                ensure(c, c->xbpart, (size_t)kspl * nc * ldp * 8) != PLS_HIP_OK) {
+                c->err.clear();
+                ok = false;
+                break;
+            }
+            double *xp = (double *)c->xbpart.p;
+            const double *b = Bm + (i64)c0 * ldb;
+            T *o = out + (i64)c0 * ldo;
+            {
+                Scope s(c, PLS_HIP_FAM_XB, (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8);
+                int ncols = use, kp = kper;
+                i64 lp = ldp;
+                void *args[] = {(void *)&X, (void *)&ldx, (void *)&N, (void *)&K, (void *)&b, (void *)&ldb, (void *)&ncols, (void *)&o, (void *)&ldo,
+                                (void *)&sw, (void *)&kp, (void *)&xp, (void *)&lp};
+                if (hipLaunchKernel(fn, dim3((unsigned)xb4_tiles, (unsigned)kspl), dim3(plsk::XB4_WG), args, lds, c->stream) != hipSuccess) {
+                    c->err = "kernel launch: xb_mfma4w (split)";
+                    (void)hipGetLastError();
+                    return PLS_HIP_ERR_DEVICE;
+                }
+                hipLaunchKernelGGL((plsk::xb_split_finish_kernel<T>), dim3(fb, use), dim3(plsk::WG), 0, c->stream, (const double *)xp, ldp, kspl, nc, N, o,
+                                   ldo, (double *)nullptr);
+                LAUNCH_CHECK(c);
+            }
+            c0 += use;
+        }
+        if (ok) return PLS_HIP_OK;
+    }
     if (N > 0 && K >= 1024 && !many && !xb4_first) {
         const bool v2 = vec_ok<T>(X, ldx, FV) && (N + (i64)FV * plsk::WG - 1) / ((i64)FV * plsk::WG) >= 8;
         const i64 per = (i64)plsk::WG * (v2 ? FV : 1);
@@ -216,7 +272,11 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
                 const i64 bytes = (i64)N * K * sizeof(T) + (i64)N * use * sizeof(T) + (i64)K * use * 8;
                 Scope s(c, PLS_HIP_FAM_XB, bytes);
                 int ncols = use;
-                void *args[] = {(void *)&X, (void *)&ldx, (void *)&N, (void *)&K, (void *)&b, (void *)&ldb, (void *)&ncols, (void *)&o, (void *)&ldo, (void *)&sw};
+                int kp0 = 0;
+                double *nopart = nullptr;
+                i64 lp0 = 0;
+                void *args[] = {(void *)&X, (void *)&ldx, (void *)&N, (void *)&K, (void *)&b, (void *)&ldb, (void *)&ncols, (void *)&o, (void *)&ldo, (void *)&sw,
+                                (void *)&kp0, (void *)&nopart, (void *)&lp0};
                 if (hipLaunchKernel(fn, dim3(grid), dim3(plsk::XB4_WG), args, lds, c->stream) != hipSuccess) {
                     c->err = "kernel launch: xb_mfma4w";
                     (void)hipGetLastError();

@@ -28,7 +28,7 @@ __host__ __device__ constexpr int xb4w_kcl2(int v, int ncg) { return ncg <= 2 ? 
 
 template <typename T, int V, int NCG>
 __global__ __launch_bounds__(XB4_WG) void xb_mfma4w_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, const double *__restrict__ Bm,
-                                                           i64 ldb, int ncols, T *__restrict__ out, i64 ldo, int SW) {
+                                                           i64 ldb, int ncols, T *__restrict__ out, i64 ldo, int SW, int kper, double *__restrict__ part, i64 ldp) {
     constexpr int NC = 4 * NCG, ST = xb4_stride(NCG), U = xb4w_u(V, NCG), RW = 16 * V, NWV = XB4_WG / WAVE;
     constexpr uint32_t OOR = 0xFFFFFFF0u;
     constexpr int KL = xb4w_kcl2(V, NCG), KC = 1 << KL;
@@ -42,7 +42,11 @@ __global__ __launch_bounds__(XB4_WG) void xb_mfma4w_kernel(const T *__restrict__
     const int G = gridDim.x;
     const i64 mytiles = (ntiles - blockIdx.x + G - 1) / G;       // tiles b, b + G, b + 2 G ... of this workgroup
     const int rounds = (int)((mytiles + TW - 1) / TW);
-    const int NQ = (K + KC - 1) / KC;                            // windows
+    // part != nullptr: the columns are split over blockIdx.y as well (VERY short matrices: fewer tiles than CUs) -- this
+    // workgroup walks [k_lo, k_hi) and leaves fp64 partial sums, part[(blockIdx.y * 4 NCG + column) * ldp + row], which
+    // xb_split_finish_kernel (stream_kernels.hpp) adds in range order
+    const int k_lo = part ? (int)blockIdx.y * kper : 0, k_hi = part ? min(K, k_lo + kper) : K;
+    const int NQ = (k_hi - k_lo + KC - 1) / KC;                  // windows
     const int KS = KC / SW, nbw = KS / (4 * U);                  // a wave's part of a window, in column steps and batches
     const uint32_t voff = (uint32_t)((V * li + (i64)lq * ldx) * (i64)sizeof(T));
     const int cstep = (int)(4 * ldx * (i64)sizeof(T));
@@ -54,8 +58,8 @@ __global__ __launch_bounds__(XB4_WG) void xb_mfma4w_kernel(const T *__restrict__
     auto fetch_b = [&](int q) {
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const int j = tid + i * XB4_WG, kk = j & (KC - 1), m = j >> KL, k = q * KC + kk;
-            breg[i] = (j < KC * NC && k < K && m < ncols) ? Bm[k + (i64)m * ldb] : 0.0;
+            const int j = tid + i * XB4_WG, kk = j & (KC - 1), m = j >> KL, k = k_lo + q * KC + kk;
+            breg[i] = (j < KC * NC && k < k_hi && m < ncols) ? Bm[k + (i64)m * ldb] : 0.0;
         }
     };
     auto put_b = [&](int buf) {
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(XB4_WG) void xb_mfma4w_kernel(const T *__restrict__
             __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X + tt * RW + (i64)k0 * ldx), (short)0, 0x7fffffff, BUF_WORD3);
         const bool rowok = t >= 0 && tt * RW + V * li < N;
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = buf_ld_so<T, V, 2>(rs, (rowok && k0 + 4 * u + lq < K) ? voff : OOR, u * cstep);
+        for (int u = 0; u < U; ++u) x[u] = buf_ld_so<T, V, 2>(rs, (rowok && k0 + 4 * u + lq < k_hi) ? voff : OOR, u * cstep);
     };
 
     double acc[V][NCG];
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(XB4_WG) void xb_mfma4w_kernel(const T *__restrict__
         }
         const bool more = rn < rounds;
         const i64 tn = rn == r ? tile : (more ? tile_of(rn) : -1);
-        if (more) load_x(xb, tn, qn * KC + sw * KS + jn * 4 * U);
+        if (more) load_x(xb, tn, k_lo + qn * KC + sw * KS + jn * 4 * U);
         const double *brow = xb4w_bs + (size_t)(wseq & 1) * KC * ST + (size_t)(sw * KS + j * 4 * U + lq) * ST + lj;
         double bc[NCG], bn[NCG];
 #pragma unroll
@@ -151,7 +155,13 @@ __global__ __launch_bounds__(XB4_WG) void xb_mfma4w_kernel(const T *__restrict__
                 }
                 if (sw == 0 && tile >= 0) {
                     const i64 r0 = tile * RW + V * (4 * ((lane >> 2) & 3) + lq);
-                    if ((tile + 1) * RW <= N) {
+                    if (part) {
+#pragma unroll
+                        for (int c = 0; c < NCG; ++c)
+#pragma unroll
+                            for (int e = 0; e < V; ++e)
+                                if (4 * c + lj < ncols && r0 + e < N) part[((i64)blockIdx.y * NC + 4 * c + lj) * ldp + r0 + e] = acc[e][c];
+                    } else if ((tile + 1) * RW <= N) {
                         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + tile * RW, (short)0, 0x7fffffff, BUF_WORD3);
 #pragma unroll
                         for (int c = 0; c < NCG; ++c) {
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(XB4_WG) void xb_mfma4w_kernel(const T *__restrict__
         return more;
     };
     Pack<T, V> x0[U], x1[U];
-    load_x(x0, tile, sw * KS);
+    load_x(x0, tile, k_lo + sw * KS);
     while (true) {
         if (!step(x0, x1)) break;
         if (!step(x1, x0)) break;

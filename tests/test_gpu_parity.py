@@ -575,7 +575,9 @@ def test_xb_many_columns(handle, N, K, C, dt):
                                       # the windowed form (xb_mfma4w.hpp): Bm beyond LDS, few row tiles (tile slots x sub-windows), partial last tile
                                       (131072, 4096, 8, "f32"), (131072 + 3, 1030, 20, "f64"), (262144, 1024, 32, "f64"), (40001, 200, 19, "f64"),
                                       (3001, 3000, 7, "f64"), (70000, 130, 24, "f32"), (16388, 2052, 12, "f32"), (65536 + 33, 640, 5, "f64"),
-                                      (20000, 2000, 20, "f32"), (8200, 1500, 9, "f64"), (16390, 700, 17, "f32")])
+                                      (20000, 2000, 20, "f32"), (8200, 1500, 9, "f64"), (16390, 700, 17, "f32"),
+                                      # very short: the columns split over workgroups as well, partial sums + finish kernel
+                                      (2000, 20000, 20, "f64"), (512, 50000, 8, "f32"), (1001, 9001, 5, "f64"), (130, 70000, 23, "f32"), (64, 140000, 32, "f64")])
 def test_xb_tall_5_to_32_columns(handle, N, K, C, dt):
     """X * B with 5..32 columns on a TALL matrix (scores T = X R with A columns, src/pls.cpp:439-442): the 4 x 4 x 4 MFMA kernel
     (xb_mfma4.hpp) -- K not a multiple of the 4-column step or of the batch, column counts that are not multiples of 4, the
@@ -587,10 +589,10 @@ def test_xb_tall_5_to_32_columns(handle, N, K, C, dt):
     g = torch.Generator(device="cpu"); g.manual_seed(7)
     Bm = torch.randn(K, C, generator=g, dtype=torch.float64).cuda()
     got = handle.xb(X, Bm); handle.synchronize()
-    idx = torch.cat([torch.randint(0, N, (8192,), device="cuda"), torch.arange(N - 200, N, device="cuda"), torch.arange(0, 200, device="cuda")])
+    idx = torch.cat([torch.randint(0, N, (8192,), device="cuda"), torch.arange(max(0, N - 200), N, device="cuda"), torch.arange(0, min(200, N), device="cuda")])
     if N * K > 1 << 27: idx = idx[::8]
     ref = X[idx].double() @ Bm
-    tol = 2e-7 if dt == "f32" else 1e-14
+    tol = 2e-7 if dt == "f32" else 1e-14 * max(1.0, (K / 2000.0) ** 0.5)  # (two summation orders over K terms)
     assert float((got[idx].double() - ref).norm() / ref.norm()) < tol
     with handle_with_env(PLS_HIP_XB4=0) as h0:
         old = h0.xb(X, Bm); h0.synchronize()
