@@ -212,7 +212,7 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
             // 5..32 columns (fp32 storage: ..24) with all of Bm in LDS: the 4 x 4 x 4 MFMA form, columns padded to 4 (xb_mfma4.hpp)
             const int use = std::min(rem, sizeof(T) == 8 ? 32 : 24);
             const int ncg = (use + 3) / 4;
-            const i64 ntiles = N / (16 * FV);
+            const i64 ntiles = (N + 16 * FV - 1) / (16 * FV);
             const size_t lds = (size_t)plsk::xb4_kp(K, plsk::xb4_u(FV, ncg)) * plsk::xb4_stride(ncg) * 8;
             const int waves = plsk::XB4_WG / plsk::WAVE;
             if (xb4_resident(use)) {

@@ -11,8 +11,8 @@
 // Persistent workgroups of 16 waves; a wave owns the 16 V rows of a tile and walks all K with the next batch of U loads in
 // flight behind the MFMAs of this one (two register sets that swap roles: no copy, also across the tile boundary).
 // Addressing: one buffer descriptor per (tile, batch) -- scalar -- plus ONE lane offset for the whole launch and the
-// instruction's scalar offset per column step; a column beyond K is an out-of-range offset (returns 0).  Every tile of the
-// loop is FULL: the last N % (16 V) rows are xb4_tail_rows'.
+// instruction's scalar offset per column step; a column beyond K -- and, in the partial last tile, a row beyond N -- is an
+// out-of-range offset (returns 0).
 // What the time is made of (tune/xb4_tune.hip, 1,048,576 x 512 fp64, 20 columns; profiles/r5/xb4_tune.txt):
 //   * without its stores the kernel streams X at 0.655 ms whatever the column count (the MFMAs are free: 0.27 ms of pipe);
 //   * the 168 MB of output -- 4 % of the bytes -- cost 0.06 ms in some processes and 0.19 ms in most (per process, not per
@@ -37,51 +37,6 @@ __host__ __device__ constexpr int xb4_u(int v, int ncg) { return v * ncg > 20 ? 
 __host__ __device__ constexpr int xb4_kp(int K, int u) { return (K + (4 * u > 32 ? 4 * u : 32) - 1) / (4 * u > 32 ? 4 * u : 32) * (4 * u > 32 ? 4 * u : 32); }  // rows of Bm in LDS
 __host__ __device__ constexpr int xb4_stride(int ncg) { return (8 * ncg) % 64 == 0 ? 4 * ncg + 4 : 4 * ncg; }  // (k-rows on disjoint banks)
 
-// the rows beyond the last full tile (fewer than 16 V NP): ONE wave, element loads with row and column guards, U column
-// steps in flight.  Out of line (its own register allocation); runs BEFORE that wave's share of the full tiles, beside
-// the other waves' streaming, so its latency-bound walk over K costs the launch nothing.
-template <typename T, int V, int NCG>
-__device__ __noinline__ void xb4_tail_rows(const T *__restrict__ X, i64 ldx, i64 N, int K, const double *bs, int ncols,
-                                           T *__restrict__ out, i64 ldo, i64 row0) {
-    constexpr int ST = xb4_stride(NCG), U = 8;
-    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4, lj = lane & 3;
-    for (i64 rb = row0; rb < N; rb += 16 * V) {
-        const i64 r = rb + (i64)V * li;
-        double acc[V][NCG];
-#pragma unroll
-        for (int e = 0; e < V; ++e)
-#pragma unroll
-            for (int c = 0; c < NCG; ++c) acc[e][c] = 0.0;
-        for (int k0 = 0; k0 < K; k0 += 4 * U) {
-            T x[U][V];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = k0 + 4 * u + lq;
-#pragma unroll
-                for (int e = 0; e < V; ++e) x[u][e] = (k < K && r + e < N) ? X[r + e + (i64)k * ldx] : (T)0;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const double *brow = bs + (k0 + 4 * u + lq) * ST + lj;  // (rows of Bm beyond K are zero in LDS: Kp >= k0 + 4 U)
-#pragma unroll
-                for (int c = 0; c < NCG; ++c) {
-                    const double bv = brow[4 * c];
-#pragma unroll
-                    for (int e = 0; e < V; ++e) acc[e][c] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)x[u][e], bv, acc[e][c], 0, 0, 0);
-                }
-            }
-        }
-        const i64 ro = rb + (i64)V * (4 * ((lane >> 2) & 3) + lq);
-#pragma unroll
-        for (int c = 0; c < NCG; ++c) {
-            const int col = 4 * c + lj;
-#pragma unroll
-            for (int e = 0; e < V; ++e)
-                if (col < ncols && ro + e < N) out[ro + e + (i64)col * ldo] = (T)acc[e][c];
-        }
-    }
-}
-
 template <typename T, int V, int NCG, int SLP = 0, int MAP = 0, int WGT = XB4_WG, int UU = 0, int NP = 1, int AUXL = 2, int STNT = 2, int DBG = 0, int BAR = 1>
 __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, const double *__restrict__ Bm,
                                                           i64 ldb, int ncols, T *__restrict__ out, i64 ldo) {
@@ -92,7 +47,7 @@ __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, 
     const int li = lane & 15, lq = lane >> 4, lj = lane & 3;
     constexpr int KR = 4 * U > 32 ? 4 * U : 32;
     const int Kp = (K + KR - 1) / KR * KR;  // (a multiple of the batch depth and of the tail's: xb4_kp)
-    const i64 ntiles = N / RW;
+    const i64 ntiles = (N + RW - 1) / RW;  // (the last one may be partial)
     for (int j = tid; j < Kp * NC; j += WGT) {  // consecutive threads: consecutive k of one column (coalesced)
         const int kk = j % Kp, m = j / Kp;
         xb4_bs[kk * ST + m] = (kk < K && m < ncols) ? Bm[kk + (i64)m * ldb] : 0.0;
@@ -100,8 +55,6 @@ __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, 
     __syncthreads();
     const i64 wstride = (i64)gridDim.x * (WGT / WAVE);
     const int wvu = __builtin_amdgcn_readfirstlane(wv);  // (wave-uniform: scalar descriptors)
-    if (ntiles * RW < N && blockIdx.x == gridDim.x - 1 && wvu == WGT / WAVE - 1)
-        xb4_tail_rows<T, V, NCG>(X, ldx, N, K, xb4_bs, ncols, out, ldo, ntiles * RW);
     // the tiles of a round (16 per workgroup): the waves of a workgroup take tiles MAP apart (MAP = 0: a whole grid apart)
     i64 tile = MAP == 0 ? (i64)wvu * gridDim.x + blockIdx.x
                         : (i64)(blockIdx.x / MAP) * ((WGT / WAVE) * MAP) + (i64)wvu * MAP + blockIdx.x % MAP;
@@ -114,11 +67,15 @@ __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, 
     auto load_x = [&](Pack<T, V> (&x)[U][NP], i64 t, int k0) {
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X + t * RW + (i64)k0 * ldx), (short)0, 0x7fffffff, BUF_WORD3);
+        // the partial last tile: lanes whose rows lie beyond N load out-of-range offsets; a pack that straddles N reads the
+        // padding of its column (ldx is a multiple of the pack: the launcher's vec_ok) and is stored element by element
+        const i64 rl = t * RW + V * li;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t vo = (k0 + 4 * u + lq < K) ? voff : OOR;
+            const bool kok = k0 + 4 * u + lq < K;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) x[u][p] = buf_ld_so<T, V, AUXL>(rs, vo + (uint32_t)(p * RS * sizeof(T)), u * cstep);
+            for (int p = 0; p < NP; ++p)
+                x[u][p] = buf_ld_so<T, V, AUXL>(rs, (kok && rl + p * RS < N) ? voff + (uint32_t)(p * RS * sizeof(T)) : OOR, u * cstep);
         }
     };
     const double *bl = xb4_bs + lq * ST + lj;
@@ -177,6 +134,7 @@ __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, 
             // D: lane holds (row 4 b + i, column j) with i = lane / 16, b = (lane / 4) % 4: rows row0 + V (4 b + i) + e, e < V,
             // are contiguous -- one 16-byte store per lane, pack and column group
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + tile * RW, (short)0, 0x7fffffff, BUF_WORD3);
+            const bool tfull = (tile + 1) * RW <= N;  // (wave-uniform)
             if constexpr ((DBG & 4) != 0) {  // (tuning: what one burst per TWO rounds would cost -- wrong values, the same traffic)
                 if (!(round & 1) && tile >= wstride) {
                     const __amdgpu_buffer_rsrc_t rp =
@@ -195,10 +153,17 @@ __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, 
                 const bool ok = 4 * c + lj < ncols && (!(DBG & 1) || acc[0][0][c] == 1.2345e300) && (!(DBG & 4) || !(round & 1));
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    Pack<T, V> o;
+                    if (tfull) {
+                        Pack<T, V> o;
 #pragma unroll
-                    for (int e = 0; e < V; ++e) o.v[e] = (T)acc[p][e][c];
-                    buf_st_so<T, V, STNT>(ro, ok ? soff + (uint32_t)(p * RS * sizeof(T)) : OOR, c * ostep, o);
+                        for (int e = 0; e < V; ++e) o.v[e] = (T)acc[p][e][c];
+                        buf_st_so<T, V, STNT>(ro, ok ? soff + (uint32_t)(p * RS * sizeof(T)) : OOR, c * ostep, o);
+                    } else {  // the partial last tile, element by element
+                        const i64 r0 = tile * RW + p * RS + V * (4 * ((lane >> 2) & 3) + lq);
+#pragma unroll
+                        for (int e = 0; e < V; ++e)
+                            if (ok && r0 + e < N) out[r0 + e + (i64)(4 * c + lj) * ldo] = (T)acc[p][e][c];
+                    }
                 }
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
