@@ -65,6 +65,51 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         LAUNCH_CHECK(c);
         return PLS_HIP_OK;
     }
+    // Mid-size single-response data with at most 128 columns under AUTO: ONE launch with three grid-wide hand-offs whatever A -- X^T X and X^T Y on
+    // the matrix cores, the component loop on XX in ONE workgroup's LDS, the scores at the end (resident_gram.hpp); the resident
+    // fits below exchange once per component.  An explicit KERNEL request keeps the reference's TYPE1 arithmetic (below).
+    if (method == PLS_HIP_KERNEL_TYPE1 && (c->opt_algo == PLS_HIP_ALGO_AUTO || c->env.resident_gram == 2) && c->opt_fuse && !c->reducer &&
+        c->env.tiny && c->env.resident && c->env.resident_gram && !c->opt_graph && plsk::elem_aligned<T>(X) && plsk::elem_aligned<T>(Y) && Tm &&
+        !plsk::tiny_fit_covers(N, K, M, A, ldx, sizeof(T)) && !plsk::tiny_fit_m_covers(N, K, M, A, ldx, sizeof(T)) &&
+        !plsk::micro_fit_covers(N, K, M, A, ldx, sizeof(T))) {
+        int G = plsk::resident_gram_grid(N, K, M, A, ldx, sizeof(T), c->num_cu);
+        if (G > 0 && host_flags(c)) {
+            plsk::ResidentGram rg;
+            rg.rows_per = (int)(((N + G - 1) / G + 3) & ~(i64)3);
+            G = (int)((N + rg.rows_per - 1) / rg.rows_per);
+            rg.LP = ((i64)K * K + (i64)K + 7) & ~(i64)7;
+            rg.big = plsk::resident_gram_big(K);
+            const size_t need = 256 + ((size_t)(G + 1) * rg.LP + (size_t)K * A) * 8;
+            if (c->resident.bytes < need) {
+                CHK(ensure(c, c->resident, need));
+                HIPCHK(c, hipMemsetAsync(c->resident.p, 0, 256, c->stream));  // both counters start from zero
+                c->resident_launches = 0;
+            }
+            const size_t lds = ((size_t)rg.big + plsk::RG_SMALL + (size_t)2 * K * A) * 8;
+            if (!plsk::raise_dynamic_lds((const void *)plsk::resident_gram_fit_kernel<T>, (int)lds))
+                return fail(c, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the resident fit could not be raised");
+            unsigned *ctr = (unsigned *)c->resident.p;
+            rg.sy.bar = ctr + 16 * (c->resident_launches & 1);
+            rg.sy.bar_next = ctr + 16 * ((c->resident_launches + 1) & 1);
+            ++c->resident_launches;
+            rg.part = (double *)((char *)c->resident.p + 256);
+            rg.gred = rg.part + (size_t)G * rg.LP;
+            rg.rshare = rg.gred + rg.LP;
+            rg.sy.status = c->diverged_dev + 1;
+            rg.sy.limit = (long long)(0.05 * 1e8);  // 50 ms of the 100 MHz wall clock
+#ifdef PLS_HIP_TESTING
+            if (const char *e = getenv("PLS_HIP_TEST_RESIDENT_LIMIT_TICKS")) rg.sy.limit = atoll(e);
+#endif
+            Range r_fit("pls_hip_fit (single launch, resident, X^T X)");
+            Scope s(c, PLS_HIP_FAM_SMALL, (2 * (i64)N * K + (i64)N * M + (i64)N * A) * (i64)sizeof(T) + (3 * (i64)K + M) * A * 8);
+            resident_turn(c);
+            hipLaunchKernelGGL((plsk::resident_gram_fit_kernel<T>), dim3(G), dim3(plsk::UPD_THREADS), lds, c->stream, X, ldx, Y, N, K, A, W, P, Q,
+                               R, Tm, ldt, B, rg);
+            LAUNCH_CHECK(c);
+            resident_done(c);
+            return PLS_HIP_OK;
+        }
+    }
     // Mid-size single-response data (beyond one workgroup's 1024 rows, up to ~50 MB): the same single launch on up to 256
     // workgroups with one grid-wide exchange per component (resident_kernels.hpp)
     if (method == PLS_HIP_KERNEL_TYPE1 && (c->opt_algo == PLS_HIP_ALGO_KERNEL || c->opt_algo == PLS_HIP_ALGO_AUTO) && c->opt_fuse &&

@@ -25,6 +25,7 @@
 #include "largem_kernels.hpp"
 #include "tiny_kernels.hpp"
 #include "resident_kernels.hpp"
+#include "resident_gram.hpp"
 #include "stream_kernels.hpp"
 #include "xb_mfma4.hpp"
 #include "xb_mfma4w.hpp"
@@ -85,6 +86,7 @@ int pls_hip_create(pls_hip_handle *out, int device, void *stream) {
         c->env.replica_guard = !off("PLS_HIP_REPLICA_GUARD");
         c->env.resident = !off("PLS_HIP_RESIDENT");
         if (const char *e = getenv("PLS_HIP_XB4")) c->env.xb4 = atoi(e);
+        if (const char *e = getenv("PLS_HIP_RESIDENT_GRAM")) c->env.resident_gram = atoi(e);
     }
     c->device = device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

@@ -1,0 +1,434 @@
+// resident_gram.hpp -- the whole fit of a mid-size problem with K <= 128 columns in ONE launch and THREE grid-wide hand-offs,
+// whatever the number of components (round 5).
+//
+// resident_fit_kernel (resident_kernels.hpp) keeps X in registers and exchanges [X^T t, t^T t] once per COMPONENT: 10-13 us
+// each, of which the exchange is 5-6 (a store, an arrival, a poll and a gather: four trips over the fabric on a chip that
+// idles at low clocks).  With few columns the component loop needs no pass over X at all (src/pls.cpp:398, :422-425:
+// t^T t = r^T XX r, X^T t = XX r) -- the GRAM plan's algebra -- and XX = X^T X of 128 columns is 128 KB: it fits in the LDS
+// of ONE workgroup.  So:
+//   1. every workgroup stages its rows of X (and Y) in LDS and forms its part of XX and XY on v_mfma_f64_16x16x4_f64
+//      (a wave per pair of 16-column blocks), stores it sc1;                                          -- hand-off 1 --
+//   2. every workgroup sums a SLICE of the K^2 + K values over the G parts, in workgroup order         -- hand-off 2 --
+//      (G (K^2 + K) <= 32,768: workgroup 0 sums them itself and the hand-off is saved);
+//   3. workgroup 0 alone, XX and every p_j, r_j in LDS: for every component XX r (a wave per output), r^T XX r, q, p, the
+//      XY deflation, w, the r recurrence (the single-launch kernels' update: thread k owns column k); B = R Q^T; R goes
+//      out sc1;                                                                                       -- hand-off 3 --
+//   4. every workgroup forms the scores of its rows, T = X R (src/pls.cpp:439-442).
+// The hand-offs are resident_kernels.hpp's (first row of MI355X_MICROARCH.md's "Valid forms": sc1 stores, vmcnt(0), barrier,
+// one lane's agent-scope arrival; sc1 loads behind the poll and a barrier; one workgroup per CU; bounded waits that end in a
+// status word, never a hang).  One response (2-8: resident_fit_m_kernel), fp64 or fp32 storage.
+#pragma once
+#include "resident_kernels.hpp"
+
+namespace plsk {
+
+#ifdef PLS_HIP_TESTING
+// testing/libpls_hip.so only: wall-clock stamps of the phases (tools/resident_gram_stamps.py)
+#define RG_STAMP(slot)                                                                                      \
+    do {                                                                                                    \
+        if (g_pass_stamps && threadIdx.x == 0) g_pass_stamps[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define RG_STAMP(slot) do { } while (0)
+#endif
+
+constexpr int RG_KMAX = 128;
+constexpr int RG_ACH = 8;        // score columns per pass of phase 4
+constexpr int RG_SMALL = 512 + 4 * RG_KMAX + 16;  // partial sums of XX r (or of a slice), r, the p_j^T w, w, q: doubles of dynamic LDS behind the big block
+constexpr int RG_LDS_DOUBLES = 20416;          // what one workgroup may ask for (160 KB less the static few)
+constexpr i64 RG_DIRECT = 32768;               // G (K^2 + K) at or below this: workgroup 0 sums the parts itself (no hand-off 2)
+
+struct ResidentGram {
+    ResidentSync sy;           // bar, bar_next, status, limit (part, LP unused)
+    double *part = nullptr;    // [G][LP]: XX (K x K, column-major) then XY (K) of every workgroup
+    double *gred = nullptr;    // [LP]: their sums
+    double *rshare = nullptr;  // [K A]: R for phase 4
+    i64 LP = 0;
+    int rows_per = 0;          // rows per workgroup (a multiple of 4)
+    int big = 0;               // doubles of the big LDS block: XX, or the staged rows, or the score partials
+};
+
+// doubles of the big LDS block: XX and XY (a workgroup's part on its way out); 16 x RG_ACH x 64 score partials; at least 32 staged rows
+inline int resident_gram_big(int K) {
+    const int kp = (K + 15) / 16 * 16 + 16;
+    return std::max(std::max(K * K + K, 16 * RG_ACH * 64), 32 * kp);
+}
+// 0: not covered; else the number of workgroups.  One response.
+inline int resident_gram_grid(i64 N, int K, int M, int A, i64 ldx, size_t es, int num_cu) {
+    if (M != 1 || K < 1 || K > RG_KMAX || A < 1 || 2 * A > K || N < 256) return 0;  // (A close to K: the last directions are noise, and XX squares
+                                                                                      // the condition number -- P^T R = I to 1e-8 only up to ~K/2; the TYPE1 kernels take those)
+    if (resident_gram_big(K) + RG_SMALL + 2 * K * A > RG_LDS_DOUBLES) return 0;   // XX + P and R of every component in LDS
+    if ((i64)N * K * (i64)es > ((i64)64 << 20) || (i64)K * ldx * (i64)es >= (1ll << 31)) return 0;
+    const i64 L = (i64)K * K + K;
+    // phase 1 is matrix-core work on G CUs at the clocks of a nearly idle chip (~1.1 GHz: 5,000 x 128 on 60 workgroups 19 us):
+    // as many workgroups as leave 32 rows each (64 below 64 columns), up to ~20 MB of parts
+    i64 G = std::min<i64>(std::min<i64>(num_cu, RESIDENT_MAX_WG), N / (K >= 64 ? 32 : 64));  // (few columns: the hand-offs cost more than the product)
+    G = std::min<i64>(G, std::max<i64>(8, (i64)2500000 / L));
+    return (int)std::max<i64>(G, 2);
+}
+
+// the arrival-and-wait of resident_grid_sum alone: every wave's sc1 stores are complete (vmcnt(0)) before the barrier behind
+// which one lane arrives; returns false when the wait ran out (status raised)
+__device__ __forceinline__ bool resident_grid_barrier(const ResidentSync &sy, unsigned phase, int *flag, bool wait) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(sy.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (phase + 1u) * gridDim.x;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(sy.bar, (short)0, 4, BUF_WORD3);
+        const long long t0 = wall_clock64();
+        int ok = wait ? 1 : 0;
+        while (wait && (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rb, 0, 0, AUX_SC1) < target) {
+            if (wall_clock64() - t0 > sy.limit) {
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0;
+    if (!ok && threadIdx.x == 0) __hip_atomic_store(sy.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return ok;
+}
+
+__device__ __forceinline__ double ld_sc1(const double *base, i64 idx) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), (short)0, 0x7fffffff, BUF_WORD3);
+    const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(r, (uint32_t)(idx * 8), 0, AUX_SC1);
+    double v;
+    __builtin_memcpy(&v, &raw, 8);
+    return v;
+}
+
+// X: N x K (ld ldx), Y: N x 1; W, P, R: K x A; Q: 1 x A; Tm: N x A (ld ldt); B: K x 1 or null.
+// grid = G workgroups of 1024 threads; dynamic LDS: rg.big + RG_SMALL + 2 K A doubles.
+template <typename T>
+__global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T *__restrict__ X, i64 ldx, const T *__restrict__ Y, i64 N, int K,
+                                                                        int A, double *__restrict__ W, double *__restrict__ P,
+                                                                        double *__restrict__ Q, double *__restrict__ R, T *__restrict__ Tm,
+                                                                        i64 ldt, double *__restrict__ B, const ResidentGram rg) {
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) double rgd[];
+    __shared__ double sred[2 * UPD_WAVES];
+    __shared__ int flag;
+    double *big = rgd;                          // [rg.big]
+    double *sp = rgd + rg.big;                  // [512]: partial sums (XX r by column group; a slice by workgroup subset)
+    double *rl = sp + 512;                      // [K]: r_a
+    double *cs = rl + RG_KMAX;                  // [A]: p_j^T w
+    double *wl = cs + RG_KMAX;                  // [K]: w
+    double *ql = wl + RG_KMAX;                  // [A]: q
+    double *Pl = ql + RG_KMAX + 8;              // [K A]
+    double *Rq = Pl + (i64)K * A;               // [K A]
+    constexpr int M = 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int G = gridDim.x, g = blockIdx.x;
+    const i64 L = (i64)K * K + (i64)K * M;
+    const bool direct = (i64)G * L <= RG_DIRECT;  // (the same in every workgroup)
+    const ResidentSync &sy = rg.sy;
+    bool ok = true;
+    unsigned phase = 0;
+    if (g == 0 && tid == 0) __hip_atomic_store(sy.bar_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    RG_STAMP(0);
+    // ---- 1. this workgroup's rows: XX and XY parts on the matrix cores, operands from LDS ----
+    const i64 r0 = (i64)g * rg.rows_per, r1 = min(N, r0 + (i64)rg.rows_per);
+    const int nb = (K + 15) / 16;                 // 16-column blocks of X; block index nb: the responses
+    const int KP = nb * 16 + 16;                  // row stride of the staged rows: X blocks, then 16 response slots
+    const int chunk = (rg.big / KP) & ~3;  // rows staged at a time (>= 32)
+    const int npairs = nb * (nb + 1) / 2 + nb;    // (bi <= bj) and (bi, Y)
+    const int li = lane & 15, lk = lane >> 4;
+    double *mine = rg.part + (i64)g * rg.LP;
+    // a wave owns the pairs wv, wv + 16, ...: at most 3 for K = 128 (44 pairs)
+    constexpr int MAXP = 3;
+    f64x4 acc[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) acc[p] = f64x4{0.0, 0.0, 0.0, 0.0};
+    auto pair_of = [&](int idx, int &bi, int &bj) {  // row-major over bj >= bi, then the (bi, Y) pairs
+        int rest = idx;
+        for (bi = 0; bi < nb; ++bi) {
+            const int len = nb - bi;
+            if (rest < len) {
+                bj = bi + rest;
+                return;
+            }
+            rest -= len;
+        }
+        bi = rest;
+        bj = nb;
+    };
+    for (i64 c0 = r0; c0 < r1; c0 += chunk) {
+        const int rc = (int)min((i64)chunk, r1 - c0), rc4 = (rc + 3) & ~3;
+        __syncthreads();  // the previous chunk has been read
+        for (int base = 0; base < rc4 * KP; base += 8 * UPD_THREADS) {  // consecutive threads: consecutive rows of one column; eight loads in flight
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * UPD_THREADS + tid, row = idx % rc4, col = idx / rc4;
+                v[u] = 0.0;
+                if (idx < rc4 * KP && row < rc) {
+                    if (col < K) v[u] = (double)X[c0 + row + (i64)col * ldx];
+                    else if (col == nb * 16) v[u] = (double)Y[c0 + row];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * UPD_THREADS + tid, row = idx % rc4, col = idx / rc4;
+                if (idx < rc4 * KP) big[row * KP + col] = v[u];
+            }
+        }
+        __syncthreads();
+        const double *ap[MAXP], *bp[MAXP];
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            int bi = 0, bj = 0;
+            if (wv + p * UPD_WAVES < npairs) pair_of(wv + p * UPD_WAVES, bi, bj);
+            ap[p] = big + lk * KP + bi * 16 + li;
+            bp[p] = big + lk * KP + bj * 16 + li;
+        }
+        for (int r = 0; r < rc4; r += 4) {  // the wave's (up to) three accumulation chains side by side
+#pragma unroll
+            for (int p = 0; p < MAXP; ++p)
+                if (wv + p * UPD_WAVES < npairs) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[p][r * KP], bp[p][r * KP], acc[p], 0, 0, 0);
+        }
+    }
+    // D: lane holds rows (lane >> 4) + 4 q, column lane & 15 of the 16 x 16 block (assembling the part in LDS for consecutive stores
+    // was tried: two barriers and a store loop cost more than the scattered stores, 19 -> 25 us at K = 128)
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int idx = wv + p * UPD_WAVES;
+        if (idx < npairs) {
+            int bi, bj;
+            pair_of(idx, bi, bj);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = bi * 16 + lk + 4 * q, j = (bj < nb ? bj * 16 : 0) + li;
+                const double v = acc[p][q];
+                if (bj < nb) {
+                    if (i < K && j < K) {
+                        st_agent(mine + i + (i64)j * K, v);
+                        if (bi != bj) st_agent(mine + j + (i64)i * K, v);
+                    }
+                } else if (i < K && li == 0) {
+                    st_agent(mine + (i64)K * K + i, v);
+                }
+            }
+        }
+    }
+    RG_STAMP(1);
+    ok = resident_grid_barrier(sy, phase++, &flag, ok);
+    RG_STAMP(2);
+
+    // ---- 2. a slice of the L values summed over the G parts, in workgroup order (few values: workgroup 0 does it itself) ----
+    auto sum_parts = [&](i64 j) -> double {  // sixteen loads in flight, added in workgroup order
+        double s = 0.0;
+        int h = 0;
+        for (; h + 16 <= G; h += 16) {
+            double x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = ld_sc1(rg.part + (i64)(h + u) * rg.LP, j);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += x[u];
+        }
+        for (; h < G; ++h) s += ld_sc1(rg.part + (i64)h * rg.LP, j);
+        return s;
+    };
+    if (!direct) {
+        // the slice's S values: NS = 512 / LW workgroup subsets per value (LW = S rounded up to whole waves, at most 512 at a time):
+        // thread (e, hs) adds the parts hs, hs + NS, ... in that order, then the NS sums meet in order -- fixed, whatever the run
+        const i64 S = (L + G - 1) / G, j0 = (i64)g * S, j1 = min(L, j0 + S);
+        for (i64 jb = j0; jb < j1; jb += 512) {
+            const int cnt = (int)min((i64)512, j1 - jb), LW = (cnt + WAVE - 1) / WAVE * WAVE, NS = 512 / LW;
+            const int e = tid % LW, hs = tid / LW;
+            double s = 0.0;
+            if (hs < NS && e < cnt) {
+                int h = hs;
+                for (; h + 7 * NS < G; h += 8 * NS) {  // eight loads in flight, added in order
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = ld_sc1(rg.part + (i64)(h + u * NS) * rg.LP, jb + e);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += x[u];
+                }
+                for (; h < G; h += NS) s += ld_sc1(rg.part + (i64)h * rg.LP, jb + e);
+            }
+            __syncthreads();  // (the previous chunk's sums have been read)
+            if (hs < NS) sp[hs * LW + e] = s;
+            __syncthreads();
+            if (tid < cnt) {
+                double t = 0.0;
+                for (int q = 0; q < NS; ++q) t += sp[q * LW + tid];
+                st_agent(rg.gred + jb + tid, ok ? t : __builtin_nan(""));
+            }
+        }
+        ok = resident_grid_barrier(sy, phase++, &flag, ok);
+    }
+    RG_STAMP(3);
+
+    // ---- 3. workgroup 0: the components, everything K-sized in LDS (thread k owns column k) ----
+    if (g == 0) {
+        const int k = tid;
+        const bool kok = k < K;
+        const int KW = K <= WAVE ? WAVE : 2 * WAVE, NJG = 512 / KW, JL = (K + NJG - 1) / NJG, kq = tid % KW, jg = tid / KW;
+        if (direct) {
+            for (i64 j = tid; j < (i64)K * K; j += UPD_THREADS) big[j] = ok ? sum_parts(j) : __builtin_nan("");
+        } else {
+            for (int j0 = 0; j0 < K * K; j0 += 16 * UPD_THREADS) {  // sixteen loads in flight per lane
+                double x[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int j = j0 + u * UPD_THREADS + tid;
+                    x[u] = j < K * K ? ld_sc1(rg.gred, j) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int j = j0 + u * UPD_THREADS + tid;
+                    if (j < K * K) big[j] = ok ? x[u] : __builtin_nan("");
+                }
+            }
+        }
+        double xyk = kok ? (direct ? sum_parts((i64)K * K + k) : ld_sc1(rg.gred, (i64)K * K + k)) : 0.0;  // XY = X^T Y (:396)
+        auto bsum = [&](double v) -> double {  // block sum on lds_barrier (every thread calls it)
+            v = wave_sum(v);
+            lds_barrier();
+            if (lane == 0) sred[wv] = v;
+            lds_barrier();
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < UPD_WAVES; ++w) t += sred[w];
+            return t;
+        };
+        RG_STAMP(4);
+        {  // w_0 = XY / |XY| (:404, :411), r_0 = w_0
+            const double w = xyk / sqrt(bsum(xyk * xyk));
+            if (kok) {
+                W[k] = w;
+                R[k] = w;
+                Rq[k] = w;
+                rl[k] = w;
+            }
+        }
+        for (int a = 0; a < A; ++a) {
+            lds_barrier();  // r_a (rl) complete; XX in LDS
+            // XX r (:424): thread (kq, jg) adds XX[kq][j] r[j] over the jg-th group of the columns j (row kq of column j: consecutive
+            // lanes, consecutive addresses; r[j] a broadcast), then the NJG partial sums of an output meet in order
+            if (jg < NJG && kq < K) {
+                double s0 = 0.0, s1 = 0.0;
+                const int ja = jg * JL, jb2 = min(K, ja + JL);
+                int j = ja;
+                for (; j + 1 < jb2; j += 2) {
+                    s0 = fma(big[(i64)j * K + kq], rl[j], s0);
+                    s1 = fma(big[(i64)(j + 1) * K + kq], rl[j + 1], s1);
+                }
+                if (j < jb2) s0 = fma(big[(i64)j * K + kq], rl[j], s0);
+                sp[jg * KW + kq] = s0 + s1;
+            }
+            lds_barrier();
+            double pr = 0.0;
+            if (kok)
+                for (int q = 0; q < NJG; ++q) pr += sp[q * KW + k];
+            const double rk = kok ? rl[k] : 0.0;
+            // tt = r^T XX r (:425) and r^T XY in one reduction
+            double v0 = wave_sum(rk * pr), v1 = wave_sum(rk * xyk);
+            lds_barrier();
+            if (lane == 0) {
+                sred[wv] = v0;
+                sred[UPD_WAVES + wv] = v1;
+            }
+            lds_barrier();
+            double tt = 0.0, rxy = 0.0;
+#pragma unroll
+            for (int w = 0; w < UPD_WAVES; ++w) {
+                tt += sred[w];
+                rxy += sred[UPD_WAVES + w];
+            }
+            const double p = pr / tt, q = rxy / tt;  // (:427, :428)
+            if (kok) {
+                P[k + (i64)a * K] = p;
+                Pl[k + (i64)a * K] = p;
+            }
+            if (tid == 0) {
+                Q[a] = q;
+                ql[a] = q;
+            }
+            xyk -= (p * q) * tt;  // XY -= (p q^T) tt (:429)
+            const int n = a + 1;
+            if (n >= A) break;
+            const double w = xyk / sqrt(bsum(xyk * xyk));  // (:404, :411)
+            if (kok) {
+                W[k + (i64)n * K] = w;
+                wl[k] = w;
+            }
+            lds_barrier();
+            for (int j = wv; j < n; j += UPD_WAVES) {  // c_j = p_j^T w, against the ORIGINAL w (:415)
+                double c = 0.0;
+                for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
+                c = wave_sum(c);
+                if (lane == 0) cs[j] = c;
+            }
+            lds_barrier();
+            double r = w;
+            for (int j = 0; j < n; ++j) r -= cs[j] * Rq[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
+            if (kok) {
+                R[k + (i64)n * K] = r;
+                Rq[k + (i64)n * K] = r;
+                rl[k] = r;
+            }
+        }
+        lds_barrier();
+        if (B && kok) {  // B = R Q^T (:444-451)
+            double b = 0.0;
+            for (int a = 0; a < A; ++a) b = fma(Rq[k + (i64)a * K], ql[a], b);
+            B[k] = b;
+        }
+        for (int j = tid; j < K * A; j += UPD_THREADS) st_agent(rg.rshare + j, Rq[j]);
+    }
+    RG_STAMP(5);
+    ok = resident_grid_barrier(sy, phase++, &flag, ok);
+    RG_STAMP(6);
+
+    // ---- 4. the scores of this workgroup's rows: T = X R.  A wave per slice of the columns, a lane per row of a 64-row block,
+    //         RG_ACH score columns at a time; the 16 partial sums of a score meet in LDS in wave order ----
+    double *Rl = Rq, *tp = big;  // tp: [16 waves][RG_ACH][64]
+    if (g != 0 || !ok)
+        for (int j = tid; j < K * A; j += UPD_THREADS) Rl[j] = ok ? ld_sc1(rg.rshare, j) : __builtin_nan("");
+    const int ksl = (K + UPD_WAVES - 1) / UPD_WAVES, k_lo = wv * ksl, k_hi = min(K, k_lo + ksl);  // (ksl <= 8)
+    double xn[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xn[u] = (r0 + lane < r1 && k_lo + u < k_hi) ? (double)X[r0 + lane + (i64)(k_lo + u) * ldx] : 0.0;
+    for (i64 b0 = r0; b0 < r1; b0 += WAVE) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = xn[u];
+        {  // the next block's values are asked for ahead of this block's arithmetic
+            const i64 row = b0 + WAVE + lane;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xn[u] = (row < r1 && k_lo + u < k_hi) ? (double)X[row + (i64)(k_lo + u) * ldx] : 0.0;
+        }
+        for (int a0 = 0; a0 < A; a0 += RG_ACH) {
+            __syncthreads();  // Rl complete / the previous tp has been read
+            double ac[RG_ACH];
+#pragma unroll
+            for (int c = 0; c < RG_ACH; ++c) {
+                ac[c] = 0.0;
+                if (a0 + c < A) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (k_lo + u < k_hi) ac[c] = fma(x[u], Rl[k_lo + u + (i64)(a0 + c) * K], ac[c]);
+                }
+                tp[(wv * RG_ACH + c) * WAVE + lane] = ac[c];
+            }
+            __syncthreads();
+            if (tid < RG_ACH * WAVE) {
+                const int c = tid / WAVE, l = tid % WAVE;
+                double s = 0.0;
+                for (int w = 0; w < UPD_WAVES; ++w) s += tp[(w * RG_ACH + c) * WAVE + l];
+                if (a0 + c < A && b0 + l < r1) Tm[b0 + l + (i64)(a0 + c) * ldt] = (T)s;
+            }
+        }
+    }
+    RG_STAMP(7);
+}
+
+}  // namespace plsk

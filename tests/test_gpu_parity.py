@@ -1049,6 +1049,75 @@ def test_resident_single_launch_fit(handle, oracle, po, N, K, A, dt, pad, M):
     assert po.rel_fro(first["B"].cpu().numpy(), plain["B"].cpu().numpy()) < (1e-10 if dt == "f64" else 2e-5)
 
 
+@pytest.mark.parametrize("N,K,A,dt,pad", [(1025, 26, 5, "f64", 0), (5000, 128, 10, "f64", 0), (5003, 128, 11, "f64", 3), (20000, 16, 5, "f64", 1), (100000, 40, 12, "f64", 0),
+                                          (262144, 26, 4, "f64", 0), (3001, 77, 7, "f32", 5), (70000, 50, 9, "f32", 0), (2050, 64, 32, "f64", 0), (1500, 100, 20, "f64", 0),
+                                          (8000, 100, 5, "f64", 0), (300, 90, 6, "f64", 0)])
+def test_resident_gram_single_launch_fit(handle, oracle, po, N, K, A, dt, pad):
+    """AUTO on mid-size single-response data with at most 128 columns: ONE launch with three grid-wide hand-offs whatever A
+    (resident_gram.hpp: X^T X and X^T Y on the matrix cores, the component loop on XX in one workgroup's LDS, the scores at the
+    end).  Row counts that leave ragged last workgroups, a padded leading dimension, fp32 storage, the direct and the sliced
+    sum of the parts, as many components as the LDS holds: against the oracle and the general plan, one launch in all, repeated
+    fits equal bit for bit; PLS_HIP_RESIDENT_GRAM=0 gives the per-component resident kernel."""
+    import pls_amd
+    torch = _torch()
+    tdt = torch.float64 if dt == "f64" else torch.float32
+    Xbig = torch.zeros((K, N + pad), dtype=tdt, device="cuda")
+    Xbig[:, :N] = handle.synth_x(5, N, K, 31, dtype=tdt).T
+    Xd = Xbig.T[:N]                                   # column-major view, ld = N + pad
+    Yd = handle.synth_y(5, N, 1, 31, dtype=tdt)
+    Xh = np.asfortranarray(Xd.cpu().numpy().astype(np.float64)); Yh = np.asfortranarray(Yd.cpu().numpy().astype(np.float64))
+    ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
+    handle.set_option(pls_amd.OPT_PROFILE, 2)
+    handle.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_AUTO)
+    try:
+        handle.timing()
+        out = handle.fit_device(Xd, Yd, A)
+        handle.synchronize()
+        t = handle.timing()
+        assert sum(t["launches"].values()) == 1, t["launches"]
+        first = {k: v.clone() for k, v in out.items()}
+        for _ in range(5):
+            again = handle.fit_device(Xd, Yd, A); handle.synchronize()
+            for k in "WPQRTB":
+                assert torch.equal(again[k], first[k]), k
+        with handle_with_env(PLS_HIP_RESIDENT=0) as general:
+            plain = general.fit_device(Xd, Yd, A)
+            general.synchronize()
+            plain = {k: v.clone() for k, v in plain.items()}
+    finally:
+        handle.set_option(pls_amd.OPT_PROFILE, 0)
+        handle.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_KERNEL)
+    tol = dict(tol_b=1e-10, tol_col=1e-9) if dt == "f64" else dict(tol_b=2e-5, tol_col=2e-4, tol_inv=1e-3)
+    if A >= 20: tol = dict(tol_b=1e-8, tol_col=1e-7)  # (the later directions of a long fit: XX squares the condition number)
+    check_against(po, first, ref, Bref, Tref=ref["T"], col_err=cerr, **tol)
+    assert po.rel_fro(first["B"].cpu().numpy(), plain["B"].cpu().numpy()) < (1e-8 if A >= 20 else 1e-10 if dt == "f64" else 2e-5)
+
+
+def test_resident_gram_fit_wait_that_runs_out_is_reported():
+    """The same bounded waits in the X^T X form (AUTO): a limit of one tick ends the launch with the device error of
+    pls_hip_synchronize, and the next fit works."""
+    code = '''
+import os, sys
+sys.path.insert(0, %r)
+import torch, pls_amd
+h = pls_amd.Handle(); h.set_option(pls_amd.OPT_ALGO, pls_amd.ALGO_AUTO)
+X = h.synth_x(0, 60000, 40, 3); Y = h.synth_y(0, 60000, 1, 3)
+os.environ["PLS_HIP_TEST_RESIDENT_LIMIT_TICKS"] = "1"
+out = h.fit_device(X, Y, 6)
+try:
+    h.synchronize(); print("no error")
+except pls_amd.PlsHipError as e:
+    print("error", e.code)
+del os.environ["PLS_HIP_TEST_RESIDENT_LIMIT_TICKS"]
+out = h.fit_device(X, Y, 6); h.synchronize()
+print("refit finite", bool(torch.isfinite(out["B"]).all()))
+''' % ROOT
+    env = dict(os.environ, PLS_AMD_LIBRARY=os.path.join(ROOT, "pls_amd", "csrc", "testing", "libpls_hip.so"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "error 2" in r.stdout and "refit finite True" in r.stdout, r.stdout[-1500:]
+
+
 def test_resident_fit_wait_that_runs_out_is_reported():
     """The resident fit's workgroups wait for each other inside the launch; a wait beyond its time limit (another process holding
     the GPU's CUs) must end, poison the results and be reported by pls_hip_synchronize -- and the next fit must work.  The limit is
