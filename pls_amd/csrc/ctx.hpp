@@ -68,6 +68,8 @@ struct pls_hip_context {
     } xep;
     DevBuf tailcnt;  // arrival counters of slice_tail (fused_kernels.hpp)
     DevBuf resident;  // resident_fit_kernel: two arrival counters (256 bytes) + [2][G][LP] partial vectors
+    DevBuf rgflags;   // resident_gram_fit_kernel: one arrival word per workgroup (1 KB), values grow from launch to launch
+    unsigned rg_epoch = 0;
     unsigned long long resident_launches = 0;
     // The environment switches of the library, read ONCE when the handle is created (INTEGRATION.md lists them):
     //   PLS_HIP_TINY=0           small fits on the general plan instead of the single-launch kernels (tests compare the two)

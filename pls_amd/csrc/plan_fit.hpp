@@ -88,10 +88,14 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             const size_t lds = ((size_t)rg.big + plsk::RG_SMALL + (size_t)2 * K * A) * 8;
             if (!plsk::raise_dynamic_lds((const void *)plsk::resident_gram_fit_kernel<T>, (int)lds))
                 return fail(c, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the resident fit could not be raised");
-            unsigned *ctr = (unsigned *)c->resident.p;
-            rg.sy.bar = ctr + 16 * (c->resident_launches & 1);
-            rg.sy.bar_next = ctr + 16 * ((c->resident_launches + 1) & 1);
-            ++c->resident_launches;
+            if (!c->rgflags.p) {
+                CHK(ensure(c, c->rgflags, (size_t)plsk::RESIDENT_MAX_WG * 4));
+                HIPCHK(c, hipMemsetAsync(c->rgflags.p, 0, (size_t)plsk::RESIDENT_MAX_WG * 4, c->stream));
+                c->rg_epoch = 0;
+            }
+            rg.flags = (unsigned *)c->rgflags.p;
+            rg.epoch = c->rg_epoch;
+            c->rg_epoch += 4;  // (three hand-offs at most; the words wrap with it: the kernel compares signed distances)
             rg.part = (double *)((char *)c->resident.p + 256);
             rg.gred = rg.part + (size_t)G * rg.LP;
             rg.rshare = rg.gred + rg.LP;

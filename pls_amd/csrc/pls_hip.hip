@@ -100,7 +100,7 @@ int pls_hip_destroy(pls_hip_handle h) {
     if (!h) return PLS_HIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->tailcnt, &h->resident, &h->zeros, &h->part, &h->sspart, &h->xbpart, &h->wide1, &h->red, &h->red2, &h->xx, &h->xyp, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
+    DevBuf *bufs[] = {&h->tailcnt, &h->resident, &h->rgflags, &h->zeros, &h->part, &h->sspart, &h->xbpart, &h->wide1, &h->red, &h->red2, &h->xx, &h->xyp, &h->praw, &h->xy, &h->v, &h->cs, &h->coop, &h->lm, &h->gxx, &h->gxy, &h->tab,
                       &h->cvidx, &h->cvx, &h->cvy, &h->cvws, &h->cve, &h->cvtx, &h->cvty, &h->cvtt, &h->cvm, &h->cvkeep, &h->work, &h->hX, &h->hY,
                       &h->hT, &h->hW, &h->hP, &h->hQ, &h->hR, &h->hB, &h->hIn, &h->hOut};
     for (DevBuf *b : bufs)

@@ -39,7 +39,9 @@ constexpr int RG_LDS_DOUBLES = 20416;          // what one workgroup may ask for
 constexpr i64 RG_DIRECT = 32768;               // G (K^2 + K) at or below this: workgroup 0 sums the parts itself (no hand-off 2)
 
 struct ResidentGram {
-    ResidentSync sy;           // bar, bar_next, status, limit (part, LP unused)
+    ResidentSync sy;           // status, limit (the counters, part and LP are the per-component kernels')
+    unsigned *flags = nullptr; // [256]: workgroup g's arrival word -- epoch + (hand-offs passed): grows from launch to launch, never reset
+    unsigned epoch = 0;        // the value before this launch's first hand-off
     double *part = nullptr;    // [G][LP]: XX (K x K, column-major) then XY (K) of every workgroup
     double *gred = nullptr;    // [LP]: their sums
     double *rshare = nullptr;  // [K A]: R for phase 4
@@ -67,32 +69,12 @@ inline int resident_gram_grid(i64 N, int K, int M, int A, i64 ldx, size_t es, in
     return (int)std::max<i64>(G, 2);
 }
 
-// the arrival-and-wait of resident_grid_sum alone: every wave's sc1 stores are complete (vmcnt(0)) before the barrier behind
-// which one lane arrives; returns false when the wait ran out (status raised)
-__device__ __forceinline__ bool resident_grid_barrier(const ResidentSync &sy, unsigned phase, int *flag, bool wait) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(sy.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = (phase + 1u) * gridDim.x;
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(sy.bar, (short)0, 4, BUF_WORD3);
-        const long long t0 = wall_clock64();
-        int ok = wait ? 1 : 0;
-        while (wait && (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rb, 0, 0, AUX_SC1) < target) {
-            if (wall_clock64() - t0 > sy.limit) {
-                ok = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        *flag = ok;
-    }
-    __syncthreads();
-    const bool ok = *flag != 0;
-    if (!ok && threadIdx.x == 0) __hip_atomic_store(sy.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return ok;
-}
-
+// A grid-wide hand-off without a shared counter: every wave's sc1 stores are complete (vmcnt(0)) before the barrier behind which
+// one lane publishes the workgroup's OWN arrival word (an agent-scope store); wave 0 polls all G words in one 16-byte load per
+// lane until none is behind.  (One counter for all: 139 agent-scope additions to one address took 10 us -- profiles/r5/
+// resident_gram_stamps.txt.)  The words only ever grow, from launch to launch (rg.epoch): a launch that ended in a time-out
+// leaves nothing to clean up.  Returns false when the wait ran out (status raised).
+__device__ __forceinline__ bool resident_gram_barrier(const ResidentGram &rg, unsigned phase, int *flag, bool wait);
 __device__ __forceinline__ double ld_sc1(const double *base, i64 idx) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), (short)0, 0x7fffffff, BUF_WORD3);
@@ -100,6 +82,37 @@ __device__ __forceinline__ double ld_sc1(const double *base, i64 idx) {
     double v;
     __builtin_memcpy(&v, &raw, 8);
     return v;
+}
+
+__device__ __forceinline__ bool resident_gram_barrier(const ResidentGram &rg, unsigned phase, int *flag, bool wait) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned target = rg.epoch + phase + 1u;
+    if (threadIdx.x == 0) __hip_atomic_store(rg.flags + blockIdx.x, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < WAVE) {
+        const int G = gridDim.x, lane = threadIdx.x;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(rg.flags, (short)0, RESIDENT_MAX_WG * 4, BUF_WORD3);
+        const long long t0 = wall_clock64();
+        int ok = wait ? 1 : 0;
+        while (wait) {
+            const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(rb, (uint32_t)lane * 16u, 0, AUX_SC1);
+            bool mine = true;  // (signed distance: the words wrap with the epoch)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mine = mine && (4 * lane + q >= G || (int)(f[q] - target) >= 0);
+            if (__all(mine)) break;
+            if (wall_clock64() - t0 > rg.sy.limit) {
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) *flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0;
+    if (!ok && threadIdx.x == 0) __hip_atomic_store(rg.sy.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return ok;
 }
 
 // X: N x K (ld ldx), Y: N x 1; W, P, R: K x A; Q: 1 x A; Tm: N x A (ld ldt); B: K x 1 or null.
@@ -126,10 +139,8 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
     const int G = gridDim.x, g = blockIdx.x;
     const i64 L = (i64)K * K + (i64)K * M;
     const bool direct = (i64)G * L <= RG_DIRECT;  // (the same in every workgroup)
-    const ResidentSync &sy = rg.sy;
     bool ok = true;
     unsigned phase = 0;
-    if (g == 0 && tid == 0) __hip_atomic_store(sy.bar_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     RG_STAMP(0);
     // ---- 1. this workgroup's rows: XX and XY parts on the matrix cores, operands from LDS ----
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
         }
     }
     RG_STAMP(1);
-    ok = resident_grid_barrier(sy, phase++, &flag, ok);
+    ok = resident_gram_barrier(rg, phase++, &flag, ok);
     RG_STAMP(2);
 
     // ---- 2. a slice of the L values summed over the G parts, in workgroup order (few values: workgroup 0 does it itself) ----
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
                 st_agent(rg.gred + jb + tid, ok ? t : __builtin_nan(""));
             }
         }
-        ok = resident_grid_barrier(sy, phase++, &flag, ok);
+        ok = resident_gram_barrier(rg, phase++, &flag, ok);
     }
     RG_STAMP(3);
 
@@ -385,7 +396,7 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
         for (int j = tid; j < K * A; j += UPD_THREADS) st_agent(rg.rshare + j, Rq[j]);
     }
     RG_STAMP(5);
-    ok = resident_grid_barrier(sy, phase++, &flag, ok);
+    ok = resident_gram_barrier(rg, phase++, &flag, ok);
     RG_STAMP(6);
 
     // ---- 4. the scores of this workgroup's rows: T = X R.  A wave per slice of the columns, a lane per row of a 64-row block,
