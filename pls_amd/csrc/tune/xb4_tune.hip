@@ -63,10 +63,10 @@ void calibrate(const double *X, i64 N, double *sink, int cus) {
     fflush(stdout);
 }
 
-template <int NCG, int SLP, int MAP, int WGT, int UU, int NP = 1, int AUXL = 2, int STNT = 0, int DBG = 0, int BAR = 0>
+template <int NCG, int MAP, int WGT, int UU, int AUXL = 2, int STAUX = 2, int BAR = 1>
 void run(const char *name, const double *X, i64 ldx, i64 N, int K, const double *B, int C, double *out, double *maxerr, int cus, int per_cu) {
-    auto fn = plsk::xb_mfma4_kernel<double, 2, NCG, SLP, MAP, WGT, UU, NP, AUXL, STNT, DBG, BAR>;
-    const int U = UU ? UU : plsk::xb4_u(2 * NP, NCG);
+    auto fn = plsk::xb_mfma4_kernel<double, 2, NCG, MAP, WGT, UU, AUXL, STAUX, BAR>;
+    const int U = UU ? UU : plsk::xb4_u(2, NCG);
     const size_t lds = (size_t)plsk::xb4_kp(K, U) * plsk::xb4_stride(NCG) * 8;
     CK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -83,7 +83,7 @@ void run(const char *name, const double *X, i64 ldx, i64 N, int K, const double 
     hipLaunchKernelGGL(check_kernel, dim3(256), dim3(32), 0, 0, X, ldx, K, B, C, out, ldx, N, maxerr);
     double err; CK(hipMemcpy(&err, maxerr, 8, hipMemcpyDeviceToHost));
     const double by = (double)N * K * 8 + (double)N * C * 8;
-    printf("%-44s C=%2d  avg %.4f ms (best %.4f)  %.3f of peak  max err %.1e\n", name, C, sum / reps, best, by / (sum / reps * 1e-3) / 8e12, err);
+    printf("%-60s C=%2d  avg %.4f ms (best %.4f)  %.3f of peak  max err %.1e\n", name, C, sum / reps, best, by / (sum / reps * 1e-3) / 8e12, err);
     fflush(stdout);
 }
 
@@ -97,23 +97,21 @@ int main() {
     CK(hipDeviceSynchronize());
     calibrate(X, N, maxerr, cus);
     i64 LDX = N, NN = N;
-#define RUN4(NCG, MAP, WGT, UU, NP, STNT, DBG, BAR) run<NCG, 0, MAP, WGT, UU, NP, 2, STNT, DBG, BAR>("ncg=" #NCG " map=" #MAP " wg=" #WGT " U=" #UU " np=" #NP " staux=" #STNT " dbg=" #DBG " bar=" #BAR, X, LDX, NN, K, B, 4 * NCG, out, maxerr, cus, 1)
-    // (MAP = 0: the waves of a workgroup a grid apart; BAR = 1: one barrier per round ahead of the stores; DBG = 1: no stores)
-    RUN4(5, 0, 1024, 8, 1, 2, 0, 1);
-    RUN4(5, 0, 1024, 4, 1, 2, 0, 1);
-    RUN4(5, 0, 1024, 2, 1, 2, 0, 1);
-    RUN4(5, 0, 1024, 1, 1, 2, 0, 1);
-    RUN4(5, 0, 1024, 4, 1, 2, 1, 1);
-    RUN4(5, 0, 1024, 2, 1, 2, 1, 1);
-    RUN4(5, 0, 1024, 4, 1, 2, 0, 0);
-    RUN4(5, 0, 1024, 2, 1, 2, 0, 0);
-    RUN4(5, 0, 1024, 2, 1, 2, 4, 1);
-    RUN4(5, 0, 512, 4, 1, 2, 0, 1);
-    RUN4(5, 0, 1024, 4, 2, 2, 0, 1);
-    RUN4(2, 0, 1024, 4, 1, 2, 0, 1);
-    RUN4(2, 0, 1024, 2, 1, 2, 0, 1);
-    RUN4(8, 0, 1024, 2, 1, 2, 0, 1);
-    RUN4(5, 0, 1024, 4, 1, 2, 0, 1);
+#define RUN(NCG, MAP, WGT, UU, STAUX, BAR) run<NCG, MAP, WGT, UU, 2, STAUX, BAR>("ncg=" #NCG " map=" #MAP " wg=" #WGT " U=" #UU " staux=" #STAUX " bar=" #BAR, X, LDX, NN, K, B, 4 * NCG, out, maxerr, cus, 1)
+    // (MAP = 0: the waves of a workgroup a grid apart; BAR = 1: one barrier per round ahead of the stores; earlier states of this
+    // file also timed the kernel without its stores, pacing, two row packs per lane: profiles/r5/xb4_tune.txt)
+    RUN(5, 0, 1024, 0, 2, 1);   // the shipped configuration
+    RUN(5, 0, 1024, 0, 2, 0);   // no barrier: the stores of the 16 waves trickle
+    RUN(5, 16, 1024, 0, 2, 1);  // the workgroup's 16 tiles contiguous (4 KB per column)
+    RUN(5, 0, 512, 0, 2, 1);
+    RUN(5, 0, 1024, 8, 2, 1);   // eight column steps per batch
+    RUN(5, 0, 1024, 2, 2, 1);
+    RUN(5, 0, 1024, 0, 0, 1);   // plain stores
+    NN = N - 1;                   // 31 rows in the partial last tile
+    RUN(5, 0, 1024, 0, 2, 1);
+    NN = N;
+    RUN(2, 0, 1024, 0, 2, 1);
+    RUN(8, 0, 1024, 0, 2, 1);
     calibrate(X, N, maxerr, cus);
     return 0;
 }

@@ -22,8 +22,8 @@
 //   * MAP: the 16 tiles of a workgroup's round lie a whole grid apart (tile = workgroup + grid x wave), the walk of the
 //     fused pass -- workgroup b, on XCD b % 8, only ever touches the 256-byte pieces b mod 256 of every column.  Tiles 1,
 //     2 ... 128 apart (a workgroup's round contiguous in each column) are 4-15 % slower;
-//   * nt stores (STAUX 2) before plain, sc1 or sc0 sc1 ones by 0-4 %; one burst per TWO rounds (timed with wrong values,
-//     DBG 4) another 1.5 %: not built; 512-thread workgroups, two row packs per lane, barriers inside the round, pacing
+//   * nt stores (STAUX 2) before plain, sc1 or sc0 sc1 ones by 0-4 %; one burst per TWO rounds (timed with wrong values)
+//     another 1.5 %: not built; 512-thread workgroups, two row packs per lane, barriers inside the round, pacing
 //     with s_sleep: nothing or worse.
 #pragma once
 #include "fused_kernels.hpp"  // buf_ld_so, BUF_WORD3
@@ -37,16 +37,17 @@ __host__ __device__ constexpr int xb4_u(int v, int ncg) { return v * ncg > 20 ? 
 __host__ __device__ constexpr int xb4_kp(int K, int u) { return (K + (4 * u > 32 ? 4 * u : 32) - 1) / (4 * u > 32 ? 4 * u : 32) * (4 * u > 32 ? 4 * u : 32); }  // rows of Bm in LDS
 __host__ __device__ constexpr int xb4_stride(int ncg) { return (8 * ncg) % 64 == 0 ? 4 * ncg + 4 : 4 * ncg; }  // (k-rows on disjoint banks)
 
-template <typename T, int V, int NCG, int SLP = 0, int MAP = 0, int WGT = XB4_WG, int UU = 0, int NP = 1, int AUXL = 2, int STNT = 2, int DBG = 0, int BAR = 1>
+// MAP, WGT, UU, AUXL, STAUX, BAR: the choices the header's measurements settled (tune/xb4_tune.hip instantiates the others)
+template <typename T, int V, int NCG, int MAP = 0, int WGT = XB4_WG, int UU = 0, int AUXL = 2, int STAUX = 2, int BAR = 1>
 __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, i64 ldx, i64 N, int K, const double *__restrict__ Bm,
                                                           i64 ldb, int ncols, T *__restrict__ out, i64 ldo) {
-    constexpr int NC = 4 * NCG, ST = xb4_stride(NCG), U = UU ? UU : xb4_u(V * NP, NCG), RS = 16 * V, RW = RS * NP;
+    constexpr int NC = 4 * NCG, ST = xb4_stride(NCG), U = UU ? UU : xb4_u(V, NCG), RW = 16 * V;
     constexpr uint32_t OOR = 0xFFFFFFF0u;
     extern __shared__ __attribute__((aligned(16))) double xb4_bs[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lq = lane >> 4, lj = lane & 3;
     constexpr int KR = 4 * U > 32 ? 4 * U : 32;
-    const int Kp = (K + KR - 1) / KR * KR;  // (a multiple of the batch depth and of the tail's: xb4_kp)
+    const int Kp = (K + KR - 1) / KR * KR;  // (xb4_kp)
     const i64 ntiles = (N + RW - 1) / RW;  // (the last one may be partial)
     for (int j = tid; j < Kp * NC; j += WGT) {  // consecutive threads: consecutive k of one column (coalesced)
         const int kk = j % Kp, m = j / Kp;
@@ -64,45 +65,34 @@ __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, 
     // the stores: D lane = 16 i + 4 b + j holds rows V (4 b + i) + e, e < V, of column 4 c + j -- 16 contiguous bytes per lane
     const uint32_t soff = (uint32_t)((V * (4 * ((lane >> 2) & 3) + lq) + (i64)lj * ldo) * (i64)sizeof(T));
     const int ostep = (int)(4 * ldo * (i64)sizeof(T));  // bytes between the column groups
-    auto load_x = [&](Pack<T, V> (&x)[U][NP], i64 t, int k0) {
+    auto load_x = [&](Pack<T, V> (&x)[U], i64 t, int k0) {
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X + t * RW + (i64)k0 * ldx), (short)0, 0x7fffffff, BUF_WORD3);
         // the partial last tile: lanes whose rows lie beyond N load out-of-range offsets; a pack that straddles N reads the
         // padding of its column (ldx is a multiple of the pack: the launcher's vec_ok) and is stored element by element
-        const i64 rl = t * RW + V * li;
+        const bool rowok = t * RW + V * li < N;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool kok = k0 + 4 * u + lq < K;
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
-                x[u][p] = buf_ld_so<T, V, AUXL>(rs, (kok && rl + p * RS < N) ? voff + (uint32_t)(p * RS * sizeof(T)) : OOR, u * cstep);
-        }
+        for (int u = 0; u < U; ++u) x[u] = buf_ld_so<T, V, AUXL>(rs, (rowok && k0 + 4 * u + lq < K) ? voff : OOR, u * cstep);
     };
     const double *bl = xb4_bs + lq * ST + lj;
-    double acc[NP][V][NCG];
+    double acc[V][NCG];
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
+    for (int e = 0; e < V; ++e)
 #pragma unroll
-        for (int e = 0; e < V; ++e)
-#pragma unroll
-            for (int c = 0; c < NCG; ++c) acc[p][e][c] = 0.0;
+        for (int c = 0; c < NCG; ++c) acc[e][c] = 0.0;
     int k0 = 0;
-    [[maybe_unused]] i64 round = 0;
-    [[maybe_unused]] const i64 rfull = ntiles / wstride;  // rounds in which every wave of the workgroup has a tile
+    i64 round = 0;
+    const i64 rfull = ntiles / wstride;  // rounds in which every wave of the workgroup has a tile
     // one batch: the loads of the NEXT batch (of this tile, or the first of the wave's next tile) go out into xb, then the
     // MFMAs of this one out of xa; the two register sets swap roles from step to step (no copy, no wait for the loads in flight)
-    auto step = [&](Pack<T, V> (&xa)[U][NP], Pack<T, V> (&xb)[U][NP]) -> bool {
+    auto step = [&](Pack<T, V> (&xa)[U], Pack<T, V> (&xb)[U]) -> bool {
         int kn = k0 + 4 * U;
         i64 tn = tile;
         if (kn >= K) {
             kn = 0;
             tn = tile + wstride;
         }
-        if constexpr (BAR >= 2) {  // (tuning: the waves of the workgroup in step inside the round as well)
-            if (round < rfull && ((k0 / (4 * U)) % (BAR == 2 ? 1 : BAR == 3 ? 4 : 8)) == 0) __syncthreads();
-        }
         if (tn < ntiles) load_x(xb, tn, kn);
-        if constexpr (SLP > 0) __builtin_amdgcn_s_sleep(SLP);
         const double *brow = bl + k0 * ST;
         double bc[NCG], bn[NCG];
 #pragma unroll
@@ -116,66 +106,43 @@ __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, 
 #pragma unroll
             for (int c = 0; c < NCG; ++c)
 #pragma unroll
-                for (int p = 0; p < NP; ++p)
-#pragma unroll
-                    for (int e = 0; e < V; ++e) {
-                        if constexpr (DBG & 2) { if (c == 0) acc[p][e][0] += (double)xa[u][p].v[e] * bc[0]; }
-                        else acc[p][e][c] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)xa[u][p].v[e], bc[c], acc[p][e][c], 0, 0, 0);
-                    }
+                for (int e = 0; e < V; ++e) acc[e][c] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)xa[u].v[e], bc[c], acc[e][c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < NCG; ++c) bc[c] = bn[c];
         }
         if (kn == 0) {
-            if constexpr (BAR) {
-                if (round < rfull && (!(DBG & 4) || (round & 1))) __syncthreads();
+            if constexpr (BAR != 0) {  // the 16 waves store their tiles together: a burst of 80 KB, not a trickle into the read stream
+                if (round < rfull) __syncthreads();
                 ++round;
             }
             // D: lane holds (row 4 b + i, column j) with i = lane / 16, b = (lane / 4) % 4: rows row0 + V (4 b + i) + e, e < V,
-            // are contiguous -- one 16-byte store per lane, pack and column group
+            // are contiguous -- one 16-byte store per lane and column group
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + tile * RW, (short)0, 0x7fffffff, BUF_WORD3);
             const bool tfull = (tile + 1) * RW <= N;  // (wave-uniform)
-            if constexpr ((DBG & 4) != 0) {  // (tuning: what one burst per TWO rounds would cost -- wrong values, the same traffic)
-                if (!(round & 1) && tile >= wstride) {
-                    const __amdgpu_buffer_rsrc_t rp =
-                        __builtin_amdgcn_make_buffer_rsrc(out + (tile - wstride) * RW, (short)0, 0x7fffffff, BUF_WORD3);
-#pragma unroll
-                    for (int c = 0; c < NCG; ++c) {
-                        Pack<T, V> o;
-#pragma unroll
-                        for (int e = 0; e < V; ++e) o.v[e] = (T)acc[0][e][c];
-                        buf_st_so<T, V, STNT>(rp, (4 * c + lj < ncols) ? soff : OOR, c * ostep, o);
-                    }
-                }
-            }
 #pragma unroll
             for (int c = 0; c < NCG; ++c) {
-                const bool ok = 4 * c + lj < ncols && (!(DBG & 1) || acc[0][0][c] == 1.2345e300) && (!(DBG & 4) || !(round & 1));
+                const bool ok = 4 * c + lj < ncols;
+                if (tfull) {
+                    Pack<T, V> o;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    if (tfull) {
-                        Pack<T, V> o;
+                    for (int e = 0; e < V; ++e) o.v[e] = (T)acc[e][c];
+                    buf_st_so<T, V, STAUX>(ro, ok ? soff : OOR, c * ostep, o);
+                } else {  // the partial last tile, element by element
+                    const i64 r0 = tile * RW + V * (4 * ((lane >> 2) & 3) + lq);
 #pragma unroll
-                        for (int e = 0; e < V; ++e) o.v[e] = (T)acc[p][e][c];
-                        buf_st_so<T, V, STNT>(ro, ok ? soff + (uint32_t)(p * RS * sizeof(T)) : OOR, c * ostep, o);
-                    } else {  // the partial last tile, element by element
-                        const i64 r0 = tile * RW + p * RS + V * (4 * ((lane >> 2) & 3) + lq);
-#pragma unroll
-                        for (int e = 0; e < V; ++e)
-                            if (ok && r0 + e < N) out[r0 + e + (i64)(4 * c + lj) * ldo] = (T)acc[p][e][c];
-                    }
+                    for (int e = 0; e < V; ++e)
+                        if (ok && r0 + e < N) out[r0 + e + (i64)(4 * c + lj) * ldo] = (T)acc[e][c];
                 }
 #pragma unroll
-                for (int p = 0; p < NP; ++p)
-#pragma unroll
-                    for (int e = 0; e < V; ++e) acc[p][e][c] = 0.0;
+                for (int e = 0; e < V; ++e) acc[e][c] = 0.0;
             }
         }
         k0 = kn;
         tile = tn;
         return tn < ntiles;
     };
-    Pack<T, V> x0[U][NP], x1[U][NP];
+    Pack<T, V> x0[U], x1[U];
     load_x(x0, tile, 0);
     while (true) {
         if (!step(x0, x1)) break;
