@@ -124,7 +124,7 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
                                                                         i64 ldt, double *__restrict__ B, const ResidentGram rg) {
     typedef double f64x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) double rgd[];
-    __shared__ double sred[2 * UPD_WAVES];
+    __shared__ double sred[2 * UPD_WAVES + 8];
     __shared__ int flag;
     double *big = rgd;                          // [rg.big]
     double *sp = rgd + rg.big;                  // [512]: partial sums (XX r by column group; a slice by workgroup subset)
@@ -320,10 +320,14 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
                 rl[k] = w;
             }
         }
+        // Four barriers per component: what would be a reduction of its own rides on a barrier that is there anyway --
+        // r^T XX r and r^T XY are summed by waves next to the partial sums of XX r; |XY| next to the p_j^T XY (the norm then
+        // divides both w and the p_j^T w).
         for (int a = 0; a < A; ++a) {
             lds_barrier();  // r_a (rl) complete; XX in LDS
             // XX r (:424): thread (kq, jg) adds XX[kq][j] r[j] over the jg-th group of the columns j (row kq of column j: consecutive
-            // lanes, consecutive addresses; r[j] a broadcast), then the NJG partial sums of an output meet in order
+            // lanes, consecutive addresses; r[j] a broadcast); the NJG partial sums of an output meet in order behind the barrier
+            double s = 0.0;
             if (jg < NJG && kq < K) {
                 double s0 = 0.0, s1 = 0.0;
                 const int ja = jg * JL, jb2 = min(K, ja + JL);
@@ -333,21 +337,20 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
                     s1 = fma(big[(i64)(j + 1) * K + kq], rl[j + 1], s1);
                 }
                 if (j < jb2) s0 = fma(big[(i64)j * K + kq], rl[j], s0);
-                sp[jg * KW + kq] = s0 + s1;
+                s = s0 + s1;
+                sp[jg * KW + kq] = s;
+            }
+            {  // tt = r^T XX r (:425) = the sum of r[kq] * (partial sum) over every (kq, jg); r^T XY from the threads that own a column
+                const double v0 = wave_sum((jg < NJG && kq < K) ? rl[kq] * s : 0.0), v1 = wave_sum(kok ? rl[k] * xyk : 0.0);
+                if (lane == 0) {
+                    sred[wv] = v0;
+                    sred[UPD_WAVES + wv] = v1;
+                }
             }
             lds_barrier();
             double pr = 0.0;
             if (kok)
                 for (int q = 0; q < NJG; ++q) pr += sp[q * KW + k];
-            const double rk = kok ? rl[k] : 0.0;
-            // tt = r^T XX r (:425) and r^T XY in one reduction
-            double v0 = wave_sum(rk * pr), v1 = wave_sum(rk * xyk);
-            lds_barrier();
-            if (lane == 0) {
-                sred[wv] = v0;
-                sred[UPD_WAVES + wv] = v1;
-            }
-            lds_barrier();
             double tt = 0.0, rxy = 0.0;
 #pragma unroll
             for (int w = 0; w < UPD_WAVES; ++w) {
@@ -366,22 +369,25 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
             xyk -= (p * q) * tt;  // XY -= (p q^T) tt (:429)
             const int n = a + 1;
             if (n >= A) break;
-            const double w = xyk / sqrt(bsum(xyk * xyk));  // (:404, :411)
+            if (kok) wl[k] = xyk;  // the deflated XY, not yet normalised
+            lds_barrier();
+            for (int j = wv; j <= n; j += UPD_WAVES) {  // p_j^T XY for j < n (a wave each), |XY|^2 (one more wave)
+                double c = 0.0;
+                if (j < n) {
+                    for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
+                } else {
+                    for (int kk = lane; kk < K; kk += WAVE) c = fma(wl[kk], wl[kk], c);
+                }
+                c = wave_sum(c);
+                if (lane == 0) (j < n ? cs[j] : sred[2 * UPD_WAVES]) = c;
+            }
+            lds_barrier();
+            const double inv = 1.0 / sqrt(sred[2 * UPD_WAVES]);
+            const double w = xyk * inv;  // w = XY / |XY| (:404, :411)
+            double r = w;
+            for (int j = 0; j < n; ++j) r -= (cs[j] * inv) * Rq[(kok ? k : 0) + (i64)j * K];  // c_j = p_j^T w; the reference's order (:412-416)
             if (kok) {
                 W[k + (i64)n * K] = w;
-                wl[k] = w;
-            }
-            lds_barrier();
-            for (int j = wv; j < n; j += UPD_WAVES) {  // c_j = p_j^T w, against the ORIGINAL w (:415)
-                double c = 0.0;
-                for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
-                c = wave_sum(c);
-                if (lane == 0) cs[j] = c;
-            }
-            lds_barrier();
-            double r = w;
-            for (int j = 0; j < n; ++j) r -= cs[j] * Rq[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
-            if (kok) {
                 R[k + (i64)n * K] = r;
                 Rq[k + (i64)n * K] = r;
                 rl[k] = r;
