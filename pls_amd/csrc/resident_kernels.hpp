@@ -203,19 +203,26 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
         xyk -= (p * q) * tt;  // XY -= (p q^T) tt (:429)
         const int n = a + 1;
         if (n >= A) break;
-        const double w = xyk / sqrt(tiny_block_sum(xyk * xyk, sred));  // (:404, :411)
-        st_out(rW, kof, (uint32_t)n * (uint32_t)K * 8u, w);
-        if (kok) wl[k] = w;
+        // |XY|^2 is one more wave's sum beside the p_j^T XY (no reduction of its own: two barriers fewer per component); the norm
+        // then divides both w = XY / |XY| (:404, :411) and the c_j = p_j^T w (:415)
+        if (kok) wl[k] = xyk;
         lds_barrier();
-        for (int j = wv; j < n; j += UPD_WAVES) {  // c_j = p_j^T w, against the ORIGINAL w (:415)
+        for (int j = wv; j <= n; j += UPD_WAVES) {
             double c = 0.0;
-            for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
+            if (j < n) {
+                for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
+            } else {
+                for (int kk = lane; kk < K; kk += WAVE) c = fma(wl[kk], wl[kk], c);
+            }
             c = wave_sum(c);
-            if (lane == 0) cs[j] = c;
+            if (lane == 0) (j < n ? cs[j] : sred[0]) = c;
         }
         lds_barrier();
+        const double inv = 1.0 / sqrt(sred[0]);
+        const double w = xyk * inv;
+        st_out(rW, kof, (uint32_t)n * (uint32_t)K * 8u, w);
         double r = w;
-        for (int j = 0; j < n; ++j) r -= cs[j] * Rl[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
+        for (int j = 0; j < n; ++j) r -= (cs[j] * inv) * Rl[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
         st_out(rR, kof, (uint32_t)n * (uint32_t)K * 8u, r);
         if (kok) {
             Rl[k + (i64)n * K] = r;
