@@ -123,7 +123,7 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
     extern __shared__ double dyn[];
     double *Pl = dyn, *Rl = dyn + (i64)K * A;  // P[:, j], R[:, j] as they are produced
     __shared__ double tp[UPD_THREADS], colp[UPD_WAVES][TINY_RC], praw[TINY_KMAX + 8], tot[TINY_KMAX + 8], wl[TINY_KMAX], vsl[TINY_KMAX];
-    __shared__ double cs[TINY_KMAX], ql[TINY_KMAX], sred[UPD_WAVES];
+    __shared__ double cs[TINY_KMAX], ql[TINY_KMAX], sred[2 * UPD_WAVES];
     __shared__ int flag;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     TinyShape shp(1);
@@ -169,6 +169,8 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
             Rl[k] = w;
             vsl[slot] = w;
         }
+        const double c = wave_sum(kok ? w * xyk : 0.0);  // r_0^T XY: see the end of the loop
+        if (lane == 0) sred[UPD_WAVES + wv] = c;
     }
     const double *vs = vsl + s * TINY_RC;
     for (int a = 0; a < A; ++a) {
@@ -187,13 +189,16 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
         ti = (double)(T)ti;  // the score as stored
         st_score<T>(rT, tof, (uint32_t)((i64)a * ldt * (i64)sizeof(T)), ti);
         const double ttl = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // this workgroup's rows of t^T t (:420)
-        tiny_column_sums(x, ti, colp, K, shp, praw);                                     // ... and of X^T t (:427)
+        tiny_column_sums<false>(x, ti, colp, K, shp, praw);                              // ... and of X^T t (:427); colp, praw: last read barriers ago
         if (tid == 0) praw[K] = ttl;
         lds_barrier();
         ok = resident_grid_sum(praw, K + 1, sy, phase++, tot, tp, &flag, ok);
         const double tt = tot[K];
         const double p = kok ? tot[k] / tt : 0.0;                                                      // (:427)
-        const double q = tiny_block_sum(kok ? Rl[k + (i64)a * K] * xyk : 0.0, sred) / tt;        // q = r^T XY / tt (:428)
+        double rxy = 0.0;  // r^T XY: its wave sums were left in sred[UPD_WAVES ..] when r_a was formed
+#pragma unroll
+        for (int w2 = 0; w2 < UPD_WAVES; ++w2) rxy += sred[UPD_WAVES + w2];
+        const double q = rxy / tt;                                                                     // q = r^T XY / tt (:428)
         st_out(rP, kof, (uint32_t)a * (uint32_t)K * 8u, p);
         if (kok) Pl[k + (i64)a * K] = p;
         if (tid == 0) {
@@ -227,6 +232,10 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
         if (kok) {
             Rl[k + (i64)n * K] = r;
             vsl[slot] = r;
+        }
+        {  // r_n^T XY, the numerator of the next q (:428): summed by waves now, added up behind the barriers of the next exchange
+            const double c = wave_sum(kok ? r * xyk : 0.0);
+            if (lane == 0) sred[UPD_WAVES + wv] = c;
         }
     }
     lds_barrier();

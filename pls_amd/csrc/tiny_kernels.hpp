@@ -90,10 +90,12 @@ __device__ __forceinline__ double tiny_block_sum(double v, double *smem) {
 }
 
 // out[k] = sum over the rows of x[.] * f for the column k of every (slice, j); all threads of the workgroup call it
+// LEAD = false: the caller has passed a barrier of its own since colp (and out) were last read
+template <bool LEAD = true>
 __device__ __forceinline__ void tiny_column_sums(const double (&x)[TINY_RC], double f, double (*colp)[TINY_RC], int K,
                                                  const TinyShape &shp, double *out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    lds_barrier();  // the previous use of colp has been read
+    if (LEAD) lds_barrier();  // the previous use of colp has been read
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         double vals[TINY_HALF];
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
     extern __shared__ double dyn[];
     double *Pl = dyn, *Rl = dyn + (i64)K * A;  // P[:, j], R[:, j] as they are produced
     __shared__ double tp[UPD_THREADS], colp[UPD_WAVES][TINY_RC], praw[TINY_KMAX], xy[TINY_KMAX], wl[TINY_KMAX], vsl[TINY_KMAX];
-    __shared__ double cs[TINY_KMAX], ql[TINY_KMAX], sred[UPD_WAVES];
+    __shared__ double cs[TINY_KMAX], ql[TINY_KMAX], sred[2 * UPD_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const TinyShape shp(N);
     const int s = wv / shp.wps, rb = wv % shp.wps, i = rb * WAVE + lane;
@@ -174,6 +176,8 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
             Rl[k] = w;
             vsl[slot] = w;
         }
+        const double c = wave_sum(kok ? w * xyk : 0.0);  // r_0^T XY: see the end of the loop
+        if (lane == 0) sred[UPD_WAVES + wv] = c;
     }
     const double *vs = vsl + s * TINY_RC;
     for (int a = 0; a < A; ++a) {
@@ -193,10 +197,13 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
         if (held) ti = 0.0;       // ... which has no score in its fold's fit
         st_score<T>(rT, tof, (uint32_t)((i64)a * ldt * (i64)sizeof(T)), ti);
         const double tt = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // (:420)
-        tiny_column_sums(x, ti, colp, K, shp, praw);                                    // X^T t (:427)
+        tiny_column_sums<false>(x, ti, colp, K, shp, praw);                             // X^T t (:427); colp, praw: last read two barriers ago
         lds_barrier();
         const double p = kok ? praw[k] / tt : 0.0;                                                        // (:427)
-        const double q = tiny_block_sum(kok ? Rl[k + (i64)a * K] * xyk : 0.0, sred) / tt;          // q = r^T XY / tt (:428)
+        double rxy = 0.0;  // r^T XY: its wave sums were left in sred[UPD_WAVES ..] when r_a was formed
+#pragma unroll
+        for (int w2 = 0; w2 < UPD_WAVES; ++w2) rxy += sred[UPD_WAVES + w2];
+        const double q = rxy / tt;                                                                        // q = r^T XY / tt (:428)
         st_out(rP, kof, (uint32_t)a * (uint32_t)K * 8u, p);
         if (kok) Pl[k + (i64)a * K] = p;
         if (tid == 0) {
@@ -234,6 +241,10 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
         if (kok) {
             Rl[k + (i64)n * K] = r;
             vsl[slot] = r;
+        }
+        {  // r_n^T XY, the numerator of the next q (:428): summed by waves now, added up behind the barriers of the next t^T t
+            const double c = wave_sum(kok ? r * xyk : 0.0);
+            if (lane == 0) sred[UPD_WAVES + wv] = c;
         }
     }
     lds_barrier();
