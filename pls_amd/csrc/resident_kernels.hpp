@@ -188,9 +188,17 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
             for (int q = 0; q < shp.S; ++q) ti += tp[(q * shp.wps + rb) * WAVE + lane];
         ti = (double)(T)ti;  // the score as stored
         st_score<T>(rT, tof, (uint32_t)((i64)a * ldt * (i64)sizeof(T)), ti);
-        const double ttl = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // this workgroup's rows of t^T t (:420)
+        {  // this workgroup's rows of t^T t (:420): summed by waves here, added up behind the barrier inside the column sums
+            const double c = wave_sum((act && s == 0) ? ti * ti : 0.0);
+            if (lane == 0) sred[wv] = c;
+        }
         tiny_column_sums<false>(x, ti, colp, K, shp, praw);                              // ... and of X^T t (:427); colp, praw: last read barriers ago
-        if (tid == 0) praw[K] = ttl;
+        if (tid == 0) {
+            double ttl = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < UPD_WAVES; ++w2) ttl += sred[w2];
+            praw[K] = ttl;
+        }
         lds_barrier();
         ok = resident_grid_sum(praw, K + 1, sy, phase++, tot, tp, &flag, ok);
         const double tt = tot[K];

@@ -196,9 +196,15 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
         const double ui = ti;     // x_i . r_a, also for a held-out row
         if (held) ti = 0.0;       // ... which has no score in its fold's fit
         st_score<T>(rT, tof, (uint32_t)((i64)a * ldt * (i64)sizeof(T)), ti);
-        const double tt = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // (:420)
+        {  // t^T t (:420): summed by waves here, added up behind the barriers of the column sums
+            const double c = wave_sum((act && s == 0) ? ti * ti : 0.0);
+            if (lane == 0) sred[wv] = c;
+        }
         tiny_column_sums<false>(x, ti, colp, K, shp, praw);                             // X^T t (:427); colp, praw: last read two barriers ago
         lds_barrier();
+        double tt = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < UPD_WAVES; ++w2) tt += sred[w2];
         const double p = kok ? praw[k] / tt : 0.0;                                                        // (:427)
         double rxy = 0.0;  // r^T XY: its wave sums were left in sred[UPD_WAVES ..] when r_a was formed
 #pragma unroll
