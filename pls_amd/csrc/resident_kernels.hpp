@@ -193,13 +193,12 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_kernel(const T *__re
             if (lane == 0) sred[wv] = c;
         }
         tiny_column_sums<false>(x, ti, colp, K, shp, praw);                              // ... and of X^T t (:427); colp, praw: last read barriers ago
-        if (tid == 0) {
+        if (tid == K) {  // (thread j of the exchange stores praw[j]: every thread reads what it wrote itself -- no barrier in between)
             double ttl = 0.0;
 #pragma unroll
             for (int w2 = 0; w2 < UPD_WAVES; ++w2) ttl += sred[w2];
             praw[K] = ttl;
         }
-        lds_barrier();
         ok = resident_grid_sum(praw, K + 1, sy, phase++, tot, tp, &flag, ok);
         const double tt = tot[K];
         const double p = kok ? tot[k] / tt : 0.0;                                                      // (:427)

@@ -89,11 +89,12 @@ __device__ __forceinline__ double tiny_block_sum(double v, double *smem) {
     return t;
 }
 
-// out[k] = sum over the rows of x[.] * f for the column k of every (slice, j); all threads of the workgroup call it
+// out[k] = sum over the rows of x[.] * f for the column k of every (slice, j); all threads of the workgroup call it; returns
+// out[threadIdx.x] (0 beyond K): the caller that only needs its own column reads no LDS and needs no barrier behind the call
 // LEAD = false: the caller has passed a barrier of its own since colp (and out) were last read
 template <bool LEAD = true>
-__device__ __forceinline__ void tiny_column_sums(const double (&x)[TINY_RC], double f, double (*colp)[TINY_RC], int K,
-                                                 const TinyShape &shp, double *out) {
+__device__ __forceinline__ double tiny_column_sums(const double (&x)[TINY_RC], double f, double (*colp)[TINY_RC], int K,
+                                                   const TinyShape &shp, double *out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (LEAD) lds_barrier();  // the previous use of colp has been read
 #pragma unroll
@@ -106,12 +107,15 @@ __device__ __forceinline__ void tiny_column_sums(const double (&x)[TINY_RC], dou
         if (valid) colp[wv][c * TINY_HALF + idx] = vals[0];
     }
     lds_barrier();
+    double own = 0.0;  // (K <= TINY_KMAX < UPD_THREADS: thread k forms the sum of column k -- and is the thread that owns it afterwards)
     for (int k = threadIdx.x; k < K; k += UPD_THREADS) {
         const int s = k % shp.S, j = k / shp.S;
         double t = 0.0;
         for (int w = 0; w < shp.wps; ++w) t += colp[s * shp.wps + w][j];
         out[k] = t;
+        own = t;
     }
+    return own;
 }
 
 // X: N x K (ld ldx), Y: N x 1; W, P, R: K x A; Q: 1 x A; Tm: N x A (ld ldt); B: K x 1 or null.
@@ -200,12 +204,11 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_kernel(const T *__restri
             const double c = wave_sum((act && s == 0) ? ti * ti : 0.0);
             if (lane == 0) sred[wv] = c;
         }
-        tiny_column_sums<false>(x, ti, colp, K, shp, praw);                             // X^T t (:427); colp, praw: last read two barriers ago
-        lds_barrier();
-        double tt = 0.0;
+        const double pk = tiny_column_sums<false>(x, ti, colp, K, shp, praw);           // X^T t (:427); colp, praw: last read two barriers ago
+        double tt = 0.0;  // (the wave sums were stored before the barrier inside the column sums)
 #pragma unroll
         for (int w2 = 0; w2 < UPD_WAVES; ++w2) tt += sred[w2];
-        const double p = kok ? praw[k] / tt : 0.0;                                                        // (:427)
+        const double p = kok ? pk / tt : 0.0;                                                             // (:427)
         double rxy = 0.0;  // r^T XY: its wave sums were left in sred[UPD_WAVES ..] when r_a was formed
 #pragma unroll
         for (int w2 = 0; w2 < UPD_WAVES; ++w2) rxy += sred[UPD_WAVES + w2];
