@@ -386,10 +386,17 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_fit_m_kernel(const T *__
             for (int q = 0; q < shp.S; ++q) ti += tp[(q * shp.wps + rb) * WAVE + lane];
         ti = (double)(T)ti;  // the score as stored
         if (act && s == 0) Tm[i + (i64)a * ldt] = (T)ti;
-        const double ttl = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // this workgroup's rows of t^T t (:420)
-        tiny_column_sums(x, ti, colp, K, shp, praw);                              // ... and of X^T t (:421)
-        if (tid == 0) praw[K] = ttl;
-        lds_barrier();
+        {  // this workgroup's rows of t^T t (:420): summed by waves here, added up behind the barrier inside the column sums
+            const double c = wave_sum((act && s == 0) ? ti * ti : 0.0);
+            if (lane == 0) sred[wv] = c;
+        }
+        tiny_column_sums<false>(x, ti, colp, K, shp, praw);                       // ... and of X^T t (:421); colp, praw: last read barriers ago
+        if (tid == K) {  // (thread j of the exchange stores praw[j]: every thread reads what it wrote itself -- no barrier in between)
+            double ttl = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < UPD_WAVES; ++w2) ttl += sred[w2];
+            praw[K] = ttl;
+        }
         ok = resident_grid_sum(praw, K + 1, sy, phase++, tot, tp, &flag, ok);
         const double tt = tot[K];
         const double p = kok ? tot[k] / tt : 0.0;  // (:427)

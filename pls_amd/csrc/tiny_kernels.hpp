@@ -386,10 +386,15 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_m_kernel(const T *__rest
         const double ui = ti;
         if (held) ti = 0.0;
         if (act && s == 0 && !fold) Tm[i + (i64)a * ldt] = (T)ti;
-        const double tt = tiny_block_sum((act && s == 0) ? ti * ti : 0.0, sred);  // (:420)
-        tiny_column_sums(x, ti, colp, K, shp, praw);                              // X^T t (:421)
-        lds_barrier();
-        const double p = kok ? praw[k] / tt : 0.0;  // (:427)
+        {  // t^T t (:420): summed by waves here, added up behind the barrier inside the column sums
+            const double c = wave_sum((act && s == 0) ? ti * ti : 0.0);
+            if (lane == 0) sred[wv] = c;
+        }
+        const double pk = tiny_column_sums<false>(x, ti, colp, K, shp, praw);     // X^T t (:421); colp, praw: last read barriers ago
+        double tt = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < UPD_WAVES; ++w2) tt += sred[w2];
+        const double p = kok ? pk / tt : 0.0;  // (:427) -- the thread's own column sum: no barrier behind the column sums
         if (kok) {
             if (!fold) P[k + (i64)a * K] = p;
             Pl[k + (i64)a * K] = p;
