@@ -350,21 +350,26 @@ __global__ __launch_bounds__(UPD_THREADS) void tiny_fit_m_kernel(const T *__rest
         double wk = 0.0;
 #pragma unroll
         for (int m = 0; m < MM; ++m) wk = fma(kok ? xy[m][k] : 0.0, qs[m], wk);  // w = XY q (:408)
-        wk = wk / sqrt(tiny_block_sum(wk * wk, sred));                          // (:411)
-        if (kok) {
-            if (!fold) W[k + (i64)a * K] = wk;
-            wl[k] = wk;
-        }
+        // |XY q|^2 is one more wave's sum beside the p_j^T (XY q) (no reduction of its own: two barriers fewer per component); the
+        // norm then divides both w (:411) and the c_j = p_j^T w (:415)
+        if (kok) wl[k] = wk;
         lds_barrier();
-        for (int j = wv; j < a; j += UPD_WAVES) {  // c_j = p_j^T w, against the ORIGINAL w (:415)
+        for (int j = wv; j <= a; j += UPD_WAVES) {
             double c = 0.0;
-            for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
+            if (j < a) {
+                for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
+            } else {
+                for (int kk = lane; kk < K; kk += WAVE) c = fma(wl[kk], wl[kk], c);
+            }
             c = wave_sum(c);
-            if (lane == 0) cs[j] = c;
+            if (lane == 0) (j < a ? cs[j] : sred[0]) = c;
         }
         lds_barrier();
+        const double inv = 1.0 / sqrt(sred[0]);
+        wk *= inv;
+        if (kok && !fold) W[k + (i64)a * K] = wk;
         double r = wk;
-        for (int j = 0; j < a; ++j) r -= cs[j] * Rl[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
+        for (int j = 0; j < a; ++j) r -= (cs[j] * inv) * Rl[(kok ? k : 0) + (i64)j * K];  // the reference's order (:412-416)
         if (kok) {
             if (!fold) R[k + (i64)a * K] = r;
             Rl[k + (i64)a * K] = r;
