@@ -66,10 +66,12 @@ __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, 
     const uint32_t soff = (uint32_t)((V * (4 * ((lane >> 2) & 3) + lq) + (i64)lj * ldo) * (i64)sizeof(T));
     const int ostep = (int)(4 * ldo * (i64)sizeof(T));  // bytes between the column groups
     auto load_x = [&](Pack<T, V> (&x)[U], i64 t, int k0) {
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X + t * RW + (i64)k0 * ldx), (short)0, 0x7fffffff, BUF_WORD3);
-        // the partial last tile: lanes whose rows lie beyond N load out-of-range offsets; a pack that straddles N reads the
-        // padding of its column (ldx is a multiple of the pack: the launcher's vec_ok) and is stored element by element
+        // the descriptor ends with the matrix (element (N - 1, K - 1)): a pack of the partial last tile that straddles N reads the
+        // padding between the columns (ldx is a multiple of the pack: the launcher's vec_ok) -- and, in the LAST column, nothing
+        // beyond the caller's allocation (out of range: zeros).  Lanes whose rows lie beyond N load out-of-range offsets.
+        const i64 ext = (((i64)(K - 1 - k0) * ldx + N - t * RW) * (i64)sizeof(T));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X + t * RW + (i64)k0 * ldx), (short)0,
+                                                                            (int)min(ext > 0 ? ext : (i64)0, (i64)0x7fffffff), BUF_WORD3);
         const bool rowok = t * RW + V * li < N;
 #pragma unroll
         for (int u = 0; u < U; ++u) x[u] = buf_ld_so<T, V, AUXL>(rs, (rowok && k0 + 4 * u + lq < K) ? voff : OOR, u * cstep);

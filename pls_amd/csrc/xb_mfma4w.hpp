@@ -77,8 +77,10 @@ __global__ __launch_bounds__(XB4_WG) void xb_mfma4w_kernel(const T *__restrict__
     };
     auto load_x = [&](Pack<T, V> (&x)[U], i64 t, int k0) {  // columns k0 + 4 u + lq of tile t (t < 0: nothing)
         const i64 tt = t < 0 ? 0 : t;
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X + tt * RW + (i64)k0 * ldx), (short)0, 0x7fffffff, BUF_WORD3);
+        // (the descriptor ends with the matrix: a straddling pack of the last column reads nothing beyond the caller's allocation)
+        const i64 ext = (((i64)(K - 1 - k0) * ldx + N - tt * RW) * (i64)sizeof(T));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X + tt * RW + (i64)k0 * ldx), (short)0,
+                                                                            (int)min(ext > 0 ? ext : (i64)0, (i64)0x7fffffff), BUF_WORD3);
         const bool rowok = t >= 0 && tt * RW + V * li < N;
 #pragma unroll
         for (int u = 0; u < U; ++u) x[u] = buf_ld_so<T, V, 2>(rs, (rowok && k0 + 4 * u + lq < k_hi) ? voff : OOR, u * cstep);
