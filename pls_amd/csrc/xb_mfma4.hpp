@@ -69,7 +69,8 @@ __global__ __launch_bounds__(WGT) void xb_mfma4_kernel(const T *__restrict__ X, 
         // the descriptor ends with the matrix (element (N - 1, K - 1)): a pack of the partial last tile that straddles N reads the
         // padding between the columns (ldx is a multiple of the pack: the launcher's vec_ok) -- and, in the LAST column, nothing
         // beyond the caller's allocation (out of range: zeros).  Lanes whose rows lie beyond N load out-of-range offsets.
-        const i64 ext = (((i64)(K - 1 - k0) * ldx + N - t * RW) * (i64)sizeof(T));
+        const i64 ext = (t + 1) * RW <= N ? (i64)0x7fffffff  // (a full tile: no bound to compute)
+                                         : ((i64)(K - 1 - k0) * ldx + N - t * RW) * (i64)sizeof(T);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X + t * RW + (i64)k0 * ldx), (short)0,
                                                                             (int)min(ext > 0 ? ext : (i64)0, (i64)0x7fffffff), BUF_WORD3);
         const bool rowok = t * RW + V * li < N;

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(XB4_WG) void xb_mfma4w_kernel(const T *__restrict__
     auto load_x = [&](Pack<T, V> (&x)[U], i64 t, int k0) {  // columns k0 + 4 u + lq of tile t (t < 0: nothing)
         const i64 tt = t < 0 ? 0 : t;
         // (the descriptor ends with the matrix: a straddling pack of the last column reads nothing beyond the caller's allocation)
-        const i64 ext = (((i64)(K - 1 - k0) * ldx + N - tt * RW) * (i64)sizeof(T));
+        const i64 ext = (tt + 1) * RW <= N ? (i64)0x7fffffff  // (a full tile: no bound to compute)
+                                         : ((i64)(K - 1 - k0) * ldx + N - tt * RW) * (i64)sizeof(T);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X + tt * RW + (i64)k0 * ldx), (short)0,
                                                                             (int)min(ext > 0 ? ext : (i64)0, (i64)0x7fffffff), BUF_WORD3);
         const bool rowok = t >= 0 && tt * RW + V * li < N;
