@@ -65,7 +65,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         LAUNCH_CHECK(c);
         return PLS_HIP_OK;
     }
-    // Mid-size single-response data with at most 128 columns under AUTO: ONE launch with three grid-wide hand-offs whatever A -- X^T X and X^T Y on
+    // Mid-size data (1-8 responses) with at most 128 columns under AUTO: ONE launch with three grid-wide hand-offs whatever A -- X^T X and X^T Y on
     // the matrix cores, the component loop on XX in ONE workgroup's LDS, the scores at the end (resident_gram.hpp); the resident
     // fits below exchange once per component.  An explicit KERNEL request keeps the reference's TYPE1 arithmetic (below).
     if (method == PLS_HIP_KERNEL_TYPE1 && (c->opt_algo == PLS_HIP_ALGO_AUTO || c->env.resident_gram == 2) && c->opt_fuse && !c->reducer &&
@@ -77,7 +77,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             plsk::ResidentGram rg;
             rg.rows_per = (int)(((N + G - 1) / G + 3) & ~(i64)3);
             G = (int)((N + rg.rows_per - 1) / rg.rows_per);
-            rg.LP = ((i64)K * K + (i64)K + 7) & ~(i64)7;
+            rg.LP = ((i64)K * K + (i64)K * M + 7) & ~(i64)7;
             rg.big = plsk::resident_gram_big(K);
             const size_t need = 256 + ((size_t)(G + 1) * rg.LP + (size_t)K * A) * 8;
             if (c->resident.bytes < need) {
@@ -85,8 +85,12 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 HIPCHK(c, hipMemsetAsync(c->resident.p, 0, 256, c->stream));  // both counters start from zero
                 c->resident_launches = 0;
             }
-            const size_t lds = ((size_t)rg.big + plsk::RG_SMALL + (size_t)2 * K * A) * 8;
-            if (!plsk::raise_dynamic_lds((const void *)plsk::resident_gram_fit_kernel<T>, (int)lds))
+            const size_t lds = ((size_t)rg.big + plsk::RG_SMALL + (size_t)plsk::resident_gram_extra(K, M, A)) * 8;
+            const void *fn = M <= 1   ? (const void *)plsk::resident_gram_fit_kernel<T, 1>
+                             : M <= 2 ? (const void *)plsk::resident_gram_fit_kernel<T, 2>
+                             : M <= 4 ? (const void *)plsk::resident_gram_fit_kernel<T, 4>
+                                      : (const void *)plsk::resident_gram_fit_kernel<T, 8>;
+            if (!plsk::raise_dynamic_lds(fn, (int)lds))
                 return fail(c, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the resident fit could not be raised");
             if (!c->rgflags.p) {
                 CHK(ensure(c, c->rgflags, (size_t)plsk::RESIDENT_MAX_WG * 4));
@@ -107,9 +111,15 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             Range r_fit("pls_hip_fit (single launch, resident, X^T X)");
             Scope s(c, PLS_HIP_FAM_SMALL, (2 * (i64)N * K + (i64)N * M + (i64)N * A) * (i64)sizeof(T) + (3 * (i64)K + M) * A * 8);
             resident_turn(c);
-            hipLaunchKernelGGL((plsk::resident_gram_fit_kernel<T>), dim3(G), dim3(plsk::UPD_THREADS), lds, c->stream, X, ldx, Y, N, K, A, W, P, Q,
-                               R, Tm, ldt, B, rg);
-            LAUNCH_CHECK(c);
+            {
+                int pit = (int)c->opt_power_iters;
+                void *args[] = {(void *)&X, (void *)&ldx, (void *)&Y, (void *)&ldy, (void *)&N, (void *)&K, (void *)&M, (void *)&A, (void *)&pit, (void *)&W,
+                                (void *)&P, (void *)&Q, (void *)&R, (void *)&Tm, (void *)&ldt, (void *)&B, (void *)&rg};
+                if (hipLaunchKernel(fn, dim3(G), dim3(plsk::UPD_THREADS), args, lds, c->stream) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(c, PLS_HIP_ERR_DEVICE, "kernel launch: resident_gram_fit");
+                }
+            }
             resident_done(c);
             return PLS_HIP_OK;
         }

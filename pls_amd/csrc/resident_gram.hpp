@@ -16,7 +16,8 @@
 //   4. every workgroup forms the scores of its rows, T = X R (src/pls.cpp:439-442).
 // The hand-offs are resident_kernels.hpp's (first row of MI355X_MICROARCH.md's "Valid forms": sc1 stores, vmcnt(0), barrier,
 // one lane's agent-scope arrival; sc1 loads behind the poll and a barrier; one workgroup per CU; bounded waits that end in a
-// status word, never a hang).  One response (2-8: resident_fit_m_kernel), fp64 or fp32 storage.
+// status word, never a hang).  1-8 responses (more than one: the direction by the one-wave eigen solver, still ONE product XX r per
+// component), fp64 or fp32 storage.
 #pragma once
 #include "resident_kernels.hpp"
 
@@ -55,13 +56,19 @@ inline int resident_gram_big(int K) {
     const int kp = (K + 15) / 16 * 16 + 16;
     return std::max(std::max(K * K + K, 16 * RG_ACH * 64), 32 * kp);
 }
-// 0: not covered; else the number of workgroups.  One response.
+// doubles of dynamic LDS behind the big block and the small vectors: P and R of every component; more responses: XY and Q as well
+inline int resident_gram_extra(int K, int M, int A) {
+    const int mm = M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8;
+    return 2 * K * A + (M > 1 ? mm * K + M * A : 0);
+}
+// 0: not covered; else the number of workgroups.  1-8 responses.
 inline int resident_gram_grid(i64 N, int K, int M, int A, i64 ldx, size_t es, int num_cu) {
-    if (M != 1 || K < 1 || K > RG_KMAX || A < 1 || 2 * A > K || N < 256) return 0;  // (A close to K: the last directions are noise, and XX squares
+    if (M < 1 || M > 8 || K < 1 || K > RG_KMAX || A < 1 || 2 * A > K || N < 256) return 0;  // (A close to K: the last directions are noise, and XX squares
                                                                                       // the condition number -- P^T R = I to 1e-8 only up to ~K/2; the TYPE1 kernels take those)
-    if (resident_gram_big(K) + RG_SMALL + 2 * K * A > RG_LDS_DOUBLES) return 0;   // XX + P and R of every component in LDS
+    if (resident_gram_big(K) + RG_SMALL + resident_gram_extra(K, M, A) > RG_LDS_DOUBLES - (M > 1 ? 256 : 0)) return 0;   // XX + P and R of every component in LDS
+                                                                                                                          // (more responses: 2 KB of static LDS for the eigen solver)
     if ((i64)N * K * (i64)es > ((i64)64 << 20) || (i64)K * ldx * (i64)es >= (1ll << 31)) return 0;
-    const i64 L = (i64)K * K + K;
+    const i64 L = (i64)K * K + (i64)K * M;
     // phase 1 is matrix-core work on G CUs at the clocks of a nearly idle chip (~1.1 GHz: 5,000 x 128 on 60 workgroups 19 us):
     // as many workgroups as leave 32 rows each (64 below 64 columns), up to ~20 MB of parts
     i64 G = std::min<i64>(std::min<i64>(num_cu, RESIDENT_MAX_WG), N / (K >= 64 ? 32 : 64));  // (few columns: the hand-offs cost more than the product)
@@ -115,26 +122,29 @@ __device__ __forceinline__ bool resident_gram_barrier(const ResidentGram &rg, un
     return ok;
 }
 
-// X: N x K (ld ldx), Y: N x 1; W, P, R: K x A; Q: 1 x A; Tm: N x A (ld ldt); B: K x 1 or null.
-// grid = G workgroups of 1024 threads; dynamic LDS: rg.big + RG_SMALL + 2 K A doubles.
-template <typename T>
-__global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T *__restrict__ X, i64 ldx, const T *__restrict__ Y, i64 N, int K,
-                                                                        int A, double *__restrict__ W, double *__restrict__ P,
-                                                                        double *__restrict__ Q, double *__restrict__ R, T *__restrict__ Tm,
-                                                                        i64 ldt, double *__restrict__ B, const ResidentGram rg) {
+// X: N x K (ld ldx), Y: N x M (ld ldy), M <= MM; W, P, R: K x A; Q: M x A; Tm: N x A (ld ldt); B: K x M or null.
+// grid = G workgroups of 1024 threads; dynamic LDS: rg.big + RG_SMALL + resident_gram_extra(K, M, A) doubles.
+template <typename T, int MM>
+__global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T *__restrict__ X, i64 ldx, const T *__restrict__ Y, i64 ldy, i64 N,
+                                                                        int K, int M, int A, int power_iters, double *__restrict__ W,
+                                                                        double *__restrict__ P, double *__restrict__ Q, double *__restrict__ R,
+                                                                        T *__restrict__ Tm, i64 ldt, double *__restrict__ B,
+                                                                        const ResidentGram rg) {
+    static_assert(MM == 1 || MM * MM <= WAVE, "one wave solves the eigenproblem");
     typedef double f64x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) double rgd[];
-    __shared__ double sred[2 * UPD_WAVES + 8];
+    __shared__ double sred[2 * UPD_WAVES + 8], Gs[MM * MM], Bs[MM * MM], Cs[MM * MM], qs[MM], qa[MM];
     __shared__ int flag;
     double *big = rgd;                          // [rg.big]
     double *sp = rgd + rg.big;                  // [512]: partial sums (XX r by column group; a slice by workgroup subset)
     double *rl = sp + 512;                      // [K]: r_a
     double *cs = rl + RG_KMAX;                  // [A]: p_j^T w
     double *wl = cs + RG_KMAX;                  // [K]: w
-    double *ql = wl + RG_KMAX;                  // [A]: q
+    double *ql = wl + RG_KMAX;                  // [M A]: q (M = 1: room for A <= 136; more responses: behind R)
     double *Pl = ql + RG_KMAX + 8;              // [K A]
     double *Rq = Pl + (i64)K * A;               // [K A]
-    constexpr int M = 1;
+    double *xyl = Rq + (i64)K * A;              // MM > 1: [MM][K] XY, then [M A] Q
+    if (MM > 1) ql = xyl + (i64)MM * K;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int G = gridDim.x, g = blockIdx.x;
     const i64 L = (i64)K * K + (i64)K * M;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
                 v[u] = 0.0;
                 if (idx < rc4 * KP && row < rc) {
                     if (col < K) v[u] = (double)X[c0 + row + (i64)col * ldx];
-                    else if (col == nb * 16) v[u] = (double)Y[c0 + row];
+                    else if (col >= nb * 16 && col - nb * 16 < M) v[u] = (double)Y[c0 + row + (i64)(col - nb * 16) * ldy];
                 }
             }
 #pragma unroll
@@ -221,8 +231,8 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
                         st_agent(mine + i + (i64)j * K, v);
                         if (bi != bj) st_agent(mine + j + (i64)i * K, v);
                     }
-                } else if (i < K && li == 0) {
-                    st_agent(mine + (i64)K * K + i, v);
+                } else if (i < K && li < M) {
+                    st_agent(mine + (i64)K * K + i + (i64)li * K, v);
                 }
             }
         }
@@ -299,105 +309,203 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
                 }
             }
         }
-        double xyk = kok ? (direct ? sum_parts((i64)K * K + k) : ld_sc1(rg.gred, (i64)K * K + k)) : 0.0;  // XY = X^T Y (:396)
-        auto bsum = [&](double v) -> double {  // block sum on lds_barrier (every thread calls it)
-            v = wave_sum(v);
+        if constexpr (MM == 1) {
+            double xyk = kok ? (direct ? sum_parts((i64)K * K + k) : ld_sc1(rg.gred, (i64)K * K + k)) : 0.0;  // XY = X^T Y (:396)
+            auto bsum = [&](double v) -> double {  // block sum on lds_barrier (every thread calls it)
+                v = wave_sum(v);
+                lds_barrier();
+                if (lane == 0) sred[wv] = v;
+                lds_barrier();
+                double t = 0.0;
+    #pragma unroll
+                for (int w = 0; w < UPD_WAVES; ++w) t += sred[w];
+                return t;
+            };
+            RG_STAMP(4);
+            {  // w_0 = XY / |XY| (:404, :411), r_0 = w_0
+                const double w = xyk / sqrt(bsum(xyk * xyk));
+                if (kok) {
+                    W[k] = w;
+                    R[k] = w;
+                    Rq[k] = w;
+                    rl[k] = w;
+                }
+            }
+            // Four barriers per component: what would be a reduction of its own rides on a barrier that is there anyway --
+            // r^T XX r and r^T XY are summed by waves next to the partial sums of XX r; |XY| next to the p_j^T XY (the norm then
+            // divides both w and the p_j^T w).
+            for (int a = 0; a < A; ++a) {
+                lds_barrier();  // r_a (rl) complete; XX in LDS
+                // XX r (:424): thread (kq, jg) adds XX[kq][j] r[j] over the jg-th group of the columns j (row kq of column j: consecutive
+                // lanes, consecutive addresses; r[j] a broadcast); the NJG partial sums of an output meet in order behind the barrier
+                double s = 0.0;
+                if (jg < NJG && kq < K) {
+                    double s0 = 0.0, s1 = 0.0;
+                    const int ja = jg * JL, jb2 = min(K, ja + JL);
+                    int j = ja;
+                    for (; j + 1 < jb2; j += 2) {
+                        s0 = fma(big[(i64)j * K + kq], rl[j], s0);
+                        s1 = fma(big[(i64)(j + 1) * K + kq], rl[j + 1], s1);
+                    }
+                    if (j < jb2) s0 = fma(big[(i64)j * K + kq], rl[j], s0);
+                    s = s0 + s1;
+                    sp[jg * KW + kq] = s;
+                }
+                {  // tt = r^T XX r (:425) = the sum of r[kq] * (partial sum) over every (kq, jg); r^T XY from the threads that own a column
+                    const double v0 = wave_sum((jg < NJG && kq < K) ? rl[kq] * s : 0.0), v1 = wave_sum(kok ? rl[k] * xyk : 0.0);
+                    if (lane == 0) {
+                        sred[wv] = v0;
+                        sred[UPD_WAVES + wv] = v1;
+                    }
+                }
+                lds_barrier();
+                double pr = 0.0;
+                if (kok)
+                    for (int q = 0; q < NJG; ++q) pr += sp[q * KW + k];
+                double tt = 0.0, rxy = 0.0;
+    #pragma unroll
+                for (int w = 0; w < UPD_WAVES; ++w) {
+                    tt += sred[w];
+                    rxy += sred[UPD_WAVES + w];
+                }
+                const double p = pr / tt, q = rxy / tt;  // (:427, :428)
+                if (kok) {
+                    P[k + (i64)a * K] = p;
+                    Pl[k + (i64)a * K] = p;
+                }
+                if (tid == 0) {
+                    Q[a] = q;
+                    ql[a] = q;
+                }
+                xyk -= (p * q) * tt;  // XY -= (p q^T) tt (:429)
+                const int n = a + 1;
+                if (n >= A) break;
+                if (kok) wl[k] = xyk;  // the deflated XY, not yet normalised
+                lds_barrier();
+                for (int j = wv; j <= n; j += UPD_WAVES) {  // p_j^T XY for j < n (a wave each), |XY|^2 (one more wave)
+                    double c = 0.0;
+                    if (j < n) {
+                        for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
+                    } else {
+                        for (int kk = lane; kk < K; kk += WAVE) c = fma(wl[kk], wl[kk], c);
+                    }
+                    c = wave_sum(c);
+                    if (lane == 0) (j < n ? cs[j] : sred[2 * UPD_WAVES]) = c;
+                }
+                lds_barrier();
+                const double inv = 1.0 / sqrt(sred[2 * UPD_WAVES]);
+                const double w = xyk * inv;  // w = XY / |XY| (:404, :411)
+                double r = w;
+                for (int j = 0; j < n; ++j) r -= (cs[j] * inv) * Rq[(kok ? k : 0) + (i64)j * K];  // c_j = p_j^T w; the reference's order (:412-416)
+                if (kok) {
+                    W[k + (i64)n * K] = w;
+                    R[k + (i64)n * K] = r;
+                    Rq[k + (i64)n * K] = r;
+                    rl[k] = r;
+                }
+            }
             lds_barrier();
-            if (lane == 0) sred[wv] = v;
-            lds_barrier();
-            double t = 0.0;
+            if (B && kok) {  // B = R Q^T (:444-451)
+                double b = 0.0;
+                for (int a = 0; a < A; ++a) b = fma(Rq[k + (i64)a * K], ql[a], b);
+                B[k] = b;
+            }
+        } else {
+            // ---- 2..8 responses: the direction by the one-wave eigen solver (src/pls.cpp:403-411), ONE product XX r per component ----
+            for (int m = 0; m < MM; ++m)
+                if (kok) xyl[m * K + k] = m < M ? (direct ? sum_parts((i64)K * K + (i64)m * K + k) : ld_sc1(rg.gred, (i64)K * K + (i64)m * K + k)) : 0.0;
+            RG_STAMP(4);
+            for (int a = 0; a < A; ++a) {
+                lds_barrier();  // XY complete (and XX in LDS)
+                for (int pr = wv; pr < MM * (MM + 1) / 2; pr += UPD_WAVES) {  // G = XY^T XY, one wave per pair (i <= j)
+                    int gi = 0, rem = pr;
+                    while (rem >= MM - gi) { rem -= MM - gi; ++gi; }
+                    const int gj = gi + rem;
+                    double gsum = 0.0;
+                    for (int kk = lane; kk < K; kk += WAVE) gsum = fma(xyl[gi * K + kk], xyl[gj * K + kk], gsum);
+                    gsum = wave_sum(gsum);
+                    if (lane == 0) { Gs[gi + gj * MM] = gsum; Gs[gj + gi * MM] = gsum; }
+                }
+                lds_barrier();
+                if (wv == 0) dominant_eigvec_wave<MM>(Gs, Bs, Cs, qs, power_iters);
+                lds_barrier();
+                double wk = 0.0;
 #pragma unroll
-            for (int w = 0; w < UPD_WAVES; ++w) t += sred[w];
-            return t;
-        };
-        RG_STAMP(4);
-        {  // w_0 = XY / |XY| (:404, :411), r_0 = w_0
-            const double w = xyk / sqrt(bsum(xyk * xyk));
-            if (kok) {
-                W[k] = w;
-                R[k] = w;
-                Rq[k] = w;
-                rl[k] = w;
-            }
-        }
-        // Four barriers per component: what would be a reduction of its own rides on a barrier that is there anyway --
-        // r^T XX r and r^T XY are summed by waves next to the partial sums of XX r; |XY| next to the p_j^T XY (the norm then
-        // divides both w and the p_j^T w).
-        for (int a = 0; a < A; ++a) {
-            lds_barrier();  // r_a (rl) complete; XX in LDS
-            // XX r (:424): thread (kq, jg) adds XX[kq][j] r[j] over the jg-th group of the columns j (row kq of column j: consecutive
-            // lanes, consecutive addresses; r[j] a broadcast); the NJG partial sums of an output meet in order behind the barrier
-            double s = 0.0;
-            if (jg < NJG && kq < K) {
-                double s0 = 0.0, s1 = 0.0;
-                const int ja = jg * JL, jb2 = min(K, ja + JL);
-                int j = ja;
-                for (; j + 1 < jb2; j += 2) {
-                    s0 = fma(big[(i64)j * K + kq], rl[j], s0);
-                    s1 = fma(big[(i64)(j + 1) * K + kq], rl[j + 1], s1);
+                for (int m = 0; m < MM; ++m) wk = fma(kok ? xyl[m * K + k] : 0.0, qs[m], wk);  // w = XY q (:408), not yet normalised
+                if (kok) wl[k] = wk;
+                lds_barrier();
+                for (int j = wv; j <= a; j += UPD_WAVES) {  // p_j^T (XY q) for j < a (a wave each), |XY q|^2 (one more wave)
+                    double c = 0.0;
+                    if (j < a) {
+                        for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
+                    } else {
+                        for (int kk = lane; kk < K; kk += WAVE) c = fma(wl[kk], wl[kk], c);
+                    }
+                    c = wave_sum(c);
+                    if (lane == 0) (j < a ? cs[j] : sred[2 * UPD_WAVES]) = c;
                 }
-                if (j < jb2) s0 = fma(big[(i64)j * K + kq], rl[j], s0);
-                s = s0 + s1;
-                sp[jg * KW + kq] = s;
-            }
-            {  // tt = r^T XX r (:425) = the sum of r[kq] * (partial sum) over every (kq, jg); r^T XY from the threads that own a column
-                const double v0 = wave_sum((jg < NJG && kq < K) ? rl[kq] * s : 0.0), v1 = wave_sum(kok ? rl[k] * xyk : 0.0);
-                if (lane == 0) {
-                    sred[wv] = v0;
-                    sred[UPD_WAVES + wv] = v1;
+                lds_barrier();
+                const double inv = 1.0 / sqrt(sred[2 * UPD_WAVES]);
+                wk *= inv;  // (:411)
+                double r = wk;
+                for (int j = 0; j < a; ++j) r -= (cs[j] * inv) * Rq[(kok ? k : 0) + (i64)j * K];  // c_j = p_j^T w; the reference's order (:412-416)
+                if (kok) {
+                    W[k + (i64)a * K] = wk;
+                    R[k + (i64)a * K] = r;
+                    Rq[k + (i64)a * K] = r;
+                    rl[k] = r;
                 }
-            }
-            lds_barrier();
-            double pr = 0.0;
-            if (kok)
-                for (int q = 0; q < NJG; ++q) pr += sp[q * KW + k];
-            double tt = 0.0, rxy = 0.0;
+                lds_barrier();  // r_a complete
+                double s = 0.0;  // XX r (:424) by column groups, r^T XX r by waves beside it (as for one response)
+                if (jg < NJG && kq < K) {
+                    double s0 = 0.0, s1 = 0.0;
+                    const int ja = jg * JL, jb2 = min(K, ja + JL);
+                    int j = ja;
+                    for (; j + 1 < jb2; j += 2) {
+                        s0 = fma(big[(i64)j * K + kq], rl[j], s0);
+                        s1 = fma(big[(i64)(j + 1) * K + kq], rl[j + 1], s1);
+                    }
+                    if (j < jb2) s0 = fma(big[(i64)j * K + kq], rl[j], s0);
+                    s = s0 + s1;
+                    sp[jg * KW + kq] = s;
+                }
+                {
+                    const double v0 = wave_sum((jg < NJG && kq < K) ? rl[kq] * s : 0.0);
+                    if (lane == 0) sred[wv] = v0;
+                }
+                if (wv >= UPD_WAVES - MM) {  // q_m = r^T XY[:, m] (:428): the last MM waves, one response each (the first ones carry XX r)
+                    const int m = wv - (UPD_WAVES - MM);
+                    double c = 0.0;
+                    for (int kk = lane; kk < K; kk += WAVE) c = fma(rl[kk], xyl[m * K + kk], c);
+                    c = wave_sum(c);
+                    if (lane == 0) qa[m] = c;
+                }
+                lds_barrier();
+                double pr = 0.0;
+                if (kok)
+                    for (int q = 0; q < NJG; ++q) pr += sp[q * KW + k];
+                double tt = 0.0;
 #pragma unroll
-            for (int w = 0; w < UPD_WAVES; ++w) {
-                tt += sred[w];
-                rxy += sred[UPD_WAVES + w];
-            }
-            const double p = pr / tt, q = rxy / tt;  // (:427, :428)
-            if (kok) {
-                P[k + (i64)a * K] = p;
-                Pl[k + (i64)a * K] = p;
-            }
-            if (tid == 0) {
-                Q[a] = q;
-                ql[a] = q;
-            }
-            xyk -= (p * q) * tt;  // XY -= (p q^T) tt (:429)
-            const int n = a + 1;
-            if (n >= A) break;
-            if (kok) wl[k] = xyk;  // the deflated XY, not yet normalised
-            lds_barrier();
-            for (int j = wv; j <= n; j += UPD_WAVES) {  // p_j^T XY for j < n (a wave each), |XY|^2 (one more wave)
-                double c = 0.0;
-                if (j < n) {
-                    for (int kk = lane; kk < K; kk += WAVE) c = fma(Pl[kk + (i64)j * K], wl[kk], c);
-                } else {
-                    for (int kk = lane; kk < K; kk += WAVE) c = fma(wl[kk], wl[kk], c);
+                for (int w = 0; w < UPD_WAVES; ++w) tt += sred[w];
+                const double p = pr / tt;  // (:427)
+                if (kok) {
+                    P[k + (i64)a * K] = p;
+                    Pl[k + (i64)a * K] = p;
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) xyl[m * K + k] -= (p * (qa[m] / tt)) * tt;  // XY -= (p q^T) tt (:429)
                 }
-                c = wave_sum(c);
-                if (lane == 0) (j < n ? cs[j] : sred[2 * UPD_WAVES]) = c;
+                if (tid < M) {
+                    Q[tid + (i64)a * M] = qa[tid] / tt;
+                    ql[tid + (i64)a * M] = qa[tid] / tt;
+                }
             }
             lds_barrier();
-            const double inv = 1.0 / sqrt(sred[2 * UPD_WAVES]);
-            const double w = xyk * inv;  // w = XY / |XY| (:404, :411)
-            double r = w;
-            for (int j = 0; j < n; ++j) r -= (cs[j] * inv) * Rq[(kok ? k : 0) + (i64)j * K];  // c_j = p_j^T w; the reference's order (:412-416)
-            if (kok) {
-                W[k + (i64)n * K] = w;
-                R[k + (i64)n * K] = r;
-                Rq[k + (i64)n * K] = r;
-                rl[k] = r;
-            }
-        }
-        lds_barrier();
-        if (B && kok) {  // B = R Q^T (:444-451)
-            double b = 0.0;
-            for (int a = 0; a < A; ++a) b = fma(Rq[k + (i64)a * K], ql[a], b);
-            B[k] = b;
+            if (B && kok)  // B = R Q^T (:444-447)
+                for (int m = 0; m < M; ++m) {
+                    double b = 0.0;
+                    for (int a = 0; a < A; ++a) b = fma(Rq[k + (i64)a * K], ql[m + (i64)a * M], b);
+                    B[k + (i64)m * K] = b;
+                }
         }
         for (int j = tid; j < K * A; j += UPD_THREADS) st_agent(rg.rshare + j, Rq[j]);
     }

@@ -1049,11 +1049,13 @@ def test_resident_single_launch_fit(handle, oracle, po, N, K, A, dt, pad, M):
     assert po.rel_fro(first["B"].cpu().numpy(), plain["B"].cpu().numpy()) < (1e-10 if dt == "f64" else 2e-5)
 
 
-@pytest.mark.parametrize("N,K,A,dt,pad", [(1025, 26, 5, "f64", 0), (5000, 128, 10, "f64", 0), (5003, 128, 11, "f64", 3), (20000, 16, 5, "f64", 1), (100000, 40, 12, "f64", 0),
-                                          (262144, 26, 4, "f64", 0), (3001, 77, 7, "f32", 5), (70000, 50, 9, "f32", 0), (2050, 64, 32, "f64", 0), (1500, 100, 20, "f64", 0),
-                                          (8000, 100, 5, "f64", 0), (300, 90, 6, "f64", 0)])
-def test_resident_gram_single_launch_fit(handle, oracle, po, N, K, A, dt, pad):
-    """AUTO on mid-size single-response data with at most 128 columns: ONE launch with three grid-wide hand-offs whatever A
+@pytest.mark.parametrize("N,K,A,dt,pad,M", [(1025, 26, 5, "f64", 0, 1), (5000, 128, 10, "f64", 0, 1), (5003, 128, 11, "f64", 3, 1), (20000, 16, 5, "f64", 1, 1),
+                                            (100000, 40, 12, "f64", 0, 1), (262144, 26, 4, "f64", 0, 1), (3001, 77, 7, "f32", 5, 1), (70000, 50, 9, "f32", 0, 1),
+                                            (2050, 64, 32, "f64", 0, 1), (1500, 100, 20, "f64", 0, 1), (8000, 100, 5, "f64", 0, 1), (300, 90, 6, "f64", 0, 1),
+                                            (1025, 26, 5, "f64", 0, 3), (5000, 100, 8, "f64", 2, 4), (100000, 40, 12, "f64", 0, 8), (3001, 77, 7, "f32", 1, 5),
+                                            (2000, 120, 6, "f64", 0, 2), (9000, 128, 9, "f64", 0, 7)])
+def test_resident_gram_single_launch_fit(handle, oracle, po, N, K, A, dt, pad, M):
+    """AUTO on mid-size data (1..8 responses) with at most 128 columns: ONE launch with three grid-wide hand-offs whatever A
     (resident_gram.hpp: X^T X and X^T Y on the matrix cores, the component loop on XX in one workgroup's LDS, the scores at the
     end).  Row counts that leave ragged last workgroups, a padded leading dimension, fp32 storage, the direct and the sliced
     sum of the parts, as many components as the LDS holds: against the oracle and the general plan, one launch in all, repeated
@@ -1064,7 +1066,7 @@ def test_resident_gram_single_launch_fit(handle, oracle, po, N, K, A, dt, pad):
     Xbig = torch.zeros((K, N + pad), dtype=tdt, device="cuda")
     Xbig[:, :N] = handle.synth_x(5, N, K, 31, dtype=tdt).T
     Xd = Xbig.T[:N]                                   # column-major view, ld = N + pad
-    Yd = handle.synth_y(5, N, 1, 31, dtype=tdt)
+    Yd = handle.synth_y(5, N, M, 31, dtype=tdt)
     Xh = np.asfortranarray(Xd.cpu().numpy().astype(np.float64)); Yh = np.asfortranarray(Yd.cpu().numpy().astype(np.float64))
     ref, Bref, cerr = oracle_ref(oracle, po, Xh, Yh, A)
     handle.set_option(pls_amd.OPT_PROFILE, 2)
