@@ -79,6 +79,11 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             G = (int)((N + rg.rows_per - 1) / rg.rows_per);
             rg.LP = ((i64)K * K + (i64)K * M + 7) & ~(i64)7;
             rg.big = plsk::resident_gram_big(K);
+            {  // many rows per workgroup and room in LDS: twice the rows staged at a time
+                const int kp = (K + 15) / 16 * 16 + 16;
+                if ((i64)rg.rows_per * kp > rg.big && rg.big < 16384 && 16384 + plsk::RG_SMALL + plsk::resident_gram_extra(K, M, A) <= plsk::RG_LDS_DOUBLES - (M > 1 ? 256 : 0))
+                    rg.big = 16384;
+            }
             const size_t need = 256 + ((size_t)(G + 1) * rg.LP + (size_t)K * A) * 8;
             if (c->resident.bytes < need) {
                 CHK(ensure(c, c->resident, need));

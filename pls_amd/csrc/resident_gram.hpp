@@ -157,10 +157,15 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
     const i64 r0 = (i64)g * rg.rows_per, r1 = min(N, r0 + (i64)rg.rows_per);
     const int nb = (K + 15) / 16;                 // 16-column blocks of X; block index nb: the responses
     const int KP = nb * 16 + 16;                  // row stride of the staged rows: X blocks, then 16 response slots
-    const int chunk = (rg.big / KP) & ~3;  // rows staged at a time (>= 32)
+    // rows staged at a time: a power of two (>= 32), so that the staging's (row, column) of an element are a mask and a shift
+    const int clg = 31 - __builtin_clz((unsigned)(rg.big / KP)), chunk = 1 << clg;
     const int npairs = nb * (nb + 1) / 2 + nb;    // (bi <= bj) and (bi, Y)
     const int li = lane & 15, lk = lane >> 4;
     double *mine = rg.part + (i64)g * rg.LP;
+    // few pairs (few columns): the 16 waves are (pair, row split) -- wave = split * npairs + pair walks every RSPL-th 4-row step
+    const int RSPL = npairs < UPD_WAVES ? UPD_WAVES / npairs : 1;
+    const int task = RSPL > 1 ? wv % npairs : wv, rsp = RSPL > 1 ? wv / npairs : 0;
+    const bool tact = rsp < RSPL;  // (RSPL > 1: the waves beyond npairs * RSPL idle)
     // a wave owns the pairs wv, wv + 16, ...: at most 3 for K = 128 (44 pairs)
     constexpr int MAXP = 3;
     f64x4 acc[MAXP];
@@ -179,24 +184,26 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
         bi = rest;
         bj = nb;
     };
+    // (loading the NEXT chunk into registers behind this chunk's MFMAs was tried: sixteen guarded loads per thread whatever the
+    // chunk cost 5 us more than the waits they hid)
     for (i64 c0 = r0; c0 < r1; c0 += chunk) {
         const int rc = (int)min((i64)chunk, r1 - c0), rc4 = (rc + 3) & ~3;
         __syncthreads();  // the previous chunk has been read
-        for (int base = 0; base < rc4 * KP; base += 8 * UPD_THREADS) {  // consecutive threads: consecutive rows of one column; eight loads in flight
+        for (int base = 0; base < chunk * KP; base += 8 * UPD_THREADS) {  // consecutive threads: consecutive rows of one column; eight loads in flight
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * UPD_THREADS + tid, row = idx % rc4, col = idx / rc4;
+                const int idx = base + u * UPD_THREADS + tid, row = idx & (chunk - 1), col = idx >> clg;
                 v[u] = 0.0;
-                if (idx < rc4 * KP && row < rc) {
+                if (col < KP && row < rc) {
                     if (col < K) v[u] = (double)X[c0 + row + (i64)col * ldx];
                     else if (col >= nb * 16 && col - nb * 16 < M) v[u] = (double)Y[c0 + row + (i64)(col - nb * 16) * ldy];
                 }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * UPD_THREADS + tid, row = idx % rc4, col = idx / rc4;
-                if (idx < rc4 * KP) big[row * KP + col] = v[u];
+                const int idx = base + u * UPD_THREADS + tid, row = idx & (chunk - 1), col = idx >> clg;
+                if (col < KP && row < rc4) big[row * KP + col] = v[u];
             }
         }
         __syncthreads();
@@ -204,22 +211,35 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
             int bi = 0, bj = 0;
-            if (wv + p * UPD_WAVES < npairs) pair_of(wv + p * UPD_WAVES, bi, bj);
+            if (task + p * UPD_WAVES < npairs) pair_of(task + p * UPD_WAVES, bi, bj);
             ap[p] = big + lk * KP + bi * 16 + li;
             bp[p] = big + lk * KP + bj * 16 + li;
         }
-        for (int r = 0; r < rc4; r += 4) {  // the wave's (up to) three accumulation chains side by side
+        if (tact)
+            for (int r = 4 * rsp; r < rc4; r += 4 * RSPL) {  // the wave's (up to) three accumulation chains side by side
 #pragma unroll
-            for (int p = 0; p < MAXP; ++p)
-                if (wv + p * UPD_WAVES < npairs) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[p][r * KP], bp[p][r * KP], acc[p], 0, 0, 0);
+                for (int p = 0; p < MAXP; ++p)
+                    if (task + p * UPD_WAVES < npairs) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[p][r * KP], bp[p][r * KP], acc[p], 0, 0, 0);
+            }
+    }
+    if (RSPL > 1) {  // the row splits of a pair meet in LDS, in split order (the staged rows are done with)
+        __syncthreads();
+        if (tact && rsp > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) big[(wv * 4 + q) * WAVE + lane] = acc[0][q];
         }
+        __syncthreads();
+        if (tact && rsp == 0)
+            for (int s2 = 1; s2 < RSPL; ++s2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[0][q] += big[((s2 * npairs + task) * 4 + q) * WAVE + lane];
     }
     // D: lane holds rows (lane >> 4) + 4 q, column lane & 15 of the 16 x 16 block (assembling the part in LDS for consecutive stores
     // was tried: two barriers and a store loop cost more than the scattered stores, 19 -> 25 us at K = 128)
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
-        const int idx = wv + p * UPD_WAVES;
-        if (idx < npairs) {
+        const int idx = task + p * UPD_WAVES;
+        if (idx < npairs && rsp == 0) {
             int bi, bj;
             pair_of(idx, bi, bj);
 #pragma unroll
@@ -518,6 +538,36 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
     double *Rl = Rq, *tp = big;  // tp: [16 waves][RG_ACH][64]
     if (g != 0 || !ok)
         for (int j = tid; j < K * A; j += UPD_THREADS) Rl[j] = ok ? ld_sc1(rg.rshare, j) : __builtin_nan("");
+    if (r1 - r0 >= 6 * WAVE) {
+        // many rows: a wave per 64-row block, a lane per row, all K columns -- no partial sums to meet, no barrier; 16 score columns
+        // at a time (X is read again for the next 16: from L2)
+        __syncthreads();  // Rl complete
+        for (i64 b0 = r0 + (i64)wv * WAVE; b0 < r1; b0 += (i64)UPD_WAVES * WAVE) {
+            const i64 row = b0 + lane;
+            for (int a0 = 0; a0 < A; a0 += 16) {
+                double ac[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) ac[c] = 0.0;
+                for (int k0 = 0; k0 < K; k0 += 8) {
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = (row < r1 && k0 + u < K) ? (double)X[row + (i64)(k0 + u) * ldx] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (k0 + u < K) {
+#pragma unroll
+                            for (int c = 0; c < 16; ++c)
+                                if (a0 + c < A) ac[c] = fma(x[u], Rl[k0 + u + (i64)(a0 + c) * K], ac[c]);
+                        }
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (a0 + c < A && row < r1) Tm[row + (i64)(a0 + c) * ldt] = (T)ac[c];
+            }
+        }
+        RG_STAMP(7);
+        return;
+    }
     const int ksl = (K + UPD_WAVES - 1) / UPD_WAVES, k_lo = wv * ksl, k_hi = min(K, k_lo + ksl);  // (ksl <= 8)
     double xn[8];
 #pragma unroll
