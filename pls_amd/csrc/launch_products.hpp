@@ -399,7 +399,9 @@ int launch_xty(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         // 8 responses in one go: the copy-and-product sweep WITHOUT its copy (retile_xty_kernel, dst == nullptr) -- the Y block of
         // a tile goes through LDS once instead of 8 packs per lane and 4 columns (xty8_kernel: 0.49 / 0.60 of peak in fp32 / fp64)
         int rx_nb = 0;
-        if (wide && mt == 8 && M == 8 && m0 == 0 && K >= 256 && plsk::cols_aligned<T>(X, ldx) &&
+        // ... and 1, 2 or 4 responses up to 2,048 columns: the tile walk streams X at 0.85 of peak where xty_kernel's row chunks
+        // reach 0.76 (config 3, one response: 0.708 -> 0.631 ms; 131,072 x 4,096 is faster on the chunks: tools/probe/xty1.py)
+        if (wide && ((mt == 8 && M == 8) || (mt == M && K <= 2048)) && m0 == 0 && K >= 256 && plsk::cols_aligned<T>(X, ldx) &&
             plsk::launch_retile_xty<T, 32>(c->stream, c->num_cu, X, ldx, Y, ldy, (T *)nullptr, 0, 0, 0, N, K, M, part,
                                            (int)max_partial_rows(c, N, K), &rx_nb) == 0) {
             *nb = rx_nb;
