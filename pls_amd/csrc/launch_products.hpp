@@ -92,6 +92,12 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
     const bool split_shape = K >= 1024 && (N + plsk::WG - 1) / plsk::WG <= (i64)(sizeof(T) == 4 ? 2 : 1) * c->num_cu;
     auto xb4_windowed = [&](int cols) { return sizeof(T) == 4 ? cols <= 20 : (cols > 8 || split_shape); };  // cols: ALL that remain
     const bool xb4_first = xb4_ok && (xb4_resident(std::min(C, sizeof(T) == 8 ? 32 : 24)) || xb4_windowed(C));
+    // 1..4 columns of a TALL matrix (fitted values of a few responses; no sum of squares asked for): the resident form with one
+    // column group -- three quarters of its MFMAs are padding and free; what counts is the tile walk (config 3, one column:
+    // 0.71 -> 0.67 ms; fp32 0.41 -> 0.34)
+    const bool xb4_few = c->env.xb4 && C <= 4 && !sspart && vec_ok<T>(X, ldx, FV) && vec_ok<T>(out, ldo, FV) && K >= 128 &&
+                         36 * std::max(ldx, ldo) * (i64)sizeof(T) < ((i64)1 << 31) && (i64)N * K * (i64)sizeof(T) >= ((i64)32 << 20) &&
+                         xb4_resident(4);
     // VERY short and wide (fewer 16 FV-row tiles than CUs: 2,000 x 20,000, a usual shape of the method), 5 columns or more: the
     // windowed MFMA kernel with the columns split over blockIdx.y as well, fp64 partial sums, xb_split_finish_kernel behind it --
     // one sweep of X for up to 32 columns where the split path below makes one per 4
@@ -148,7 +154,7 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
         }
         if (ok) return PLS_HIP_OK;
     }
-    if (N > 0 && K >= 1024 && !many && !xb4_first) {
+    if (N > 0 && K >= 1024 && !many && !xb4_first && !xb4_few) {
         const bool v2 = vec_ok<T>(X, ldx, FV) && (N + (i64)FV * plsk::WG - 1) / ((i64)FV * plsk::WG) >= 8;
         const i64 per = (i64)plsk::WG * (v2 ? FV : 1);
         const i64 rg = (N + per - 1) / per;
@@ -208,7 +214,7 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
                 continue;
             }
         }
-        if (rem > 4 && xb4_ok) {
+        if ((rem > 4 && xb4_ok) || xb4_few) {
             // 5..32 columns (fp32 storage: ..24) with all of Bm in LDS: the 4 x 4 x 4 MFMA form, columns padded to 4 (xb_mfma4.hpp)
             const int use = std::min(rem, sizeof(T) == 8 ? 32 : 24);
             const int ncg = (use + 3) / 4;
@@ -219,7 +225,7 @@ int launch_xb(pls_hip_context *c, const T *X, i64 ldx, i64 N, int K, const doubl
                 const void *fn = nullptr;
 #define XB4_CASE(G_) case G_: fn = (const void *)plsk::xb_mfma4_kernel<T, FV, G_>; break;
                 switch (ncg) {
-                    XB4_CASE(2) XB4_CASE(3) XB4_CASE(4) XB4_CASE(5) XB4_CASE(6)
+                    XB4_CASE(1) XB4_CASE(2) XB4_CASE(3) XB4_CASE(4) XB4_CASE(5) XB4_CASE(6)
                     default:
                         if constexpr (sizeof(T) == 8) {
                             switch (ncg) { XB4_CASE(7) XB4_CASE(8) default: break; }

@@ -17,7 +17,7 @@ if len(sys.argv) > 2: shapes = shapes[:int(sys.argv[2])]
 for dt, N, K in shapes:
     es = 8 if dt == torch.float64 else 4
     X = hs[0].synth_x(0, N, K, 5, dtype=dt)
-    for C in (5, 8, 12, 16, 20, 24, 32):
+    for C in (1, 2, 4, 5, 8, 12, 16, 20, 24, 32):
         B = pls_amd.as_colmajor(torch.randn(K, C, dtype=torch.float64, device="cuda"))
         ref = None
         row = "xb %s N=%8d K=%5d C=%3d " % ("f64" if es == 8 else "f32", N, K, C)
