@@ -95,8 +95,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                              : M <= 2 ? (const void *)plsk::resident_gram_fit_kernel<T, 2>
                              : M <= 4 ? (const void *)plsk::resident_gram_fit_kernel<T, 4>
                                       : (const void *)plsk::resident_gram_fit_kernel<T, 8>;
-            if (!plsk::raise_dynamic_lds(fn, (int)lds))
-                return fail(c, PLS_HIP_ERR_DEVICE, "dynamic LDS limit of the resident fit could not be raised");
+            if (plsk::raise_dynamic_lds(fn, (int)lds)) {  // (refused: the per-component resident kernels below take the fit)
             if (!c->rgflags.p) {
                 CHK(ensure(c, c->rgflags, (size_t)plsk::RESIDENT_MAX_WG * 4));
                 HIPCHK(c, hipMemsetAsync(c->rgflags.p, 0, (size_t)plsk::RESIDENT_MAX_WG * 4, c->stream));
@@ -127,6 +126,7 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
             }
             resident_done(c);
             return PLS_HIP_OK;
+            }
         }
     }
     // Mid-size single-response data (beyond one workgroup's 1024 rows, up to ~50 MB): the same single launch on up to 256

@@ -36,7 +36,7 @@ namespace plsk {
 constexpr int RG_KMAX = 128;
 constexpr int RG_ACH = 8;        // score columns per pass of phase 4
 constexpr int RG_SMALL = 512 + 4 * RG_KMAX + 16;  // partial sums of XX r (or of a slice), r, the p_j^T w, w, q: doubles of dynamic LDS behind the big block
-constexpr int RG_LDS_DOUBLES = 20416;          // what one workgroup may ask for (160 KB less the static few)
+constexpr int RG_LDS_DOUBLES = 20384;          // what one workgroup may ask for (160 KB less the static few and a margin)
 constexpr i64 RG_DIRECT = 32768;               // G (K^2 + K) at or below this: workgroup 0 sums the parts itself (no hand-off 2)
 
 struct ResidentGram {
