@@ -87,7 +87,7 @@ struct pls_hip_context {
         bool tiny = true, cv_refit = false, tail = true, replica_guard = true, resident = true;
         int tail_update = 1;  // 0: never, 1: in the tail of READ-ONLY passes (default), 2: of every pass
         int xb4 = 1;          // PLS_HIP_XB4=0: X B with 5..32 columns on the older kernels
-        int resident_gram = 1;  // PLS_HIP_RESIDENT_GRAM=0: AUTO's mid-size fits on the per-component resident kernels; 2: also under KERNEL (measurements)
+        int resident_gram = 1;  // PLS_HIP_RESIDENT_GRAM=0: AUTO's mid-size fits on the per-component resident kernels; 2: also under KERNEL (measurements); 4: the row form of its first phase everywhere
     } env;
     // replica guard of sharded fits (small_kernels.hpp): host-mapped flag "the ranks derived different W/P/Q/R/B"
     int *diverged = nullptr, *diverged_dev = nullptr;

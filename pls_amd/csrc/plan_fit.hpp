@@ -75,8 +75,18 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
         int G = plsk::resident_gram_grid(N, K, M, A, ldx, sizeof(T), c->num_cu);
         if (G > 0 && host_flags(c)) {
             plsk::ResidentGram rg;
-            rg.rows_per = (int)(((N + G - 1) / G + 3) & ~(i64)3);
-            G = (int)((N + rg.rows_per - 1) / rg.rows_per);
+            // the block form of phase 1 where it pays (PLS_HIP_RESIDENT_GRAM=4: the row form everywhere)
+            rg.rs = c->env.resident_gram == 4 ? 0 : plsk::resident_gram_splits(N, K, M, c->num_cu, vec_ok<T>(X, ldx, 16 / (int)sizeof(T)) && vec_ok<T>(Y, ldy, 16 / (int)sizeof(T)));
+            if (rg.rs > 0) {
+                const int nb = (K + 15) / 16;
+                rg.brows = (int)(((N + rg.rs - 1) / rg.rs + 15) & ~(i64)15);
+                rg.rs = (int)((N + rg.brows - 1) / rg.brows);
+                G = (nb * (nb + 1) / 2 + nb) * rg.rs;
+                rg.rows_per = (int)(((N + G - 1) / G + 3) & ~(i64)3);  // (phase 4: a workgroup beyond N has no rows)
+            } else {
+                rg.rows_per = (int)(((N + G - 1) / G + 3) & ~(i64)3);
+                G = (int)((N + rg.rows_per - 1) / rg.rows_per);
+            }
             rg.LP = ((i64)K * K + (i64)K * M + 7) & ~(i64)7;
             rg.big = plsk::resident_gram_big(K);
             {  // many rows per workgroup and room in LDS: twice the rows staged at a time
@@ -91,7 +101,8 @@ int fit_device(pls_hip_context *c, const T *X, i64 ldx, const T *Y, i64 ldy, i64
                 c->resident_launches = 0;
             }
             const size_t lds = ((size_t)rg.big + plsk::RG_SMALL + (size_t)plsk::resident_gram_extra(K, M, A)) * 8;
-            const void *fn = M <= 1   ? (const void *)plsk::resident_gram_fit_kernel<T, 1>
+            const void *fn = rg.rs > 0 ? (M <= 1 ? (const void *)plsk::resident_gram_fit_kernel<T, 1, true> : (const void *)plsk::resident_gram_fit_kernel<T, 2, true>)
+                             : M <= 1 ? (const void *)plsk::resident_gram_fit_kernel<T, 1>
                              : M <= 2 ? (const void *)plsk::resident_gram_fit_kernel<T, 2>
                              : M <= 4 ? (const void *)plsk::resident_gram_fit_kernel<T, 4>
                                       : (const void *)plsk::resident_gram_fit_kernel<T, 8>;

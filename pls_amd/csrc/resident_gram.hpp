@@ -1,5 +1,5 @@
-// resident_gram.hpp -- the whole fit of a mid-size problem with K <= 128 columns in ONE launch and THREE grid-wide hand-offs,
-// whatever the number of components (round 5).
+// resident_gram.hpp -- the whole fit of a mid-size problem with K <= 128 columns in ONE launch and THREE (block form: TWO)
+// grid-wide hand-offs, whatever the number of components (round 5).
 //
 // resident_fit_kernel (resident_kernels.hpp) keeps X in registers and exchanges [X^T t, t^T t] once per COMPONENT: 10-13 us
 // each, of which the exchange is 5-6 (a store, an arrival, a poll and a gather: four trips over the fabric on a chip that
@@ -10,6 +10,11 @@
 //      (a wave per pair of 16-column blocks), stores it sc1;                                          -- hand-off 1 --
 //   2. every workgroup sums a SLICE of the K^2 + K values over the G parts, in workgroup order         -- hand-off 2 --
 //      (G (K^2 + K) <= 32,768: workgroup 0 sums them itself and the hand-off is saved);
+//      BLOCK form of 1 and 2 (48 columns and more, 16-byte-aligned columns; resident_gram_splits): workgroup (block pair, row
+//      split) forms ONE 16 x 16 block over its rows from 4-row packs straight out of global memory (no staging, no barrier in
+//      the loop), stores 256 values, and workgroup 0 adds the RS splits of the lower block triangle itself with 16-byte loads:
+//      TWO hand-offs in all.  5,000 x 128, A = 10: XX in workgroup 0's LDS at 20.5 us instead of 33.5, the fit 63.5 us
+//      instead of 76 (profiles/r5/resident_gram_stamps.txt, resident_gram_block_ab.txt);
 //   3. workgroup 0 alone, XX and every p_j, r_j in LDS: for every component XX r (a wave per output), r^T XX r, q, p, the
 //      XY deflation, w, the r recurrence (the single-launch kernels' update: thread k owns column k); B = R Q^T; R goes
 //      out sc1;                                                                                       -- hand-off 3 --
@@ -49,6 +54,8 @@ struct ResidentGram {
     i64 LP = 0;
     int rows_per = 0;          // rows per workgroup (a multiple of 4)
     int big = 0;               // doubles of the big LDS block: XX, or the staged rows, or the score partials
+    int rs = 0;                // block form (resident_gram_splits): row splits per block pair, 0 = the row form
+    int brows = 0;             //   rows per split (a multiple of 16)
 };
 
 // doubles of the big LDS block: XX and XY (a workgroup's part on its way out); 16 x RG_ACH x 64 score partials; at least 32 staged rows
@@ -74,6 +81,21 @@ inline int resident_gram_grid(i64 N, int K, int M, int A, i64 ldx, size_t es, in
     i64 G = std::min<i64>(std::min<i64>(num_cu, RESIDENT_MAX_WG), N / (K >= 64 ? 32 : 64));  // (few columns: the hand-offs cost more than the product)
     G = std::min<i64>(G, std::max<i64>(8, (i64)2500000 / L));
     return (int)std::max<i64>(G, 2);
+}
+
+// The BLOCK form of phase 1 (0: not taken; else the row splits RS): workgroup (pair, split) forms ONE 16 x 16 block of XX (or of XY)
+// over its split of the rows, operands straight from global memory in 4-row packs (whole 128-byte lines, no staging, no barrier in
+// the loop) and stores 256 values -- not K^2 + K M: nothing to drain before the hand-off, and workgroup 0 adds the RS splits of
+// the lower block triangle itself: no slices, no second hand-off.  X is read nb + 1 times, from L2.
+inline int resident_gram_splits(i64 N, int K, int M, int num_cu, bool vec) {
+    if (!vec || K < 48 || M > 2) return 0;  // (more responses: the eigen solver's loop came out 25 % slower in the kernel that holds both forms, and the
+                                            //  block form instantiated for it gained nothing at 8,000 x 100 with 8: 78.7 against 78.5 us)
+    const int nb = (K + 15) / 16, nxx = nb * (nb + 1) / 2, npairs = nxx + nb;
+    i64 rs = std::min<i64>(std::min<i64>(num_cu, RESIDENT_MAX_WG) / npairs, N / 256);
+    rs = std::min<i64>(rs, 49152 / ((i64)nxx * 256));  // what workgroup 0 reads: RS x the lower triangle
+    if (rs > 4) rs &= ~(i64)3;                          //   (four splits per round of its loads)
+    if ((i64)N * (nb + 1) * K > (i64)32 << 20) return 0;  // (elements through L2: beyond this the row form's single read -- 50,000 x 100, 8 responses: 174 against 169 us)
+    return rs >= 2 ? (int)rs : 0;
 }
 
 // A grid-wide hand-off without a shared counter: every wave's sc1 stores are complete (vmcnt(0)) before the barrier behind which
@@ -124,7 +146,7 @@ __device__ __forceinline__ bool resident_gram_barrier(const ResidentGram &rg, un
 
 // X: N x K (ld ldx), Y: N x M (ld ldy), M <= MM; W, P, R: K x A; Q: M x A; Tm: N x A (ld ldt); B: K x M or null.
 // grid = G workgroups of 1024 threads; dynamic LDS: rg.big + RG_SMALL + resident_gram_extra(K, M, A) doubles.
-template <typename T, int MM>
+template <typename T, int MM, bool BLK = false>  // BLK: the block form of phases 1-2 (rg.rs > 0)
 __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T *__restrict__ X, i64 ldx, const T *__restrict__ Y, i64 ldy, i64 N,
                                                                         int K, int M, int A, int power_iters, double *__restrict__ W,
                                                                         double *__restrict__ P, double *__restrict__ Q, double *__restrict__ R,
@@ -184,75 +206,135 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
         bi = rest;
         bj = nb;
     };
-    // (loading the NEXT chunk into registers behind this chunk's MFMAs was tried: sixteen guarded loads per thread whatever the
-    // chunk cost 5 us more than the waits they hid)
-    for (i64 c0 = r0; c0 < r1; c0 += chunk) {
-        const int rc = (int)min((i64)chunk, r1 - c0), rc4 = (rc + 3) & ~3;
-        __syncthreads();  // the previous chunk has been read
-        for (int base = 0; base < chunk * KP; base += 8 * UPD_THREADS) {  // consecutive threads: consecutive rows of one column; eight loads in flight
-            double v[8];
+    const int nxx = nb * (nb + 1) / 2;            // the (bi <= bj) pairs
+    if constexpr (BLK) {
+        // ---- 1 (block form). workgroup (pair, split): ONE block over the split's rows.  Lane (li, lk) of a wave holds the 4-row pack
+        //      rows 16 t + 4 lk .. + 3 of column li of both blocks (the k index of the MFMA is only summed over: step e takes row e of
+        //      every lane's pack) -- whole 128-byte lines per column, no staging.  The 16 waves' sums meet in LDS in wave order. ----
+        constexpr int PV = 16 / (int)sizeof(T), NPK = 4 / PV;  // 16-byte packs per lane and batch
+        const int pr = g % npairs, sp2 = g / npairs;
+        int bi, bj;
+        pair_of(pr, bi, bj);
+        const i64 b0 = (i64)sp2 * rg.brows, b1 = min(N, b0 + (i64)rg.brows);
+        const T *ca = bi * 16 + li < K ? X + (i64)(bi * 16 + li) * ldx : nullptr;
+        const T *cb = bj < nb ? (bj * 16 + li < K ? X + (i64)(bj * 16 + li) * ldx : nullptr) : (li < M ? Y + (i64)li * ldy : nullptr);
+        const bool same = bi == bj;
+        auto ld4 = [&](const T *col, i64 row, double (&o)[4]) {
+            if (col != nullptr && row + 4 <= b1) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * UPD_THREADS + tid, row = idx & (chunk - 1), col = idx >> clg;
-                v[u] = 0.0;
-                if (col < KP && row < rc) {
-                    if (col < K) v[u] = (double)X[c0 + row + (i64)col * ldx];
-                    else if (col >= nb * 16 && col - nb * 16 < M) v[u] = (double)Y[c0 + row + (i64)(col - nb * 16) * ldy];
+                for (int h = 0; h < NPK; ++h) {
+                    const Pack<T, PV> pk = ld_pack<T, PV>(col + row + h * PV);
+#pragma unroll
+                    for (int e = 0; e < PV; ++e) o[h * PV + e] = (double)pk.v[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (col != nullptr && row + e < b1) ? (double)col[row + e] : 0.0;
+            }
+        };
+        f64x4 ac = f64x4{0.0, 0.0, 0.0, 0.0};
+        i64 row = b0 + (i64)wv * 16 + 4 * lk;
+        if (sp2 < rg.rs) {
+            for (; row - 4 * lk + 16 * UPD_WAVES < b1; row += 2 * 16 * UPD_WAVES) {  // two batches in flight
+                double a0[4], a1[4], c0[4], c1[4];
+                ld4(ca, row, a0);
+                ld4(ca, row + 16 * UPD_WAVES, a1);
+                if (!same) {
+                    ld4(cb, row, c0);
+                    ld4(cb, row + 16 * UPD_WAVES, c1);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ac = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], same ? a0[e] : c0[e], ac, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ac = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], same ? a1[e] : c1[e], ac, 0, 0, 0);
+            }
+            if (row - 4 * lk < b1) {
+                double a0[4], c0[4];
+                ld4(ca, row, a0);
+                if (!same) ld4(cb, row, c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ac = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], same ? a0[e] : c0[e], ac, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) big[(wv * 4 + q) * WAVE + lane] = ac[q];
+        __syncthreads();
+        if (tid < 256 && sp2 < rg.rs) {
+            double t = 0.0;
+            for (int w = 0; w < UPD_WAVES; ++w) t += big[(w * 4 + (tid >> 6)) * WAVE + (tid & 63)];
+            st_agent(rg.part + ((i64)sp2 * npairs + pr) * 256 + tid, t);  // element q 64 + lane of the block: row lk + 4 q, column li
+        }
+    } else {
+        // (loading the NEXT chunk into registers behind this chunk's MFMAs was tried: sixteen guarded loads per thread whatever the
+        // chunk cost 5 us more than the waits they hid)
+        for (i64 c0 = r0; c0 < r1; c0 += chunk) {
+            const int rc = (int)min((i64)chunk, r1 - c0), rc4 = (rc + 3) & ~3;
+            __syncthreads();  // the previous chunk has been read
+            for (int base = 0; base < chunk * KP; base += 8 * UPD_THREADS) {  // consecutive threads: consecutive rows of one column; eight loads in flight
+                double v[8];
+    #pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * UPD_THREADS + tid, row = idx & (chunk - 1), col = idx >> clg;
+                    v[u] = 0.0;
+                    if (col < KP && row < rc) {
+                        if (col < K) v[u] = (double)X[c0 + row + (i64)col * ldx];
+                        else if (col >= nb * 16 && col - nb * 16 < M) v[u] = (double)Y[c0 + row + (i64)(col - nb * 16) * ldy];
+                    }
+                }
+    #pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * UPD_THREADS + tid, row = idx & (chunk - 1), col = idx >> clg;
+                    if (col < KP && row < rc4) big[row * KP + col] = v[u];
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * UPD_THREADS + tid, row = idx & (chunk - 1), col = idx >> clg;
-                if (col < KP && row < rc4) big[row * KP + col] = v[u];
+            __syncthreads();
+            const double *ap[MAXP], *bp[MAXP];
+    #pragma unroll
+            for (int p = 0; p < MAXP; ++p) {
+                int bi = 0, bj = 0;
+                if (task + p * UPD_WAVES < npairs) pair_of(task + p * UPD_WAVES, bi, bj);
+                ap[p] = big + lk * KP + bi * 16 + li;
+                bp[p] = big + lk * KP + bj * 16 + li;
             }
+            if (tact)
+                for (int r = 4 * rsp; r < rc4; r += 4 * RSPL) {  // the wave's (up to) three accumulation chains side by side
+    #pragma unroll
+                    for (int p = 0; p < MAXP; ++p)
+                        if (task + p * UPD_WAVES < npairs) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[p][r * KP], bp[p][r * KP], acc[p], 0, 0, 0);
+                }
         }
-        __syncthreads();
-        const double *ap[MAXP], *bp[MAXP];
-#pragma unroll
+        if (RSPL > 1) {  // the row splits of a pair meet in LDS, in split order (the staged rows are done with)
+            __syncthreads();
+            if (tact && rsp > 0) {
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) big[(wv * 4 + q) * WAVE + lane] = acc[0][q];
+            }
+            __syncthreads();
+            if (tact && rsp == 0)
+                for (int s2 = 1; s2 < RSPL; ++s2)
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[0][q] += big[((s2 * npairs + task) * 4 + q) * WAVE + lane];
+        }
+        // D: lane holds rows (lane >> 4) + 4 q, column lane & 15 of the 16 x 16 block (assembling the part in LDS for consecutive stores
+        // was tried: two barriers and a store loop cost more than the scattered stores, 19 -> 25 us at K = 128)
+    #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
-            int bi = 0, bj = 0;
-            if (task + p * UPD_WAVES < npairs) pair_of(task + p * UPD_WAVES, bi, bj);
-            ap[p] = big + lk * KP + bi * 16 + li;
-            bp[p] = big + lk * KP + bj * 16 + li;
-        }
-        if (tact)
-            for (int r = 4 * rsp; r < rc4; r += 4 * RSPL) {  // the wave's (up to) three accumulation chains side by side
-#pragma unroll
-                for (int p = 0; p < MAXP; ++p)
-                    if (task + p * UPD_WAVES < npairs) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[p][r * KP], bp[p][r * KP], acc[p], 0, 0, 0);
-            }
-    }
-    if (RSPL > 1) {  // the row splits of a pair meet in LDS, in split order (the staged rows are done with)
-        __syncthreads();
-        if (tact && rsp > 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) big[(wv * 4 + q) * WAVE + lane] = acc[0][q];
-        }
-        __syncthreads();
-        if (tact && rsp == 0)
-            for (int s2 = 1; s2 < RSPL; ++s2)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[0][q] += big[((s2 * npairs + task) * 4 + q) * WAVE + lane];
-    }
-    // D: lane holds rows (lane >> 4) + 4 q, column lane & 15 of the 16 x 16 block (assembling the part in LDS for consecutive stores
-    // was tried: two barriers and a store loop cost more than the scattered stores, 19 -> 25 us at K = 128)
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-        const int idx = task + p * UPD_WAVES;
-        if (idx < npairs && rsp == 0) {
-            int bi, bj;
-            pair_of(idx, bi, bj);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = bi * 16 + lk + 4 * q, j = (bj < nb ? bj * 16 : 0) + li;
-                const double v = acc[p][q];
-                if (bj < nb) {
-                    if (i < K && j < K) {
-                        st_agent(mine + i + (i64)j * K, v);
-                        if (bi != bj) st_agent(mine + j + (i64)i * K, v);
+            const int idx = task + p * UPD_WAVES;
+            if (idx < npairs && rsp == 0) {
+                int bi, bj;
+                pair_of(idx, bi, bj);
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = bi * 16 + lk + 4 * q, j = (bj < nb ? bj * 16 : 0) + li;
+                    const double v = acc[p][q];
+                    if (bj < nb) {
+                        if (i < K && j < K) {
+                            st_agent(mine + i + (i64)j * K, v);
+                            if (bi != bj) st_agent(mine + j + (i64)i * K, v);
+                        }
+                    } else if (i < K && li < M) {
+                        st_agent(mine + (i64)K * K + i + (i64)li * K, v);
                     }
-                } else if (i < K && li < M) {
-                    st_agent(mine + (i64)K * K + i + (i64)li * K, v);
                 }
             }
         }
@@ -275,7 +357,21 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
         for (; h < G; ++h) s += ld_sc1(rg.part + (i64)h * rg.LP, j);
         return s;
     };
-    if (!direct) {
+    auto sum_blk = [&](int p, int e) -> double {  // block form: element e of pair p over the row splits, in split order
+        double t = 0.0;
+        for (int h = 0; h < rg.rs; h += 8) {  // eight loads in flight
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = h + u < rg.rs ? ld_sc1(rg.part, ((i64)(h + u) * npairs + p) * 256 + e) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += x[u];
+        }
+        return t;
+    };
+    auto xy_blk = [&](int m, int kk) -> double {  // XY(kk, m): row kk % 16 of the block (kk / 16, Y), column m
+        return sum_blk(nxx + (kk >> 4), ((kk & 15) >> 2) * 64 + (kk & 3) * 16 + m);
+    };
+    if (!BLK && !direct) {
         // the slice's S values: NS = 512 / LW workgroup subsets per value (LW = S rounded up to whole waves, at most 512 at a time):
         // thread (e, hs) adds the parts hs, hs + NS, ... in that order, then the NS sums meet in order -- fixed, whatever the run
         const i64 S = (L + G - 1) / G, j0 = (i64)g * S, j1 = min(L, j0 + S);
@@ -312,7 +408,52 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
         const int k = tid;
         const bool kok = k < K;
         const int KW = K <= WAVE ? WAVE : 2 * WAVE, NJG = 512 / KW, JL = (K + NJG - 1) / NJG, kq = tid % KW, jg = tid / KW;
-        if (direct) {
+        if constexpr (BLK) {  // the lower block triangle, mirrored: four element pairs (16-byte loads) x four splits in flight per thread
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(rg.part, (short)0, 0x7fffffff, BUF_WORD3);
+            for (int base = 0; base < nxx * 128; base += 4 * UPD_THREADS) {
+                double v[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u][0] = v[u][1] = 0.0;
+                for (int h = 0; h < rg.rs; h += 4) {
+                    u32x4 x[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i2 = base + u * UPD_THREADS + tid;  // pair i2: elements 2 (i2 % 128), + 1 of block pair i2 / 128
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            x[u][q] = (i2 < nxx * 128 && h + q < rg.rs)
+                                          ? __builtin_amdgcn_raw_buffer_load_b128(rp, (uint32_t)((((h + q) * npairs + (i2 >> 7)) * 256 + 2 * (i2 & 127)) * 8), 0, AUX_SC1)
+                                          : u32x4{0u, 0u, 0u, 0u};
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            double d[2];
+                            __builtin_memcpy(d, &x[u][q], 16);
+                            v[u][0] += d[0];
+                            v[u][1] += d[1];
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i2 = base + u * UPD_THREADS + tid;
+                    if (i2 < nxx * 128) {
+                        int bi, bj;
+                        pair_of(i2 >> 7, bi, bj);
+#pragma unroll
+                        for (int z = 0; z < 2; ++z) {
+                            const int e = 2 * (i2 & 127) + z, i = bi * 16 + ((e >> 4) & 3) + 4 * (e >> 6), j = bj * 16 + (e & 15);
+                            if (i < K && j < K) {
+                                big[i + j * K] = ok ? v[u][z] : __builtin_nan("");
+                                if (bi != bj) big[j + i * K] = ok ? v[u][z] : __builtin_nan("");
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (direct) {
             for (i64 j = tid; j < (i64)K * K; j += UPD_THREADS) big[j] = ok ? sum_parts(j) : __builtin_nan("");
         } else {
             for (int j0 = 0; j0 < K * K; j0 += 16 * UPD_THREADS) {  // sixteen loads in flight per lane
@@ -330,7 +471,7 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
             }
         }
         if constexpr (MM == 1) {
-            double xyk = kok ? (direct ? sum_parts((i64)K * K + k) : ld_sc1(rg.gred, (i64)K * K + k)) : 0.0;  // XY = X^T Y (:396)
+            double xyk = kok ? (BLK ? xy_blk(0, k) : direct ? sum_parts((i64)K * K + k) : ld_sc1(rg.gred, (i64)K * K + k)) : 0.0;  // XY = X^T Y (:396)
             auto bsum = [&](double v) -> double {  // block sum on lds_barrier (every thread calls it)
                 v = wave_sum(v);
                 lds_barrier();
@@ -433,7 +574,7 @@ __global__ __launch_bounds__(UPD_THREADS) void resident_gram_fit_kernel(const T 
         } else {
             // ---- 2..8 responses: the direction by the one-wave eigen solver (src/pls.cpp:403-411), ONE product XX r per component ----
             for (int m = 0; m < MM; ++m)
-                if (kok) xyl[m * K + k] = m < M ? (direct ? sum_parts((i64)K * K + (i64)m * K + k) : ld_sc1(rg.gred, (i64)K * K + (i64)m * K + k)) : 0.0;
+                if (kok) xyl[m * K + k] = m < M ? (BLK ? xy_blk(m, k) : direct ? sum_parts((i64)K * K + (i64)m * K + k) : ld_sc1(rg.gred, (i64)K * K + (i64)m * K + k)) : 0.0;
             RG_STAMP(4);
             for (int a = 0; a < A; ++a) {
                 lds_barrier();  // XY complete (and XX in LDS)

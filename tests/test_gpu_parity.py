@@ -1053,12 +1053,14 @@ def test_resident_single_launch_fit(handle, oracle, po, N, K, A, dt, pad, M):
                                             (100000, 40, 12, "f64", 0, 1), (262144, 26, 4, "f64", 0, 1), (3001, 77, 7, "f32", 5, 1), (70000, 50, 9, "f32", 0, 1),
                                             (2050, 64, 32, "f64", 0, 1), (1500, 100, 20, "f64", 0, 1), (8000, 100, 5, "f64", 0, 1), (300, 90, 6, "f64", 0, 1),
                                             (1025, 26, 5, "f64", 0, 3), (5000, 100, 8, "f64", 2, 4), (100000, 40, 12, "f64", 0, 8), (3001, 77, 7, "f32", 1, 5),
-                                            (2000, 120, 6, "f64", 0, 2), (9000, 128, 9, "f64", 0, 7)])
+                                            (2000, 120, 6, "f64", 0, 2), (9000, 128, 9, "f64", 0, 7), (7001, 96, 6, "f32", 3, 3), (5001, 112, 7, "f64", 0, 2),
+                                            (4000, 48, 5, "f64", 0, 1), (100000, 64, 8, "f64", 0, 1)])
 def test_resident_gram_single_launch_fit(handle, oracle, po, N, K, A, dt, pad, M):
     """AUTO on mid-size data (1..8 responses) with at most 128 columns: ONE launch with three grid-wide hand-offs whatever A
     (resident_gram.hpp: X^T X and X^T Y on the matrix cores, the component loop on XX in one workgroup's LDS, the scores at the
     end).  Row counts that leave ragged last workgroups, a padded leading dimension, fp32 storage, the direct and the sliced
-    sum of the parts, as many components as the LDS holds: against the oracle and the general plan, one launch in all, repeated
+    sum of the parts, both forms of the first phase (48 columns and more with 16-byte-aligned columns: a 16 x 16 block of XX per
+    workgroup and row split; an odd leading dimension keeps the row form), as many components as the LDS holds: against the oracle and the general plan, one launch in all, repeated
     fits equal bit for bit; PLS_HIP_RESIDENT_GRAM=0 gives the per-component resident kernel."""
     import pls_amd
     torch = _torch()
